@@ -1,0 +1,196 @@
+/*
+ * prl_hip.h — C ABI of the MI355X (gfx950) implementation of PRLib's local-adaptive
+ * binarization hot path and its NL-means pre-stage.
+ *
+ * This is the drop-in boundary: everything above it (the prl::binarize*(cv::Mat&, cv::Mat&, ...)
+ * wrappers in prlib_amd/csrc/prl/, the ctypes binding in prlib_amd/_capi.py) only marshals
+ * pointers, sizes and strides.  No C++ or torch types appear in any signature.
+ *
+ * Reference interfaces replaced (paths relative to the PRLib tree):
+ *   prl::binarizeSauvola     src/binarizations/binarizeSauvola.h:43-47     .cpp:32-134
+ *   prl::binarizeNiblack     src/binarizations/binarizeNiblack.h:43-47     .cpp:32-127
+ *   prl::binarizeWolfJolion  src/binarizations/binarizeWolfJolion.h:43-47  .cpp:33-148
+ *   prl::binarizeNICK        src/binarizations/binarizeNICK.h:43-47        .cpp:33-144
+ *   prl::binarizeFeng        src/binarizations/binarizeFeng.h:46-53        .cpp:31-164
+ *   prl::denoise             src/denoise/denoiseNLM.h:32                   .cpp:29-32
+ *
+ * Conventions
+ *   - Images are 8-bit, row-major, `step` bytes between row starts (step >= width*channels),
+ *     exactly cv::Mat's (data, step, rows, cols) view.
+ *   - `*_device` entry points take DEVICE pointers and a hipStream_t (passed as void*; NULL = the
+ *     null stream); they enqueue work and return without synchronising unless stated.
+ *   - `*_host` entry points take HOST pointers, stage through the device and return when the
+ *     result is in the caller's buffer.
+ *   - All functions return PRL_OK (0) or a prl_status error; prl_hip_strerror() explains it and
+ *     prl_hip_last_error_detail() carries the HIP runtime message for PRL_ERR_HIP.
+ *   - The library never falls back to a CPU implementation.  Without a usable gfx950 device every
+ *     compute entry point fails with PRL_ERR_NO_DEVICE.
+ */
+#ifndef PRL_HIP_H_
+#define PRL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRL_HIP_ABI_VERSION 1
+
+typedef enum prl_status {
+    PRL_OK = 0,
+    PRL_ERR_EMPTY = 1,       /* empty input image: reference throws std::invalid_argument (binarizeSauvola.cpp:38-41) */
+    PRL_ERR_BAD_WINDOW = 2,  /* !(windowSize > 1 && windowSize odd): std::invalid_argument (binarizeSauvola.cpp:43-47) */
+    PRL_ERR_BAD_CHANNELS = 3,/* channel count the reference's cvtColor / NLM would reject */
+    PRL_ERR_EMPTY_RECT = 4,  /* processing rectangle has no pixels (reference: cv::Exception from the ROI/filter2D) */
+    PRL_ERR_BAD_ARG = 5,     /* null pointer, step < row bytes, negative count, unknown method ... */
+    PRL_ERR_NO_DEVICE = 6,   /* no gfx950 device / HIP runtime unusable */
+    PRL_ERR_HIP = 7,         /* a HIP call failed; see prl_hip_last_error_detail() */
+    PRL_ERR_NOMEM = 8        /* device or host allocation failed */
+} prl_status;
+
+/* The five local-adaptive binarizers of src/binarizations named by the north star. */
+typedef enum prl_method {
+    PRL_SAUVOLA = 0,     /* T = m * (1 + k*(s/128 - 1))            binarizeSauvola.cpp:115-118   */
+    PRL_NIBLACK = 1,     /* T = m + k*s                             binarizeNiblack.cpp:108       */
+    PRL_WOLFJOLION = 2,  /* T = m + (k*s/max(s) - k)*(m - min(I))   binarizeWolfJolion.cpp:115-130 */
+    PRL_NICK = 3,        /* T = m + k*sqrt(m*m + s*s)               binarizeNICK.cpp:121-126      */
+    PRL_FENG = 4         /* as written in binarizeFeng.cpp:111-142 (Rs aliases s)                */
+} prl_method;
+
+/*
+ * Parameters of one binarization call; field meaning = the reference's default arguments.
+ *   Sauvola / Niblack / WolfJolion: window_size=101, k=0.01, morph_iterations=2
+ *   NICK:                            window_size=21,  k=-0.01, morph_iterations=0
+ *   Feng: window_size=21, feng_alpha1=0.75, feng_k1=0.2, feng_k2=0.03, feng_gamma=2.0, morph=2
+ * prl_hip_default_params() fills these.
+ */
+typedef struct prl_binarize_params {
+    int32_t method;            /* prl_method */
+    int32_t window_size;       /* windowSize: must be > 1 and odd (checked before clamping to min(W,H)) */
+    double  k;                 /* thresholdCoefficient (unused by Feng) */
+    int32_t morph_iterations;  /* >0: dilate^n then erode^n; <0: erode^n then dilate^n; 0: none */
+    int32_t reserved0;
+    double  feng_alpha1;
+    double  feng_k1;           /* dead in the reference (binarizeFeng.cpp:128); carried for signature parity */
+    double  feng_k2;
+    double  feng_gamma;
+} prl_binarize_params;
+
+/* Geometry derived from (params, W, H) exactly as the reference derives it. */
+typedef struct prl_binarize_geometry {
+    int32_t w;        /* effective window = min(windowSize, min(W,H))      binarizeSauvola.cpp:57 */
+    int32_t half;     /* w/2 = replicate padding on each side              binarizeSauvola.cpp:65 */
+    int32_t padded_w; /* W + 2*half : size the caller's input Mat ends up with */
+    int32_t padded_h; /* H + 2*half */
+    int32_t out_w;    /* Sauvola/Niblack: W+2*half-w ; Wolf/NICK/Feng: W-w  (binarizeSauvola.cpp:66 vs binarizeWolfJolion.cpp:69) */
+    int32_t out_h;
+} prl_binarize_geometry;
+
+/* Execution mode of the binarizers (process-wide; default PRL_MODE_AUTO). */
+typedef enum prl_exec_mode {
+    PRL_MODE_AUTO = 0,     /* fused sliding-window kernel + exact fix-up of the few undecided pixels */
+    PRL_MODE_LITERAL = 1   /* materialised float64 integral images, one literal evaluation per pixel */
+} prl_exec_mode;
+
+/* Counters of the last binarize call on the calling thread (for tests and the bench report). */
+typedef struct prl_binarize_stats {
+    uint64_t pixels;            /* output pixels produced */
+    uint64_t refined_pixels;    /* decided by the in-kernel float64 interval test instead of the float32 one */
+    uint64_t exact_pixels;      /* decided by the absolute-integral literal evaluation (fix-up kernel) */
+    uint64_t literal_pages;     /* pages that ran the full literal pipeline */
+    uint64_t reserved[4];
+} prl_binarize_stats;
+
+/* ---- library / device ------------------------------------------------------------------- */
+
+int         prl_hip_abi_version(void);
+const char* prl_hip_strerror(int status);
+const char* prl_hip_last_error_detail(void);           /* thread-local, never NULL */
+int         prl_hip_device_count(int* count);          /* number of visible HIP devices */
+int         prl_hip_set_device(int device);            /* device used by subsequent calls of this thread */
+int         prl_hip_set_exec_mode(int mode);           /* prl_exec_mode */
+int         prl_hip_get_exec_mode(void);
+int         prl_hip_last_stats(prl_binarize_stats* out);
+int         prl_hip_release_workspace(void);           /* free cached device scratch of the current device */
+
+/* ---- binarizers -------------------------------------------------------------------------- */
+
+int prl_hip_default_params(int method, prl_binarize_params* out);
+
+/* Validation + geometry; returns the status the reference's argument checks imply. */
+int prl_hip_binarize_geometry(const prl_binarize_params* p, int width, int height,
+                              prl_binarize_geometry* out);
+
+/*
+ * Binarize n_pages single-channel pages of equal size that already live in device memory.
+ *   d_src        first page; page i starts at d_src + i*src_page_stride
+ *   d_dst        first output page (out_w x out_h, see prl_hip_binarize_geometry); values {0,255}
+ *   stream       hipStream_t or NULL
+ * Enqueues on `stream`; synchronises only if a page needs the literal pipeline.
+ * Replaces the body of prl::binarize{Sauvola,Niblack,WolfJolion,NICK,Feng} after cvtColor.
+ */
+int prl_hip_binarize_batch_device(const prl_binarize_params* p, int n_pages,
+                                  const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                                  int width, int height,
+                                  uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                                  void* stream);
+
+/* Same, pages addressed through host arrays of device pointers (pages need not be contiguous). */
+int prl_hip_binarize_pages_device(const prl_binarize_params* p, int n_pages,
+                                  const uint8_t* const* d_src_pages, size_t src_step,
+                                  int width, int height,
+                                  uint8_t* const* d_dst_pages, size_t dst_step,
+                                  void* stream);
+
+/*
+ * One page from/to host memory (what the cv::Mat wrapper calls).  `src` is 1-channel.
+ * If padded_out != NULL it receives the replicate-padded gray image (padded_w x padded_h) the
+ * reference leaves in the caller's input Mat (binarizeSauvola.cpp:65).
+ */
+int prl_hip_binarize_host(const prl_binarize_params* p,
+                          const uint8_t* src, size_t src_step, int width, int height,
+                          uint8_t* dst, size_t dst_step,
+                          uint8_t* padded_out, size_t padded_step);
+
+/* (2n+1)x(2n+1) rectangular closing (n>0) / opening (n<0) with out-of-image pixels ignored:
+ * the cv::dilate/cv::erode pair at binarizeSauvola.cpp:125-134.  In place is NOT allowed. */
+int prl_hip_morph_batch_device(int morph_iterations, int n_pages,
+                               const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                               int width, int height,
+                               uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                               void* stream);
+
+/* ---- NL-means denoise (prl::denoise -> cv::fastNlMeansDenoisingColored) -------------------- */
+
+/*
+ * Non-local means on interleaved 8-bit planes, template 7x7, search 21x21, integer SSD and
+ * fixed-point weights as in OpenCV's FastNlMeansDenoisingInvoker.
+ *   channels 1: the L plane (h = strength); channels 2: the ab planes (h = 3);
+ *   channels 3: treated as three jointly weighted planes (cv::fastNlMeansDenoising on 8UC3).
+ */
+int prl_hip_nlm_planes_device(int n_pages, int channels, float h,
+                              const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                              int width, int height,
+                              uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                              void* stream);
+
+/*
+ * prl::denoise on BGR (channels=3) or BGRA (channels=4) device pages:
+ * LBGR->Lab, NLM(L, strength), NLM(ab, 3), Lab->LBGR  (denoiseNLM.cpp:31).
+ */
+int prl_hip_denoise_batch_device(int n_pages, int channels, float strength,
+                                 const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                                 int width, int height,
+                                 uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                                 void* stream);
+
+int prl_hip_denoise_host(int channels, float strength,
+                         const uint8_t* src, size_t src_step, int width, int height,
+                         uint8_t* dst, size_t dst_step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRL_HIP_H_ */

@@ -1,0 +1,259 @@
+"""ctypes binding of oracle/libprl_oracle.so (the CPU restatement).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  Nothing under prlib_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libprl_oracle.so")
+
+SAUVOLA, NIBLACK, WOLFJOLION, NICK, FENG = range(5)
+METHOD_NAMES = {SAUVOLA: "sauvola", NIBLACK: "niblack", WOLFJOLION: "wolfjolion", NICK: "nick", FENG: "feng"}
+
+PRL_OK, PRL_ERR_EMPTY, PRL_ERR_BAD_WINDOW, PRL_ERR_BAD_CHANNELS, PRL_ERR_EMPTY_RECT, PRL_ERR_BAD_ARG = range(6)
+
+
+class Params(C.Structure):
+    """struct prl_binarize_params (include/prl_hip.h)."""
+
+    _fields_ = [
+        ("method", C.c_int32),
+        ("window_size", C.c_int32),
+        ("k", C.c_double),
+        ("morph_iterations", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("feng_alpha1", C.c_double),
+        ("feng_k1", C.c_double),
+        ("feng_k2", C.c_double),
+        ("feng_gamma", C.c_double),
+    ]
+
+
+class Geometry(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("w", "half", "padded_w", "padded_h", "out_w", "out_h")]
+
+
+# the reference's default arguments (binarizeSauvola.h:43-47, binarizeNICK.h:43-47, binarizeFeng.h:46-53)
+_DEFAULTS = {
+    SAUVOLA: dict(window_size=101, k=0.01, morph_iterations=2),
+    NIBLACK: dict(window_size=101, k=0.01, morph_iterations=2),
+    WOLFJOLION: dict(window_size=101, k=0.01, morph_iterations=2),
+    NICK: dict(window_size=21, k=-0.01, morph_iterations=0),
+    FENG: dict(window_size=21, k=0.0, morph_iterations=2),
+}
+
+
+def make_params(method: int, window_size=None, k=None, morph_iterations=None,
+                alpha1=0.75, k1=0.2, k2=0.03, gamma=2.0) -> Params:
+    d = dict(_DEFAULTS[method])
+    if window_size is not None:
+        d["window_size"] = window_size
+    if k is not None:
+        d["k"] = k
+    if morph_iterations is not None:
+        d["morph_iterations"] = morph_iterations
+    return Params(method, d["window_size"], d["k"], d["morph_iterations"], 0, alpha1, k1, k2, gamma)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with the committed Makefile (gcc only)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        u8p = C.c_void_p
+        L.prl_oracle_binarize_geometry.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.POINTER(Geometry)]
+        L.prl_oracle_binarize.argtypes = [C.POINTER(Params), u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t]
+        L.prl_oracle_binarize_batch.argtypes = [C.POINTER(Params), C.c_int, u8p, C.c_size_t, C.c_size_t,
+                                                C.c_int, C.c_int, u8p, C.c_size_t, C.c_size_t, C.c_int]
+        L.prl_oracle_threshold_plane.argtypes = [C.POINTER(Params), u8p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.prl_oracle_mean_dev.argtypes = [C.POINTER(Params), u8p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.prl_oracle_morph.argtypes = [C.c_int, u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t]
+        L.prl_oracle_morph.restype = None
+        L.prl_oracle_pad_replicate.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, u8p, C.c_size_t]
+        L.prl_oracle_pad_replicate.restype = None
+        L.prl_oracle_sat_u8.argtypes = [C.c_double]
+        L.prl_oracle_sat_u8.restype = C.c_uint8
+        L.prl_oracle_bgr2gray.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, u8p, C.c_size_t]
+        L.prl_oracle_bgr2gray.restype = None
+        L.prl_oracle_otsu.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t]
+        if hasattr(L, "prl_oracle_nlm_planes"):
+            L.prl_oracle_nlm_weights.argtypes = [C.c_int, C.c_float, C.c_void_p, C.c_int]
+            L.prl_oracle_nlm_planes.argtypes = [C.c_int, C.c_float, u8p, C.c_size_t, C.c_int, C.c_int,
+                                                u8p, C.c_size_t, C.c_int]
+            L.prl_oracle_lbgr2lab.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, u8p, C.c_size_t]
+            L.prl_oracle_lbgr2lab.restype = None
+            L.prl_oracle_lab2lbgr.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t, C.c_int]
+            L.prl_oracle_lab2lbgr.restype = None
+            L.prl_oracle_denoise.argtypes = [C.c_int, C.c_float, u8p, C.c_size_t, C.c_int, C.c_int,
+                                             u8p, C.c_size_t, C.c_int]
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    def __init__(self, status: int):
+        super().__init__(f"oracle status {status}")
+        self.status = status
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def geometry(params: Params, width: int, height: int):
+    g = Geometry()
+    st = lib().prl_oracle_binarize_geometry(C.byref(params), width, height, C.byref(g))
+    return st, g
+
+
+def binarize(img: np.ndarray, params: Params) -> np.ndarray:
+    """One page (H x W uint8, any row stride) -> mask."""
+    assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+    h, w = img.shape
+    st, g = geometry(params, w, h)
+    if st != PRL_OK:
+        raise OracleError(st)
+    out = np.empty((g.out_h, g.out_w), dtype=np.uint8)
+    st = lib().prl_oracle_binarize(C.byref(params), _ptr(img), img.strides[0], w, h, _ptr(out), out.strides[0])
+    if st != PRL_OK:
+        raise OracleError(st)
+    return out
+
+
+def binarize_batch(pages: np.ndarray, params: Params, threads: int = 1) -> np.ndarray:
+    """pages: N x H x W uint8 contiguous."""
+    assert pages.dtype == np.uint8 and pages.ndim == 3 and pages.flags.c_contiguous
+    n, h, w = pages.shape
+    st, g = geometry(params, w, h)
+    if st != PRL_OK:
+        raise OracleError(st)
+    out = np.empty((n, g.out_h, g.out_w), dtype=np.uint8)
+    st = lib().prl_oracle_binarize_batch(C.byref(params), n, _ptr(pages), pages.strides[0], pages.strides[1],
+                                         w, h, _ptr(out), out.strides[0], out.strides[1], threads)
+    if st != PRL_OK:
+        raise OracleError(st)
+    return out
+
+
+def threshold_plane(img: np.ndarray, params: Params) -> np.ndarray:
+    h, w = img.shape
+    st, g = geometry(params, w, h)
+    if st != PRL_OK:
+        raise OracleError(st)
+    t = np.empty((g.out_h, g.out_w), dtype=np.float64)
+    st = lib().prl_oracle_threshold_plane(C.byref(params), _ptr(img), img.strides[0], w, h, _ptr(t))
+    if st != PRL_OK:
+        raise OracleError(st)
+    return t
+
+
+def mean_dev(img: np.ndarray, params: Params):
+    h, w = img.shape
+    st, g = geometry(params, w, h)
+    if st != PRL_OK:
+        raise OracleError(st)
+    m = np.empty((g.out_h, g.out_w), dtype=np.float64)
+    s = np.empty((g.out_h, g.out_w), dtype=np.float64)
+    st = lib().prl_oracle_mean_dev(C.byref(params), _ptr(img), img.strides[0], w, h, _ptr(m), _ptr(s))
+    if st != PRL_OK:
+        raise OracleError(st)
+    return m, s
+
+
+def morph(mask: np.ndarray, iterations: int) -> np.ndarray:
+    assert mask.dtype == np.uint8 and mask.ndim == 2 and mask.strides[1] == 1
+    h, w = mask.shape
+    out = np.empty((h, w), dtype=np.uint8)
+    lib().prl_oracle_morph(iterations, _ptr(mask), mask.strides[0], w, h, _ptr(out), out.strides[0])
+    return out
+
+
+def pad_replicate(img: np.ndarray, half: int) -> np.ndarray:
+    h, w = img.shape
+    out = np.empty((h + 2 * half, w + 2 * half), dtype=np.uint8)
+    lib().prl_oracle_pad_replicate(_ptr(img), img.strides[0], w, h, half, _ptr(out), out.strides[0])
+    return out
+
+
+def sat_u8(v: float) -> int:
+    return int(lib().prl_oracle_sat_u8(float(v)))
+
+
+def bgr2gray(img: np.ndarray) -> np.ndarray:
+    h, w, c = img.shape
+    out = np.empty((h, w), dtype=np.uint8)
+    lib().prl_oracle_bgr2gray(_ptr(img), img.strides[0], w, h, c, _ptr(out), out.strides[0])
+    return out
+
+
+def otsu(img: np.ndarray):
+    h, w = img.shape
+    out = np.empty((h, w), dtype=np.uint8)
+    thr = lib().prl_oracle_otsu(_ptr(img), img.strides[0], w, h, _ptr(out), out.strides[0])
+    return thr, out
+
+
+# ---- NL-means ---------------------------------------------------------------------------------
+
+def nlm_weights(channels: int, h: float, cap: int = 1 << 18) -> np.ndarray:
+    lut = np.zeros(cap, dtype=np.int32)
+    n = lib().prl_oracle_nlm_weights(channels, h, _ptr(lut), cap)
+    return lut[:n].copy()
+
+
+def nlm_planes(img: np.ndarray, h: float, threads: int = 1) -> np.ndarray:
+    """img: H x W (1 plane) or H x W x C (C interleaved planes), uint8."""
+    a = img if img.ndim == 3 else img[:, :, None]
+    a = np.ascontiguousarray(a)
+    hh, ww, c = a.shape
+    out = np.empty_like(a)
+    st = lib().prl_oracle_nlm_planes(c, h, _ptr(a), a.strides[0], ww, hh, _ptr(out), out.strides[0], threads)
+    if st != PRL_OK:
+        raise OracleError(st)
+    return out if img.ndim == 3 else out[:, :, 0]
+
+
+def lbgr2lab(img: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(img)
+    h, w, c = a.shape
+    out = np.empty((h, w, 3), dtype=np.uint8)
+    lib().prl_oracle_lbgr2lab(_ptr(a), a.strides[0], w, h, c, _ptr(out), out.strides[0])
+    return out
+
+
+def lab2lbgr(lab: np.ndarray, channels: int = 3) -> np.ndarray:
+    a = np.ascontiguousarray(lab)
+    h, w, _ = a.shape
+    out = np.empty((h, w, channels), dtype=np.uint8)
+    lib().prl_oracle_lab2lbgr(_ptr(a), a.strides[0], w, h, _ptr(out), out.strides[0], channels)
+    return out
+
+
+def denoise(img: np.ndarray, strength: float, threads: int = 1) -> np.ndarray:
+    a = np.ascontiguousarray(img)
+    h, w, c = a.shape
+    out = np.empty_like(a)
+    st = lib().prl_oracle_denoise(c, strength, _ptr(a), a.strides[0], w, h, _ptr(out), out.strides[0], threads)
+    if st != PRL_OK:
+        raise OracleError(st)
+    return out
