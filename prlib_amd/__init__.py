@@ -1,0 +1,18 @@
+"""prlib_amd — MI355X (gfx950) implementation of PRLib's local-adaptive binarization hot path.
+
+The product is libprlib_hip.so (hand-written HIP kernels behind the C ABI of include/prl_hip.h).
+This package is the thin Python host layer used by the tests and the benchmark; the C++ host layer
+with the reference's prl::binarize*(cv::Mat&, cv::Mat&, ...) signatures lives in csrc/prl/.
+"""
+from . import _capi  # noqa: F401
+from .binarize import (  # noqa: F401
+    FENG, NICK, NIBLACK, SAUVOLA, WOLFJOLION, binarize, binarizeFeng, binarizeNICK, binarizeNiblack,
+    binarizeSauvola, binarizeWolfJolion, default_params, geometry, last_stats, make_params, morph,
+    set_exec_mode,
+)
+
+__all__ = [
+    "binarize", "binarizeSauvola", "binarizeNiblack", "binarizeWolfJolion", "binarizeNICK", "binarizeFeng",
+    "make_params", "default_params", "geometry", "last_stats", "morph", "set_exec_mode",
+    "SAUVOLA", "NIBLACK", "WOLFJOLION", "NICK", "FENG",
+]

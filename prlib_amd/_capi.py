@@ -1,0 +1,113 @@
+"""ctypes binding of libprlib_hip.so — the C ABI declared in include/prl_hip.h.
+
+This module only marshals pointers, sizes and strides.  It never computes: if the shared library
+is missing it raises, and if no gfx950 device is usable the library itself returns
+PRL_ERR_NO_DEVICE.  There is no CPU fallback anywhere in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprlib_hip.so")
+
+PRL_OK = 0
+PRL_ERR_EMPTY = 1
+PRL_ERR_BAD_WINDOW = 2
+PRL_ERR_BAD_CHANNELS = 3
+PRL_ERR_EMPTY_RECT = 4
+PRL_ERR_BAD_ARG = 5
+PRL_ERR_NO_DEVICE = 6
+PRL_ERR_HIP = 7
+PRL_ERR_NOMEM = 8
+
+SAUVOLA, NIBLACK, WOLFJOLION, NICK, FENG = range(5)
+MODE_AUTO, MODE_LITERAL = 0, 1
+
+# every symbol include/prl_hip.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "prl_hip_abi_version", "prl_hip_strerror", "prl_hip_last_error_detail", "prl_hip_device_count",
+    "prl_hip_set_device", "prl_hip_set_exec_mode", "prl_hip_get_exec_mode", "prl_hip_last_stats",
+    "prl_hip_release_workspace", "prl_hip_default_params", "prl_hip_binarize_geometry",
+    "prl_hip_binarize_batch_device", "prl_hip_binarize_pages_device", "prl_hip_binarize_host",
+    "prl_hip_morph_batch_device", "prl_hip_nlm_planes_device", "prl_hip_denoise_batch_device",
+    "prl_hip_denoise_host",
+]
+
+
+class BinarizeParams(C.Structure):
+    """struct prl_binarize_params."""
+
+    _fields_ = [
+        ("method", C.c_int32),
+        ("window_size", C.c_int32),
+        ("k", C.c_double),
+        ("morph_iterations", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("feng_alpha1", C.c_double),
+        ("feng_k1", C.c_double),
+        ("feng_k2", C.c_double),
+        ("feng_gamma", C.c_double),
+    ]
+
+
+class BinarizeGeometry(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("w", "half", "padded_w", "padded_h", "out_w", "out_h")]
+
+
+class BinarizeStats(C.Structure):
+    _fields_ = [
+        ("pixels", C.c_uint64),
+        ("refined_pixels", C.c_uint64),
+        ("exact_pixels", C.c_uint64),
+        ("literal_pages", C.c_uint64),
+        ("reserved", C.c_uint64 * 4),
+    ]
+
+
+class PrlError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). prlib_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+        P = C.POINTER
+        L.prl_hip_strerror.restype = C.c_char_p
+        L.prl_hip_strerror.argtypes = [i]
+        L.prl_hip_last_error_detail.restype = C.c_char_p
+        L.prl_hip_device_count.argtypes = [P(C.c_int)]
+        L.prl_hip_set_device.argtypes = [i]
+        L.prl_hip_set_exec_mode.argtypes = [i]
+        L.prl_hip_last_stats.argtypes = [P(BinarizeStats)]
+        L.prl_hip_default_params.argtypes = [i, P(BinarizeParams)]
+        L.prl_hip_binarize_geometry.argtypes = [P(BinarizeParams), i, i, P(BinarizeGeometry)]
+        L.prl_hip_binarize_batch_device.argtypes = [P(BinarizeParams), i, vp, sz, sz, i, i, vp, sz, sz, vp]
+        L.prl_hip_binarize_pages_device.argtypes = [P(BinarizeParams), i, P(vp), sz, i, i, P(vp), sz, vp]
+        L.prl_hip_binarize_host.argtypes = [P(BinarizeParams), vp, sz, i, i, vp, sz, vp, sz]
+        L.prl_hip_morph_batch_device.argtypes = [i, i, vp, sz, sz, i, i, vp, sz, sz, vp]
+        L.prl_hip_nlm_planes_device.argtypes = [i, i, C.c_float, vp, sz, sz, i, i, vp, sz, sz, vp]
+        L.prl_hip_denoise_batch_device.argtypes = [i, i, C.c_float, vp, sz, sz, i, i, vp, sz, sz, vp]
+        L.prl_hip_denoise_host.argtypes = [i, C.c_float, vp, sz, i, i, vp, sz]
+        _lib = L
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != PRL_OK:
+        L = lib()
+        msg = L.prl_hip_strerror(status).decode()
+        detail = L.prl_hip_last_error_detail().decode()
+        raise PrlError(status, f"{msg}" + (f" [{detail}]" if detail and status in (PRL_ERR_HIP, PRL_ERR_NO_DEVICE, PRL_ERR_NOMEM, PRL_ERR_BAD_ARG) else ""))

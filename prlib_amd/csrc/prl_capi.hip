@@ -1,0 +1,566 @@
+// prl_capi.hip — the extern "C" surface declared in include/prl_hip.h: argument validation with the
+// reference's semantics, per-device workspace, and dispatch to the kernels.
+//
+// There is deliberately no CPU implementation behind any compute entry point: without a usable
+// gfx950 device they return PRL_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "prl_internal.h"
+
+namespace prl_hip {
+
+int init_globals_run(PageGlobals* d_globals, int n_pages, hipStream_t stream);
+
+namespace {
+
+thread_local std::string t_error_detail;
+thread_local int t_device = -1;  // -1: follow hipGetDevice()
+
+struct LastCall {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int n_pages = 0;
+    uint64_t pixels = 0;
+    uint64_t literal_pages = 0;
+    bool valid = false;
+};
+thread_local LastCall t_last;
+
+std::mutex g_ctx_mu;
+std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
+int g_exec_mode = -1;  // -1: read PRL_HIP_MODE once
+
+}  // namespace
+
+void set_error_detail(const std::string& s) { t_error_detail = s; }
+
+int current_device(int* dev)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error_detail(std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0"));
+        (void)hipGetLastError();
+        return PRL_ERR_NO_DEVICE;
+    }
+    int d = t_device;
+    if (d < 0) {
+        if (hipGetDevice(&d) != hipSuccess) return PRL_ERR_NO_DEVICE;
+    } else if (d >= count) {
+        set_error_detail("device index out of range");
+        return PRL_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(d) != hipSuccess) return PRL_ERR_NO_DEVICE;
+    *dev = d;
+    return PRL_OK;
+}
+
+DeviceCtx* device_ctx(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto& p = g_ctx[dev];
+    if (!p) {
+        p.reset(new DeviceCtx());
+        p->device = dev;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) p->cu_count = prop.multiProcessorCount;
+    }
+    return p.get();
+}
+
+int ensure_scratch(DeviceCtx* ctx, size_t bytes)
+{
+    if (ctx->scratch_bytes >= bytes) return PRL_OK;
+    if (ctx->scratch) {
+        PRL_HIP_CHECK(hipDeviceSynchronize());
+        PRL_HIP_CHECK(hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    PRL_HIP_CHECK(hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return PRL_OK;
+}
+
+int ensure_small(DeviceCtx* ctx, size_t bytes)
+{
+    if (ctx->small_bytes >= bytes) return PRL_OK;
+    if (ctx->small) {
+        PRL_HIP_CHECK(hipDeviceSynchronize());
+        PRL_HIP_CHECK(hipFree(ctx->small));
+        ctx->small = nullptr;
+        ctx->small_bytes = 0;
+    }
+    bytes = std::max<size_t>(bytes, 1 << 20);
+    PRL_HIP_CHECK(hipMalloc(&ctx->small, bytes));
+    ctx->small_bytes = bytes;
+    return PRL_OK;
+}
+
+int ensure_pinned(DeviceCtx* ctx, size_t bytes)
+{
+    if (ctx->pinned_bytes >= bytes) return PRL_OK;
+    if (ctx->pinned) {
+        PRL_HIP_CHECK(hipDeviceSynchronize());
+        PRL_HIP_CHECK(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+    }
+    bytes = std::max<size_t>(bytes, 1 << 16);
+    PRL_HIP_CHECK(hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+    ctx->pinned_bytes = bytes;
+    return PRL_OK;
+}
+
+namespace {
+
+int exec_mode()
+{
+    if (g_exec_mode < 0) {
+        const char* e = std::getenv("PRL_HIP_MODE");
+        g_exec_mode = (e && std::strcmp(e, "literal") == 0) ? PRL_MODE_LITERAL : PRL_MODE_AUTO;
+    }
+    return g_exec_mode;
+}
+
+size_t literal_scratch_budget()
+{
+    // bytes of float64 integral scratch the literal pipeline may hold at once (default 8 GiB)
+    const char* e = std::getenv("PRL_HIP_LITERAL_SCRATCH_MB");
+    size_t mb = e ? (size_t)std::strtoull(e, nullptr, 10) : 8192;
+    if (mb < 64) mb = 64;
+    return mb << 20;
+}
+
+// Argument checks in the reference's order: empty (binarizeSauvola.cpp:38-41), window (:43-47).
+int geometry_impl(const prl_binarize_params* p, int width, int height, prl_binarize_geometry* g)
+{
+    if (!p || !g) return PRL_ERR_BAD_ARG;
+    std::memset(g, 0, sizeof(*g));
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    if (!((p->window_size > 1) && ((p->window_size % 2) == 1))) return PRL_ERR_BAD_WINDOW;
+    if (p->method < PRL_SAUVOLA || p->method > PRL_FENG) return PRL_ERR_BAD_ARG;
+    const int w = std::min(p->window_size, std::min(width, height));  // :57
+    g->w = w;
+    g->half = w / 2;                                                  // :65
+    g->padded_w = width + 2 * g->half;
+    g->padded_h = height + 2 * g->half;
+    if (p->method == PRL_SAUVOLA || p->method == PRL_NIBLACK) {      // rect from padded size, :66
+        g->out_w = g->padded_w - w;
+        g->out_h = g->padded_h - w;
+    } else {                                                          // rect before padding, WolfJolion.cpp:69
+        g->out_w = width - w;
+        g->out_h = height - w;
+    }
+    if (g->out_w <= 0 || g->out_h <= 0) return PRL_ERR_EMPTY_RECT;
+    return PRL_OK;
+}
+
+ThrParams make_thr_params(const prl_binarize_params* p, const prl_binarize_geometry& g, int width,
+                          int height)
+{
+    ThrParams tp{};
+    tp.method = p->method;
+    tp.w = g.w;
+    tp.half = g.half;
+    tp.width = width;
+    tp.height = height;
+    tp.pw = g.padded_w;
+    tp.ph = g.padded_h;
+    tp.ow = g.out_w;
+    tp.oh = g.out_h;
+    const int wSqr = g.w * g.w;                       // binarizeSauvola.cpp:58
+    tp.f = 1.0 / static_cast<double>(wSqr);           // :59
+    tp.k = p->k;
+    const double R = 128;
+    const double RBack = 1.0 / R;                     // :61-62
+    tp.a = (p->k * RBack);                            // :117
+    tp.b = (1.0 - p->k);                              // :117
+    tp.c1 = 1.0 - p->feng_alpha1;                     // binarizeFeng.cpp:133
+    tp.k2 = p->feng_k2;
+    tp.gamma = p->feng_gamma;
+    return tp;
+}
+
+int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int width, int height,
+                    PageSetOut dst, const uint8_t* const* h_src_tab, uint8_t* const* h_dst_tab,
+                    hipStream_t stream)
+{
+    prl_binarize_geometry g;
+    int st = geometry_impl(p, width, height, &g);
+    if (st != PRL_OK) return st;
+    if (n_pages < 0) return PRL_ERR_BAD_ARG;
+    if (n_pages == 0) return PRL_OK;
+    if ((!src.base && !h_src_tab) || (!dst.base && !h_dst_tab)) return PRL_ERR_BAD_ARG;
+    if (src.step < (size_t)width || dst.step < (size_t)g.out_w) return PRL_ERR_BAD_ARG;
+    const int morph = p->morph_iterations;
+
+    int dev;
+    st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+
+    const ThrParams tp = make_thr_params(p, g, width, height);
+
+    // the scratch areas are shared by every stream of this device: order this call after the last one
+    if (!ctx->last_use)
+        PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+    else
+        PRL_HIP_CHECK(hipStreamWaitEvent(stream, ctx->last_use, 0));
+
+    // small device area: [PageGlobals x n][src table][dst table][fused work area]
+    const size_t globals_bytes = ((sizeof(PageGlobals) * (size_t)n_pages + 255) / 256) * 256;
+    const size_t table_bytes = ((sizeof(void*) * (size_t)n_pages + 255) / 256) * 256;
+    const size_t fused_bytes = fused_small_bytes(n_pages);
+    st = ensure_small(ctx, globals_bytes + 2 * table_bytes + fused_bytes);
+    if (st != PRL_OK) return st;
+    auto* small = static_cast<uint8_t*>(ctx->small);
+    auto* d_globals = reinterpret_cast<PageGlobals*>(small);
+    auto* d_src_tab = reinterpret_cast<const uint8_t**>(small + globals_bytes);
+    auto* d_dst_tab = reinterpret_cast<uint8_t**>(small + globals_bytes + table_bytes);
+    void* d_fused = small + globals_bytes + 2 * table_bytes;
+
+    if (h_src_tab || h_dst_tab) {
+        st = ensure_pinned(ctx, 2 * table_bytes);
+        if (st != PRL_OK) return st;
+        auto* pin = static_cast<uint8_t*>(ctx->pinned);
+        // the pinned staging area is reused by the next call: wait for earlier copies out of it
+        PRL_HIP_CHECK(hipStreamSynchronize(stream));
+        if (h_src_tab) {
+            std::memcpy(pin, h_src_tab, sizeof(void*) * (size_t)n_pages);
+            PRL_HIP_CHECK(hipMemcpyAsync(d_src_tab, pin, sizeof(void*) * (size_t)n_pages,
+                                         hipMemcpyHostToDevice, stream));
+            src.table = d_src_tab;
+        }
+        if (h_dst_tab) {
+            std::memcpy(pin + table_bytes, h_dst_tab, sizeof(void*) * (size_t)n_pages);
+            PRL_HIP_CHECK(hipMemcpyAsync(d_dst_tab, pin + table_bytes, sizeof(void*) * (size_t)n_pages,
+                                         hipMemcpyHostToDevice, stream));
+            dst.table = d_dst_tab;
+        }
+    }
+
+    // With morphology the thresholded mask goes to scratch first, then the morph kernel writes dst.
+    const size_t mask_step = ((size_t)g.out_w + 63) / 64 * 64;
+    const size_t mask_page = mask_step * (size_t)g.out_h;
+    const size_t mask_bytes = morph != 0 ? mask_page * (size_t)n_pages : 0;
+
+    const bool use_fused = exec_mode() == PRL_MODE_AUTO && fused_supports(tp);
+    size_t literal_pages_per_chunk = 0, literal_bytes = 0;
+    if (!use_fused) {
+        const size_t per_page = literal_scratch_per_page(tp);
+        literal_pages_per_chunk = std::max<size_t>(1, literal_scratch_budget() / per_page);
+        literal_pages_per_chunk = std::min<size_t>(literal_pages_per_chunk, (size_t)n_pages);
+        literal_bytes = per_page * literal_pages_per_chunk;
+    }
+    const size_t mask_off = (literal_bytes + 255) / 256 * 256;
+    if (mask_off + mask_bytes > 0) {
+        st = ensure_scratch(ctx, mask_off + mask_bytes);
+        if (st != PRL_OK) return st;
+    }
+    PageSetOut thr_dst = dst;
+    if (morph != 0) {
+        thr_dst = PageSetOut{};
+        thr_dst.base = static_cast<uint8_t*>(ctx->scratch) + mask_off;
+        thr_dst.page_stride = mask_page;
+        thr_dst.step = mask_step;
+    }
+
+    st = init_globals_run(d_globals, n_pages, stream);
+    if (st != PRL_OK) return st;
+
+    t_last = LastCall{};
+    t_last.device = dev;
+    t_last.stream = stream;
+    t_last.n_pages = n_pages;
+    t_last.pixels = (uint64_t)g.out_w * g.out_h * (uint64_t)n_pages;
+
+    if (use_fused) {
+        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream);
+        if (st != PRL_OK) return st;
+    } else {
+        if (tp.method == PRL_WOLFJOLION || tp.method == PRL_FENG) {
+            st = page_min_run(tp, src, n_pages, d_globals, stream);
+            if (st != PRL_OK) return st;
+        }
+        for (int first = 0; first < n_pages; first += (int)literal_pages_per_chunk) {
+            const int cnt = std::min<int>((int)literal_pages_per_chunk, n_pages - first);
+            st = literal_run(tp, src, first, cnt, thr_dst, ctx->scratch, d_globals, stream);
+            if (st != PRL_OK) return st;
+        }
+        t_last.literal_pages = (uint64_t)n_pages;
+    }
+
+    if (morph != 0) {
+        PageSet msrc{};
+        msrc.base = thr_dst.base;
+        msrc.page_stride = thr_dst.page_stride;
+        msrc.step = thr_dst.step;
+        st = morph_run(morph, msrc, n_pages, g.out_w, g.out_h, dst, stream);
+        if (st != PRL_OK) return st;
+    }
+    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, stream));
+    t_last.valid = true;
+    return PRL_OK;
+}
+
+}  // namespace
+}  // namespace prl_hip
+
+using namespace prl_hip;
+
+extern "C" {
+
+int prl_hip_abi_version(void) { return PRL_HIP_ABI_VERSION; }
+
+const char* prl_hip_strerror(int status)
+{
+    switch (status) {
+    case PRL_OK: return "ok";
+    case PRL_ERR_EMPTY: return "Input image for binarization is empty";
+    case PRL_ERR_BAD_WINDOW:
+        return "Window size must satisfy the following condition: ( (windowSize > 1) && ((windowSize % 2) == 1) ) ";
+    case PRL_ERR_BAD_CHANNELS: return "unsupported channel count";
+    case PRL_ERR_EMPTY_RECT: return "processing rectangle is empty (image not larger than the window)";
+    case PRL_ERR_BAD_ARG: return "bad argument";
+    case PRL_ERR_NO_DEVICE: return "no usable HIP device (gfx950 required); there is no CPU fallback";
+    case PRL_ERR_HIP: return "HIP runtime error";
+    case PRL_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+const char* prl_hip_last_error_detail(void) { return t_error_detail.c_str(); }
+
+int prl_hip_device_count(int* count)
+{
+    if (!count) return PRL_ERR_BAD_ARG;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *count = c;
+    return PRL_OK;
+}
+
+int prl_hip_set_device(int device)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || device < 0 || device >= c) {
+        (void)hipGetLastError();
+        return PRL_ERR_NO_DEVICE;
+    }
+    t_device = device;
+    return PRL_OK;
+}
+
+int prl_hip_set_exec_mode(int mode)
+{
+    if (mode != PRL_MODE_AUTO && mode != PRL_MODE_LITERAL) return PRL_ERR_BAD_ARG;
+    g_exec_mode = mode;
+    return PRL_OK;
+}
+
+int prl_hip_get_exec_mode(void) { return exec_mode(); }
+
+int prl_hip_release_workspace(void)
+{
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PRL_HIP_CHECK(hipDeviceSynchronize());
+    if (ctx->scratch) PRL_HIP_CHECK(hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    if (ctx->small) PRL_HIP_CHECK(hipFree(ctx->small));
+    ctx->small = nullptr;
+    ctx->small_bytes = 0;
+    if (ctx->pinned) PRL_HIP_CHECK(hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    return PRL_OK;
+}
+
+int prl_hip_last_stats(prl_binarize_stats* out)
+{
+    if (!out) return PRL_ERR_BAD_ARG;
+    std::memset(out, 0, sizeof(*out));
+    if (!t_last.valid) return PRL_OK;
+    PRL_HIP_CHECK(hipSetDevice(t_last.device));
+    DeviceCtx* ctx = device_ctx(t_last.device);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::vector<PageGlobals> g((size_t)t_last.n_pages);
+    PRL_HIP_CHECK(hipStreamSynchronize(t_last.stream));
+    PRL_HIP_CHECK(hipMemcpy(g.data(), ctx->small, sizeof(PageGlobals) * g.size(), hipMemcpyDeviceToHost));
+    out->pixels = t_last.pixels;
+    out->literal_pages = t_last.literal_pages;
+    for (const auto& pg : g) {
+        out->refined_pixels += pg.n_refined;
+        out->exact_pixels += pg.n_exact;
+        out->literal_pages += pg.worklist_overflow ? 1 : 0;
+    }
+    return PRL_OK;
+}
+
+int prl_hip_default_params(int method, prl_binarize_params* out)
+{
+    if (!out || method < PRL_SAUVOLA || method > PRL_FENG) return PRL_ERR_BAD_ARG;
+    std::memset(out, 0, sizeof(*out));
+    out->method = method;
+    // binarizeSauvola.h:43-47, binarizeNiblack.h:43-47, binarizeWolfJolion.h:43-47
+    out->window_size = 101;
+    out->k = 0.01;
+    out->morph_iterations = 2;
+    if (method == PRL_NICK) {  // binarizeNICK.h:43-47
+        out->window_size = 21;
+        out->k = -0.01;
+        out->morph_iterations = 0;
+    }
+    if (method == PRL_FENG) {  // binarizeFeng.h:46-53
+        out->window_size = 21;
+        out->k = 0.0;
+        out->morph_iterations = 2;
+    }
+    out->feng_alpha1 = 0.75;
+    out->feng_k1 = 0.2;
+    out->feng_k2 = 0.03;
+    out->feng_gamma = 2.0;
+    return PRL_OK;
+}
+
+int prl_hip_binarize_geometry(const prl_binarize_params* p, int width, int height,
+                              prl_binarize_geometry* out)
+{
+    return geometry_impl(p, width, height, out);
+}
+
+int prl_hip_binarize_batch_device(const prl_binarize_params* p, int n_pages, const uint8_t* d_src,
+                                  size_t src_page_stride, size_t src_step, int width, int height,
+                                  uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream)
+{
+    PageSet s{};
+    s.base = d_src;
+    s.page_stride = src_page_stride;
+    s.step = src_step;
+    PageSetOut d{};
+    d.base = d_dst;
+    d.page_stride = dst_page_stride;
+    d.step = dst_step;
+    return binarize_common(p, n_pages, s, width, height, d, nullptr, nullptr,
+                           static_cast<hipStream_t>(stream));
+}
+
+int prl_hip_binarize_pages_device(const prl_binarize_params* p, int n_pages,
+                                  const uint8_t* const* d_src_pages, size_t src_step, int width,
+                                  int height, uint8_t* const* d_dst_pages, size_t dst_step, void* stream)
+{
+    if (n_pages > 0 && (!d_src_pages || !d_dst_pages)) return PRL_ERR_BAD_ARG;
+    PageSet s{};
+    s.step = src_step;
+    PageSetOut d{};
+    d.step = dst_step;
+    return binarize_common(p, n_pages, s, width, height, d, d_src_pages, d_dst_pages,
+                           static_cast<hipStream_t>(stream));
+}
+
+int prl_hip_binarize_host(const prl_binarize_params* p, const uint8_t* src, size_t src_step, int width,
+                          int height, uint8_t* dst, size_t dst_step, uint8_t* padded_out,
+                          size_t padded_step)
+{
+    prl_binarize_geometry g;
+    int st = geometry_impl(p, width, height, &g);
+    if (st != PRL_OK) return st;
+    if (!src || !dst || src_step < (size_t)width || dst_step < (size_t)g.out_w) return PRL_ERR_BAD_ARG;
+    if (padded_out && padded_step < (size_t)g.padded_w) return PRL_ERR_BAD_ARG;
+    int dev;
+    st = current_device(&dev);
+    if (st != PRL_OK) return st;
+
+    const size_t in_pitch = ((size_t)width + 255) / 256 * 256;
+    const size_t out_pitch = ((size_t)g.out_w + 255) / 256 * 256;
+    uint8_t* d_in = nullptr;
+    uint8_t* d_out = nullptr;
+    hipStream_t stream = nullptr;
+    PRL_HIP_CHECK(hipMalloc(&d_in, in_pitch * (size_t)height));
+    hipError_t e = hipMalloc(&d_out, out_pitch * (size_t)g.out_h);
+    if (e != hipSuccess) {
+        (void)hipFree(d_in);
+        return PRL_ERR_NOMEM;
+    }
+    auto cleanup = [&]() {
+        (void)hipFree(d_in);
+        (void)hipFree(d_out);
+    };
+    e = hipMemcpy2D(d_in, in_pitch, src, src_step, (size_t)width, (size_t)height, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error_detail(std::string("hipMemcpy2D H2D: ") + hipGetErrorString(e));
+        cleanup();
+        return PRL_ERR_HIP;
+    }
+    st = prl_hip_binarize_batch_device(p, 1, d_in, in_pitch * (size_t)height, in_pitch, width, height,
+                                       d_out, out_pitch * (size_t)g.out_h, out_pitch, stream);
+    if (st != PRL_OK) {
+        cleanup();
+        return st;
+    }
+    e = hipMemcpy2D(dst, dst_step, d_out, out_pitch, (size_t)g.out_w, (size_t)g.out_h, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) {
+        set_error_detail(std::string("hipMemcpy2D D2H: ") + hipGetErrorString(e));
+        return PRL_ERR_HIP;
+    }
+    if (padded_out) {
+        // cv::copyMakeBorder(in, in, h, h, h, h, BORDER_REPLICATE) side effect on the caller's Mat
+        // (binarizeSauvola.cpp:65): pure data movement of the caller's own host pixels.
+        for (int y = 0; y < g.padded_h; ++y) {
+            const int sy = std::min(std::max(y - g.half, 0), height - 1);
+            const uint8_t* s = src + (size_t)sy * src_step;
+            uint8_t* d = padded_out + (size_t)y * padded_step;
+            std::memset(d, s[0], (size_t)g.half);
+            std::memcpy(d + g.half, s, (size_t)width);
+            std::memset(d + g.half + width, s[width - 1], (size_t)g.half);
+        }
+    }
+    return PRL_OK;
+}
+
+int prl_hip_morph_batch_device(int morph_iterations, int n_pages, const uint8_t* d_src,
+                               size_t src_page_stride, size_t src_step, int width, int height,
+                               uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream)
+{
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    if (n_pages < 0 || !d_src || !d_dst || d_src == d_dst) return PRL_ERR_BAD_ARG;
+    if (src_step < (size_t)width || dst_step < (size_t)width) return PRL_ERR_BAD_ARG;
+    if (n_pages == 0) return PRL_OK;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    if (morph_iterations == 0) {
+        for (int i = 0; i < n_pages; ++i)
+            PRL_HIP_CHECK(hipMemcpy2DAsync(d_dst + (size_t)i * dst_page_stride, dst_step,
+                                           d_src + (size_t)i * src_page_stride, src_step, (size_t)width,
+                                           (size_t)height, hipMemcpyDeviceToDevice,
+                                           static_cast<hipStream_t>(stream)));
+        return PRL_OK;
+    }
+    PageSet s{};
+    s.base = d_src;
+    s.page_stride = src_page_stride;
+    s.step = src_step;
+    PageSetOut d{};
+    d.base = d_dst;
+    d.page_stride = dst_page_stride;
+    d.step = dst_step;
+    return morph_run(morph_iterations, s, n_pages, width, height, d, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

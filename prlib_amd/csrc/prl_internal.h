@@ -1,0 +1,115 @@
+// prl_internal.h — shared host-side declarations of libprlib_hip.so (not part of the public ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <mutex>
+#include <string>
+
+#include "../../include/prl_hip.h"
+
+namespace prl_hip {
+
+// ---- error plumbing -----------------------------------------------------------------------
+void set_error_detail(const std::string& s);
+
+#define PRL_HIP_CHECK(expr)                                                                       \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            ::prl_hip::set_error_detail(std::string(#expr) + ": " + hipGetErrorString(_e));       \
+            return (_e == hipErrorOutOfMemory) ? PRL_ERR_NOMEM : PRL_ERR_HIP;                     \
+        }                                                                                         \
+    } while (0)
+
+// ---- per-device context: cached scratch memory ------------------------------------------------
+struct DeviceCtx {
+    std::mutex mu;          // one binarize/denoise call at a time per device (scratch is shared)
+    int device = -1;
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void* small = nullptr;  // counters / work lists / per-page globals
+    size_t small_bytes = 0;
+    void* pinned = nullptr; // pinned host staging for tiny transfers
+    size_t pinned_bytes = 0;
+    int cu_count = 0;
+    hipEvent_t last_use = nullptr;  // recorded after each call; the next call's stream waits on it
+};
+
+int current_device(int* dev);             // validates that a gfx950 device is usable
+DeviceCtx* device_ctx(int dev);
+int ensure_scratch(DeviceCtx* ctx, size_t bytes);
+int ensure_small(DeviceCtx* ctx, size_t bytes);
+int ensure_pinned(DeviceCtx* ctx, size_t bytes);
+
+// ---- page addressing: contiguous batch or table of page pointers ---------------------------------
+struct PageSet {
+    const uint8_t* base = nullptr;   // page i at base + i*page_stride ...
+    size_t page_stride = 0;
+    const uint8_t* const* table = nullptr;  // ... unless a DEVICE array of page pointers is given
+    size_t step = 0;
+    __host__ __device__ const uint8_t* page(int i) const {
+        return table ? table[i] : base + (size_t)i * page_stride;
+    }
+};
+struct PageSetOut {
+    uint8_t* base = nullptr;
+    size_t page_stride = 0;
+    uint8_t* const* table = nullptr;
+    size_t step = 0;
+    __host__ __device__ uint8_t* page(int i) const {
+        return table ? table[i] : base + (size_t)i * page_stride;
+    }
+};
+
+// Threshold constants shared by the literal and fused kernels (host-prepared, passed by value).
+struct ThrParams {
+    int method;
+    int w;         // effective window
+    int half;
+    int width, height;      // unpadded page
+    int pw, ph;             // padded page
+    int ow, oh;             // output
+    double f;      // 1.0 / (double)(w*w)                  binarizeSauvola.cpp:58-59
+    double k;
+    double a, b;   // Sauvola: k*(1/128), 1-k             binarizeSauvola.cpp:117
+    double c1;     // Feng: 1 - alpha1                    binarizeFeng.cpp:133
+    double k2;     // Feng
+    double gamma;  // Feng
+};
+
+// Per-page globals living in device memory (Wolf-Jolion / Feng reductions, fix-up bookkeeping).
+struct PageGlobals {
+    int imin;                       // min over the page (cv::minMaxLoc(imageInput), binarizeWolfJolion.cpp:116)
+    int smax_found;                 // any non-NaN deviation seen
+    unsigned long long smax_bits;   // bit pattern of max deviation (>= +0, so integer order == value order)
+    double coeff;                   // k / devianceMax             binarizeWolfJolion.cpp:121
+    unsigned int n_refined;         // pixels decided by the float64 interval test
+    unsigned int n_exact;           // pixels sent to the absolute-integral fix-up
+    unsigned int worklist_overflow; // fix-up list overflowed -> page must rerun literally
+    unsigned int reserved;
+};
+
+// ---- literal pipeline (binarize_literal.hip) ---------------------------------------------------
+size_t literal_scratch_per_page(const ThrParams& tp);
+int literal_run(const ThrParams& tp, const PageSet& src, int first_page, int n_pages,
+                const PageSetOut& dst, void* scratch, PageGlobals* d_globals, hipStream_t stream);
+
+// ---- fused pipeline (binarize_fused.hip) -------------------------------------------------------
+struct FusedWork;  // opaque
+size_t fused_small_bytes(int n_pages);
+int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst,
+              void* small, PageGlobals* d_globals, hipStream_t stream);
+bool fused_supports(const ThrParams& tp);
+
+// ---- morphology (morph.hip) ------------------------------------------------------------------
+int morph_run(int iterations, const PageSet& src, int n_pages, int width, int height,
+              const PageSetOut& dst, hipStream_t stream);
+
+// ---- page reductions (binarize_literal.hip) ---------------------------------------------------
+int page_min_run(const ThrParams& tp, const PageSet& src, int n_pages, PageGlobals* d_globals,
+                 hipStream_t stream);
+
+}  // namespace prl_hip

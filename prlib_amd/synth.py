@@ -1,0 +1,54 @@
+"""Seeded synthetic document pages: u8 grayscale "paper" N(215,12) with dark stroke
+rectangles.  Two generators with the same statistics:
+  page_numpy  — the specified generator (numpy PCG64, seed = 1000 + page index); small parity cases
+  pages_torch — the same recipe drawn on the device with torch's generator, for full-size batches
+                (256 x 4096^2 would take minutes on host cores).  Parity runs download these pages.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def page_numpy(height: int, width: int, index: int = 0) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64(1000 + index))
+    page = rng.normal(215.0, 12.0, size=(height, width))
+    n_strokes = max(1, (height * width) // 900)
+    ys = rng.integers(0, height, n_strokes)
+    xs = rng.integers(0, width, n_strokes)
+    hs = rng.integers(2, 6, n_strokes)
+    ws = rng.integers(5, 40, n_strokes)
+    ds = rng.integers(90, 170, n_strokes)
+    for y, x, h, w, d in zip(ys, xs, hs, ws, ds):
+        page[y:y + h, x:x + w] -= d
+    return np.clip(np.rint(page), 0, 255).astype(np.uint8)
+
+
+def pages_torch(n_pages: int, height: int, width: int, device, seed: int = 1000, pitch: int | None = None):
+    """N x H x W uint8 pages on `device` (a view of an N x H x pitch buffer when pitch is given)."""
+    import torch
+
+    pitch = pitch or width
+    buf = torch.empty((n_pages, height, pitch), dtype=torch.uint8, device=device)
+    gen = torch.Generator(device=device)
+    n_strokes = max(1, (height * width) // 900)
+    for i in range(n_pages):
+        gen.manual_seed(seed + i)
+        page = torch.empty((height, width), dtype=torch.float32, device=device).normal_(215.0, 12.0, generator=gen)
+        # strokes: subtract darkness over random small rectangles via a coarse scatter + box spread
+        ys = torch.randint(0, height, (n_strokes,), device=device, generator=gen)
+        xs = torch.randint(0, width, (n_strokes,), device=device, generator=gen)
+        hs = torch.randint(2, 6, (n_strokes,), device=device, generator=gen)
+        ws = torch.randint(5, 40, (n_strokes,), device=device, generator=gen)
+        ds = torch.randint(90, 170, (n_strokes,), device=device, generator=gen).to(torch.float32)
+        # 2-D difference array: +d at (y,x), -d at (y,x+w), -d at (y+h,x), +d at (y+h,x+w); cumsum twice
+        diff = torch.zeros((height + 8, width + 48), dtype=torch.float32, device=device)
+        flat = diff.view(-1)
+        wd = width + 48
+        flat.index_add_(0, ys * wd + xs, ds)
+        flat.index_add_(0, ys * wd + xs + ws, -ds)
+        flat.index_add_(0, (ys + hs) * wd + xs, -ds)
+        flat.index_add_(0, (ys + hs) * wd + xs + ws, ds)
+        dark = diff.cumsum(0).cumsum(1)[:height, :width]
+        page = (page - dark).round_().clamp_(0, 255)
+        buf[i, :, :width] = page.to(torch.uint8)
+    return buf[:, :, :width]

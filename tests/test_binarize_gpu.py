@@ -1,0 +1,177 @@
+"""GPU parity: libprlib_hip.so (through the C ABI) against the CPU oracle, bit for bit.
+
+Integer/byte output => the bar is 0 mismatching pixels.  Cases follow SURVEY.md §4/§8c: seeded
+synthetic pages, odd/even sizes, ragged (non-multiple-of-tile) sizes, window clamping, all five
+methods, morphology in both directions, flat/black/white/binary pages, and both execution modes.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SAUVOLA, NIBLACK, WOLFJOLION, NICK, FENG = range(5)
+
+
+def _oracle_batch(oracle, pages_np, method, win, k, morph, **feng):
+    p = oracle.make_params(method, win, k, morph, **feng)
+    return [oracle.binarize(pg, p) for pg in pages_np]
+
+
+def _check(prl, oracle, dev, pages_np, method, win, k, morph, feng=None, mode=None):
+    import torch
+
+    feng = feng or {}
+    pages = torch.from_numpy(np.stack(pages_np)).to(dev)
+    if mode is not None:
+        prl.set_exec_mode(mode)
+    try:
+        got = prl.binarize(pages, prl.make_params(method, win, k, morph, **feng)).cpu().numpy()
+    finally:
+        if mode is not None:
+            prl.set_exec_mode(0)
+    want = _oracle_batch(oracle, pages_np, method, win, k, morph, **feng)
+    for i, wnt in enumerate(want):
+        assert got[i].shape == wnt.shape
+        bad = int((got[i] != wnt).sum())
+        assert bad == 0, f"page {i}: {bad} mismatching pixels (method {method}, w {win}, k {k}, morph {morph})"
+    return prl.last_stats()
+
+
+def _pages(shape, kinds, seed=0):
+    from prlib_amd import synth
+
+    rng = np.random.default_rng(seed)
+    h, w = shape
+    out = []
+    for i, kind in enumerate(kinds):
+        if kind == "doc":
+            out.append(synth.page_numpy(h, w, index=seed * 100 + i))
+        elif kind == "noise":
+            out.append(rng.integers(0, 256, (h, w), dtype=np.uint8))
+        elif kind == "binary":
+            out.append((rng.integers(0, 2, (h, w)) * 255).astype(np.uint8))
+        elif kind == "flat":
+            out.append(np.full((h, w), int(rng.integers(1, 256)), np.uint8))
+        elif kind == "black":
+            out.append(np.zeros((h, w), np.uint8))
+        elif kind == "white":
+            out.append(np.full((h, w), 255, np.uint8))
+        elif kind == "ramp":
+            out.append((np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8))
+        elif kind == "dark_corner":  # bright page, black bottom-right: small window sums, large absolute integrals
+            a = np.full((h, w), 250, np.uint8)
+            a[h // 2:, w // 2:] = rng.integers(0, 3, (h - h // 2, w - w // 2), dtype=np.uint8)
+            out.append(a)
+    return out
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["auto", "literal"])
+@pytest.mark.parametrize("method,win,k", [
+    (SAUVOLA, 31, 0.34), (SAUVOLA, 15, 0.34), (SAUVOLA, 101, 0.01),
+    (NIBLACK, 31, 0.01), (NIBLACK, 15, -0.2),
+    (WOLFJOLION, 31, 0.3), (WOLFJOLION, 15, 0.01),
+    (NICK, 21, -0.01), (NICK, 31, -0.1),
+    (FENG, 21, 0.0), (FENG, 31, 0.0),
+])
+def test_methods_on_mixed_pages(prl, oracle, cuda_device, method, win, k, mode):
+    kinds = ["doc", "noise", "binary", "flat", "black", "white", "ramp", "dark_corner"]
+    _check(prl, oracle, cuda_device, _pages((203, 331), kinds, seed=method + 1), method, win, k, 0, mode=mode)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (65, 130), (129, 67), (40, 512), (300, 33), (257, 1031)])
+@pytest.mark.parametrize("method", [SAUVOLA, NIBLACK, WOLFJOLION, NICK, FENG])
+def test_ragged_sizes(prl, oracle, cuda_device, shape, method):
+    win = 15 if min(shape) > 15 else 7
+    _check(prl, oracle, cuda_device, _pages(shape, ["doc", "noise"], seed=3), method, win, 0.2, 0)
+
+
+@pytest.mark.parametrize("morph", [1, 2, -1, -2, 3])
+@pytest.mark.parametrize("method", [SAUVOLA, NICK])
+def test_morphology(prl, oracle, cuda_device, method, morph):
+    _check(prl, oracle, cuda_device, _pages((150, 211), ["doc", "noise", "binary"], seed=5), method, 15, 0.2, morph)
+
+
+def test_window_clamped_to_page(prl, oracle, cuda_device):
+    # windowSize=101 on a 60x80 page: w = 60 (even), output = page size
+    st_pages = _pages((60, 80), ["doc", "noise"], seed=7)
+    _check(prl, oracle, cuda_device, st_pages, SAUVOLA, 101, 0.2, 0)
+    _check(prl, oracle, cuda_device, st_pages, NIBLACK, 101, 0.2, 2)
+
+
+def test_reference_defaults(prl, oracle, cuda_device):
+    # header defaults: Sauvola/Niblack/Wolf (101, 0.01, 2), NICK (21, -0.01, 0), Feng (21, ..., 2)
+    pages = _pages((260, 300), ["doc", "noise"], seed=11)
+    import torch
+
+    dev_pages = torch.from_numpy(np.stack(pages)).to(cuda_device)
+    for fn, method in [(prl.binarizeSauvola, SAUVOLA), (prl.binarizeNiblack, NIBLACK),
+                       (prl.binarizeWolfJolion, WOLFJOLION), (prl.binarizeNICK, NICK), (prl.binarizeFeng, FENG)]:
+        got = fn(dev_pages).cpu().numpy()
+        p = oracle.make_params(method)
+        for i, pg in enumerate(pages):
+            assert np.array_equal(got[i], oracle.binarize(pg, p)), f"defaults, method {method}, page {i}"
+
+
+def test_feng_parameters(prl, oracle, cuda_device):
+    pages = _pages((120, 140), ["doc", "flat", "black"], seed=13)
+    for feng in [dict(alpha1=0.12, k1=0.25, k2=0.04, gamma=2.0), dict(alpha1=0.5, k1=0.1, k2=0.01, gamma=3.0)]:
+        _check(prl, oracle, cuda_device, pages, FENG, 21, 0.0, 0, feng=feng)
+
+
+def test_host_entry_point_and_padded_side_effect(prl, oracle, cuda_device):
+    page = _pages((90, 111), ["doc"], seed=17)[0]
+    mask, padded = prl.binarize(page, prl.make_params(SAUVOLA, 15, 0.34, 2), return_padded=True)
+    assert np.array_equal(mask, oracle.binarize(page, oracle.make_params(SAUVOLA, 15, 0.34, 2)))
+    assert np.array_equal(padded, oracle.pad_replicate(page, 7))
+    # non-contiguous rows (cv::Mat ROI): step > width
+    big = np.zeros((90, 160), np.uint8)
+    big[:, :111] = page
+    assert np.array_equal(prl.binarize(big[:, :111], prl.make_params(NICK, 21, -0.1, 0)),
+                          oracle.binarize(page, oracle.make_params(NICK, 21, -0.1, 0)))
+
+
+def test_pages_table_entry_point(prl, oracle, cuda_device):
+    import ctypes as C
+
+    import torch
+    from prlib_amd import _capi
+
+    pages = _pages((100, 120), ["doc", "noise", "ramp"], seed=19)
+    dev = [torch.from_numpy(p).to(cuda_device) for p in pages]
+    params = prl.make_params(SAUVOLA, 15, 0.3, 0)
+    g = prl.geometry(params, 120, 100)
+    outs = [torch.zeros((g.out_h, 128), dtype=torch.uint8, device=cuda_device) for _ in pages]
+    src_tab = (C.c_void_p * 3)(*[t.data_ptr() for t in dev])
+    dst_tab = (C.c_void_p * 3)(*[t.data_ptr() for t in outs])
+    _capi.check(_capi.lib().prl_hip_binarize_pages_device(C.byref(params), 3, src_tab, 120, 120, 100, dst_tab, 128,
+                                                          torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    p = oracle.make_params(SAUVOLA, 15, 0.3, 0)
+    for i, pg in enumerate(pages):
+        assert np.array_equal(outs[i][:, :g.out_w].cpu().numpy(), oracle.binarize(pg, p))
+
+
+def test_errors_match_reference(prl, cuda_device):
+    import torch
+
+    page = torch.zeros((50, 50), dtype=torch.uint8, device=cuda_device)
+    with pytest.raises(ValueError):
+        prl.binarizeSauvola(page, 30)          # even window
+    with pytest.raises(ValueError):
+        prl.binarizeSauvola(page, 1)           # window <= 1
+    with pytest.raises(ValueError):
+        prl.binarizeNICK(torch.zeros((0, 0), dtype=torch.uint8, device=cuda_device))  # empty
+    from prlib_amd import _capi
+
+    with pytest.raises(_capi.PrlError) as e:
+        prl.binarizeWolfJolion(page, 51)       # W == w after clamping: empty rect (cv::Exception upstream)
+    assert e.value.status == _capi.PRL_ERR_EMPTY_RECT
+
+
+def test_c2_full_page_sauvola_w15(prl, oracle, cuda_device):
+    """BASELINE config 2: Sauvola k=0.34 w=15 on one 4096x4096 page, bit-exact vs CPU."""
+    from prlib_amd import synth
+
+    page = synth.page_numpy(4096, 4096, index=0)
+    st = _check(prl, oracle, cuda_device, [page], SAUVOLA, 15, 0.34, 0)
+    assert st.pixels == 4095 * 4095
