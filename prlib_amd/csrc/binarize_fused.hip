@@ -1,14 +1,619 @@
-// binarize_fused.hip — placeholder until the fused sliding-window kernel lands (next commit).
+// binarize_fused.hip — the fast path: one pass over the page, no integral image in memory.
+//
+// What the reference computes per output pixel (src/binarizations/binarizeSauvola.cpp:72-122 and the
+// same lines of Niblack/NICK/Feng) depends on the page only through two window sums over the
+// replicate-padded image P:
+//     S = sum of P   over rows y+1..y+w-1, cols x+1..x+w-1   ((w-1)x(w-1) window)
+//     Q = sum of P*P over the same window
+// plus last-bit rounding noise of the float64 4-tap filter on ABSOLUTE integral values.  The kernel
+// therefore
+//   1. keeps exact integer S and Q with a sliding window: each lane owns 8 adjacent columns and
+//      carries their vertical (w-1)-row sums in registers while the wavefront walks down the rows;
+//      the horizontal (w-1)-column sum is a wave-level prefix scan (DPP) + one cross-lane fetch;
+//   2. evaluates the threshold in float32 with a proven error bound eps1 (fused_bounds below) and
+//      decides every pixel whose margin |T - (p - 0.5)| exceeds it;
+//   3. re-evaluates the few remaining pixels in float64 with a per-pixel interval that also covers
+//      the literal sequence's rounding noise;
+//   4. queues what is still undecided (|T - (p-0.5)| ~< 1e-6) for k_fixup, which rebuilds the
+//      absolute integral corners from the page and runs the literal float64 sequence.
+// Steps 2-4 make the output bit-identical to the literal pipeline (binarize_literal.hip) while
+// >99.9999 % of pixels only pay for step 2.
+//
+// Memory: 1 B/px read + 1 B/px written to HBM (the algorithmic 2 B/px); window halos and the
+// "leaving" row of the sliding window are re-read from L2.  Bound: HBM; in practice VALU issue
+// (~30 lane-ops/px) is the co-limiter, see DESIGN.md.
+#include <cmath>
+
+#include "prl_device_math.h"
 #include "prl_internal.h"
 
 namespace prl_hip {
 
-size_t fused_small_bytes(int) { return 0; }
-bool fused_supports(const ThrParams&) { return false; }
-int fused_run(const ThrParams&, const PageSet&, int, const PageSetOut&, void*, PageGlobals*, hipStream_t)
+namespace {
+
+constexpr int kWave = 64;
+constexpr int CPL = 8;                 // columns per lane
+constexpr int SW = kWave * CPL;        // padded columns per wavefront strip
+constexpr unsigned kRefineCap = 1u << 20;  // pixels the float32 test may leave undecided per call
+constexpr unsigned kWorkCap = 1u << 18;    // pixels the float64 interval test may leave undecided
+
+struct RefItem {   // undecided after the float32 test: exact window sums travel with the pixel
+    int page, y, x;
+    unsigned S, Q, p;
+};
+struct WorkItem {  // undecided after the float64 interval test
+    int page, y, x;
+    int pad;
+};
+
+struct FusedParams {
+    ThrParams tp;
+    int uo;            // useful output columns per strip (multiple of 8)
+    int n_strips, n_segs, rows_per_seg;
+    int lane_off;      // (w-1) / 8
+    unsigned total_waves;
+    float ff;          // (float)f
+    float c0, c1, c2;  // method constants in float32 (see decide32)
+    float eps1;        // float32 decision margin (covers float32 evaluation + literal rounding noise)
+    float vthr32;      // variance floor below which the float32 test is not trusted
+    double vthr;       // same floor for the float64 interval test
+    double Em, Eq;     // |m_literal - f*S| <= Em, |q_literal - f*Q| <= Eq
+    unsigned ref_cap, wl_cap;
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// inclusive prefix sum over the 64 lanes: 4 row_shr steps inside each 16-lane row, then the two
+// row broadcasts (DPP, no LDS traffic)
+__device__ __forceinline__ unsigned wave_scan_incl(unsigned v)
 {
-    set_error_detail("fused path not built");
-    return PRL_ERR_HIP;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return (unsigned)x;
+}
+
+__device__ __forceinline__ unsigned byte_of(uint2 v, int c)
+{
+    const unsigned w = c < 4 ? v.x : v.y;
+    return (w >> (8 * (c & 3))) & 0xffu;
+}
+
+// 8 consecutive pixels of one image row starting at column col0, replicate-clamped to [0, W-1]
+__device__ __forceinline__ uint2 load_row8(const uint8_t* __restrict__ row, int col0, int W, bool interior)
+{
+    uint2 v;
+    if (interior) {
+        __builtin_memcpy(&v, row + col0, 8);  // one (possibly unaligned) global_load_dwordx2
+    } else {
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lo |= (unsigned)row[clampi(col0 + c, 0, W - 1)] << (8 * c);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hi |= (unsigned)row[clampi(col0 + 4 + c, 0, W - 1)] << (8 * c);
+        v.x = lo;
+        v.y = hi;
+    }
+    return v;
+}
+
+// ---- float32 evaluation: returns t = (p - 0.5) - T~ and the float32 variance v~ -----------------
+//   SAUVOLA  c0 = k/128, c1 = 1-k          T = m*(s*c0 + c1)
+//   NIBLACK  c0 = k                        T = s*c0 + m
+//   NICK     c0 = k                        T = m + c0*sqrt(q)            (m*m + s*s == q)
+//   FENG     c0 = 1 + (1-alpha1), c1 = k2*Imin - Imin (per page)   T = c0*m + c1   (s > 0)
+template <int METHOD>
+__device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsigned Q, float P, float c1page,
+                                        float* v_out)
+{
+    const float Sf = (float)S, Qf = (float)Q;
+    const float m = Sf * fp.ff;
+    const float q = Qf * fp.ff;
+    const float v = fmaf(-m, m, q);
+    *v_out = v;
+    if (METHOD == PRL_SAUVOLA) {
+        const float s = __builtin_amdgcn_sqrtf(v);
+        const float d = fmaf(s, fp.c0, fp.c1);
+        return fmaf(-m, d, P);
+    } else if (METHOD == PRL_NIBLACK) {
+        const float s = __builtin_amdgcn_sqrtf(v);
+        return P - fmaf(s, fp.c0, m);
+    } else if (METHOD == PRL_NICK) {
+        const float c = __builtin_amdgcn_sqrtf(q);
+        return P - fmaf(c, fp.c0, m);
+    } else {  // FENG
+        return P - fmaf(m, fp.c0, c1page);
+    }
+}
+
+// ---- float64 interval evaluation: 255 / 0 when provably decided, 2 otherwise -----------------
+// T* is the threshold in exact arithmetic from the exact window sums; the literal sequence differs
+// from it by at most ET (propagated from Em, Eq, the host-side bounds on the 4-tap rounding noise).
+template <int METHOD>
+__device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, unsigned Q, unsigned p, double imin)
+{
+    if (p == 0) return 0;  // 0 > T8 is false for every T8 (also for NaN -> 0)
+    const ThrParams& tp = fp.tp;
+    const double tiny = 8.9e-16;  // 8 ulp: float64 evaluation noise of the few operations below
+    const double m = (double)S * tp.f;
+    const double q = (double)Q * tp.f;
+    const double v = q - m * m;
+    const double Ev = fp.Eq + 2.0 * m * fp.Em + fp.Em * fp.Em + tiny * (q + m * m);
+    if (!(v > 4.0 * Ev)) return 2;  // literal sqrt may be NaN / arbitrarily far
+    const double s = sqrt(v);
+    const double Es = 1.001 * Ev / sqrt(v - Ev) + tiny * s;
+    double T, ET;
+    if (METHOD == PRL_SAUVOLA) {
+        const double d = s * tp.a + tp.b;
+        const double Ed = fabs(tp.a) * Es + tiny * (fabs(tp.a) * s + fabs(tp.b));
+        T = m * d;
+        ET = m * Ed + fabs(d) * fp.Em + fp.Em * Ed + tiny * fabs(T);
+    } else if (METHOD == PRL_NIBLACK) {
+        T = s * tp.k + m;
+        ET = fabs(tp.k) * Es + fp.Em + tiny * (fabs(T) + m);
+    } else if (METHOD == PRL_NICK) {
+        // literal: C = fl(fl(m*m) + fl(s*s)) = q_literal up to a few ulp
+        const double EC = fp.Eq + tiny * q;
+        const double c = sqrt(q);
+        const double Ec = 1.001 * EC / sqrt(q - EC) + tiny * c;
+        T = m + c * tp.k;
+        ET = fp.Em + fabs(tp.k) * Ec + tiny * (fabs(T) + m);
+    } else {  // FENG with s > 0 (guaranteed by v > 4 Ev): r = r2 = c2 = 1
+        const double c3 = (tp.k2 * imin + (-imin)) + 0.0;
+        const double g = 1.0 + tp.c1;
+        T = g * m + c3;
+        ET = fabs(g) * fp.Em + tiny * (fabs(T) + fabs(g) * m + fabs(c3));
+    }
+    ET = 2.0 * ET + 1e-12;
+    if (!(fabs(T) < 1e9)) return 2;
+    const double P = (double)p - 0.5;
+    if (T < P - ET) return 255;
+    if (T > P + ET) return 0;
+    return 2;
+}
+
+template <int METHOD, int SH>
+__global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, FusedParams fp,
+                                              PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
+                                              unsigned* __restrict__ counters)
+{
+    const ThrParams& tp = fp.tp;
+    const int lane = threadIdx.x & (kWave - 1);
+    // XCD-aware block order: hardware deals blocks round-robin over the 8 XCDs, so blocks b and b+8
+    // share an L2.  Give each XCD a contiguous range of logical blocks (= neighbouring strips and
+    // segments of the same pages) so halo re-reads hit that XCD's L2.  Speed only, never correctness.
+    const unsigned nb = gridDim.x;
+    const unsigned lb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+    const unsigned wid = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
+    if (wid >= fp.total_waves) return;
+    const int per_page = fp.n_strips * fp.n_segs;
+    const int page = (int)(wid / (unsigned)per_page);
+    const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
+    const int seg = rem / fp.n_strips;
+    const int strip = rem - seg * fp.n_strips;
+
+    const uint8_t* __restrict__ img = src.page(page);
+    uint8_t* __restrict__ out = dst.page(page);
+    const size_t istep = src.step, ostep = dst.step;
+    const int W = tp.width, H = tp.height, h = tp.half, w = tp.w;
+
+    const int xs = strip * fp.uo;                 // first output column of the strip
+    const int ys = seg * fp.rows_per_seg;         // first output row of the segment
+    const int ye = min(ys + fp.rows_per_seg, tp.oh);
+    const int col0 = xs + 1 - h + CPL * lane;     // image column of this lane's sub-column 0
+    const bool interior = (col0 >= 0) && (col0 + CPL <= W);
+    const int x0 = xs + CPL * lane;               // first output column of this lane
+    const bool lane_has_out = (CPL * lane < fp.uo) && (x0 < tp.ow);
+    const bool full8 = lane_has_out && (x0 + CPL <= tp.ow);
+    // lane that holds E(j0 + w - 1): byte address for ds_bpermute
+    const int far_addr0 = (lane + fp.lane_off) * 4;
+    const int far_addr1 = far_addr0 + 4;
+
+    float c1page = fp.c1;
+    if (METHOD == PRL_FENG) {
+        const double imin = (double)g[page].imin;
+        const double c3 = (tp.k2 * imin + (-imin)) + 0.0;  // binarizeFeng.cpp:137 with r2 = c2 = 1
+        c1page = (float)c3;
+    }
+
+    unsigned VS[CPL], VQ[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) VS[c] = VQ[c] = 0;
+
+    auto row_ptr = [&](int padded_row) -> const uint8_t* {
+        return img + (size_t)clampi(padded_row - h, 0, H - 1) * istep;
+    };
+
+    // warm-up: vertical sums over padded rows ys+1 .. ys+w-1
+    for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
+        const uint2 v = load_row8(row_ptr(pr), col0, W, interior);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const unsigned b = byte_of(v, c);
+            VS[c] += b;
+            VQ[c] += b * b;
+        }
+    }
+
+    for (int y = ys; y < ye; ++y) {
+        // issue next iteration's loads early: entering row y+w, leaving row y+1
+        uint2 vnew = make_uint2(0, 0), vold = make_uint2(0, 0);
+        const bool more = (y + 1 < ye);
+        if (more) {
+            vnew = load_row8(row_ptr(y + w), col0, W, interior);
+            vold = load_row8(row_ptr(y + 1), col0, W, interior);
+        }
+        // compared pixels p = page(y, x0..x0+7)
+        uint2 pv = make_uint2(0, 0);
+        if (lane_has_out) {
+            const uint8_t* prow = img + (size_t)y * istep;
+            if (x0 + CPL <= W) {
+                __builtin_memcpy(&pv, prow + x0, 8);
+            } else {
+                pv = load_row8(prow, x0, W, false);
+            }
+        }
+
+        // horizontal window sums: E = exclusive prefix over the strip, S(j0) = E(j0+w-1) - E(j0)
+        unsigned ES[CPL], EQ[CPL];
+        {
+            unsigned accs = 0, accq = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                ES[c] = accs;
+                EQ[c] = accq;
+                accs += VS[c];
+                accq += VQ[c];
+            }
+            const unsigned bs = wave_scan_incl(accs) - accs;
+            const unsigned bq = wave_scan_incl(accq) - accq;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                ES[c] += bs;
+                EQ[c] += bq;
+            }
+        }
+        unsigned Ssum[CPL], Qsum[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int sub = (c + SH) & 7;                 // compile-time
+            const int addr = (c + SH) >= 8 ? far_addr1 : far_addr0;
+            const unsigned fs = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)ES[sub]);
+            const unsigned fq = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)EQ[sub]);
+            Ssum[c] = fs - ES[c];
+            Qsum[c] = fq - EQ[c];
+        }
+
+        // float32 decision; what it cannot settle is queued with its exact sums for k_refine
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const unsigned p = byte_of(pv, c);
+            const float P = (float)p - 0.5f;
+            float v32;
+            const float t = eval32<METHOD>(fp, Ssum[c], Qsum[c], P, c1page, &v32);
+            const bool sure = ((fabsf(t) > fp.eps1) && (v32 > fp.vthr32)) || (p == 0);
+            const bool white = (t > 0.0f) && (p != 0);
+            const unsigned o = white ? 0xffu : 0u;
+            if (c < 4) lo |= o << (8 * c); else hi |= o << (8 * (c - 4));
+            if (!sure && lane_has_out && (x0 + c < tp.ow)) {
+                const unsigned idx = atomicAdd(&counters[0], 1u);
+                if (idx < fp.ref_cap) {
+                    RefItem it;
+                    it.page = page;
+                    it.y = y;
+                    it.x = x0 + c;
+                    it.S = Ssum[c];
+                    it.Q = Qsum[c];
+                    it.p = p;
+                    rl[idx] = it;
+                } else {
+                    atomicOr(&g[page].worklist_overflow, 1u);
+                }
+            }
+        }
+
+        // store 8 mask bytes
+        if (full8) {
+            uint2 o = make_uint2(lo, hi);
+            __builtin_memcpy(out + (size_t)y * ostep + x0, &o, 8);
+        } else if (lane_has_out) {
+            for (int c = 0; c < CPL && x0 + c < tp.ow; ++c)
+                out[(size_t)y * ostep + x0 + c] = (uint8_t)(c < 4 ? (lo >> (8 * c)) : (hi >> (8 * (c - 4))));
+        }
+
+        // slide the window one row down
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int nbv = (int)byte_of(vnew, c), obv = (int)byte_of(vold, c);
+                const int d = nbv - obv, sm = nbv + obv;
+                VS[c] += (unsigned)d;
+                VQ[c] += (unsigned)(d * sm);
+            }
+        }
+    }
+
+}
+
+// ---- second stage: float64 interval test of the queued pixels, one thread per pixel ----------------
+template <int METHOD>
+__global__ void __launch_bounds__(256) k_refine(PageSetOut dst, FusedParams fp, PageGlobals* __restrict__ g,
+                                               const RefItem* __restrict__ rl, WorkItem* __restrict__ wl,
+                                               unsigned* __restrict__ counters)
+{
+    const unsigned n = min(counters[0], fp.ref_cap);
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const RefItem it = rl[i];
+        const unsigned r = refine64<METHOD>(fp, it.S, it.Q, it.p, (double)g[it.page].imin);
+        if (r != 2) {
+            dst.page(it.page)[(size_t)it.y * dst.step + it.x] = (uint8_t)r;
+            atomicAdd(&g[it.page].n_refined, 1u);
+        } else {
+            atomicAdd(&g[it.page].n_exact, 1u);
+            const unsigned idx = atomicAdd(&counters[1], 1u);
+            if (idx < fp.wl_cap) {
+                WorkItem w;
+                w.page = it.page;
+                w.y = it.y;
+                w.x = it.x;
+                w.pad = 0;
+                wl[idx] = w;
+            } else {
+                atomicOr(&g[it.page].worklist_overflow, 1u);
+            }
+        }
+    }
+}
+
+// ---- fix-up: literal evaluation of the queued pixels from absolute integral corners -----------
+// One workgroup per queued pixel.  The four absolute corners of cv::integral are rebuilt from the
+// page: II'(Y,X) = sum of the replicate-padded image over rows <= Y, cols <= X (exact integers), then
+// the literal float64 sequence of prl_device_math.h decides.  Rare by construction (see header).
+template <int METHOD>
+__global__ void __launch_bounds__(256) k_fixup(PageSet src, PageSetOut dst, FusedParams fp,
+                                              const PageGlobals* __restrict__ g,
+                                              const WorkItem* __restrict__ wl,
+                                              const unsigned* __restrict__ counters)
+{
+    const ThrParams& tp = fp.tp;
+    const unsigned n = min(counters[1], fp.wl_cap);
+    __shared__ unsigned long long red[4][8];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
+        const WorkItem wi = wl[it];
+        const uint8_t* img = src.page(wi.page);
+        const int Y0 = wi.y, X0 = wi.x, Y1 = wi.y + tp.w - 1, X1 = wi.x + tp.w - 1;
+        // acc[0..3] = sums of P over (top|bottom) x (left|right); acc[4..7] same for P*P
+        unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = wv; i <= Y1; i += 4) {
+            const uint8_t* row = img + (size_t)clampi(i - tp.half, 0, tp.height - 1) * src.step;
+            unsigned sl = 0, sr = 0, ql = 0, qr = 0;
+            for (int j = lane; j <= X1; j += kWave) {
+                const unsigned v = row[clampi(j - tp.half, 0, tp.width - 1)];
+                if (j <= X0) {
+                    sl += v;
+                    ql += v * v;
+                } else {
+                    sr += v;
+                    qr += v * v;
+                }
+            }
+            const int o = (i <= Y0) ? 0 : 2;
+            acc[o] += sl;
+            acc[o + 1] += sr;
+            acc[4 + o] += ql;
+            acc[4 + o + 1] += qr;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned long long v = acc[k];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
+            if (lane == 0) red[wv][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t[8];
+            for (int k = 0; k < 8; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+            const double A = (double)t[0], B = (double)(t[0] + t[1]), C = (double)(t[0] + t[2]),
+                         D = (double)(t[0] + t[1] + t[2] + t[3]);
+            const double AQ = (double)t[4], BQ = (double)(t[4] + t[5]), CQ = (double)(t[4] + t[6]),
+                         DQ = (double)(t[4] + t[5] + t[6] + t[7]);
+            const double m = box4_literal(A, B, C, D, tp.f);
+            const double q = box4_literal(AQ, BQ, CQ, DQ, tp.f);
+            const double s = dev_from(m, q);
+            const PageGlobals& pg = g[wi.page];
+            const double T = threshold_literal(tp, m, s, (double)pg.imin, pg.coeff);
+            const unsigned p = img[(size_t)wi.y * src.step + wi.x];
+            dst.page(wi.page)[(size_t)wi.y * dst.step + wi.x] = decide_literal(p, T);
+        }
+        __syncthreads();
+    }
+}
+
+template <int METHOD>
+int launch_fused(int sh, dim3 grid, hipStream_t stream, const PageSet& src, const PageSetOut& dst,
+                 const FusedParams& fp, PageGlobals* g, RefItem* rl, WorkItem* wl, unsigned* cnt)
+{
+    switch (sh) {
+    case 0: hipLaunchKernelGGL((k_fused<METHOD, 0>), grid, dim3(256), 0, stream, src, dst, fp, g, rl, cnt); break;
+    case 2: hipLaunchKernelGGL((k_fused<METHOD, 2>), grid, dim3(256), 0, stream, src, dst, fp, g, rl, cnt); break;
+    case 4: hipLaunchKernelGGL((k_fused<METHOD, 4>), grid, dim3(256), 0, stream, src, dst, fp, g, rl, cnt); break;
+    case 6: hipLaunchKernelGGL((k_fused<METHOD, 6>), grid, dim3(256), 0, stream, src, dst, fp, g, rl, cnt); break;
+    default: return PRL_ERR_BAD_ARG;
+    }
+    PRL_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL((k_refine<METHOD>), dim3(64), dim3(256), 0, stream, dst, fp, g, rl, wl, cnt);
+    PRL_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL((k_fixup<METHOD>), dim3(512), dim3(256), 0, stream, src, dst, fp, g, wl, cnt);
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
+}  // namespace
+
+// ---- host: error bounds (documented in DESIGN.md "Decision margins") ---------------------------
+// Exact-arithmetic quantities: m* = f S, q* = f Q, v* = q* - m*^2, s* = sqrt(v*), T* = T(m*, s*).
+//   Em, Eq   : |m_literal - m*|, |q_literal - q*| — 4 products and 3 sums of values <= f*IImax
+//              (resp. f*IQmax), each rounded once in float64, plus the rounding of f itself.
+//   vthr     : below this variance the literal sqrt amplifies Ev too much for a page-wide constant;
+//              such pixels take the float64 interval test.  Note v* >= m*^2 (2w-1)/(w-1)^2 always
+//              (the (w-1)^2 window divided by w^2), so only near-black windows get there.
+//   E1       : float32 evaluation error of eval32 (u = 2^-24), first order, worst-case magnitudes
+//              m <= 255, s <= 255; kappa is the relative error of s~ after the q - m^2 cancellation,
+//              bounded through m*^2 <= R v*, R = (w-1)^2/(2w-1).
+//   Elit     : |T_literal - T*| for v* >= vthr.
+//   eps1     : 2 (E1 + Elit) + 1e-6.
+struct FusedBounds {
+    double Em, Eq, vthr, E1, Elit, eps1, kappa;
+};
+
+static FusedBounds fused_bounds(const ThrParams& tp)
+{
+    FusedBounds b{};
+    const double u = std::ldexp(1.0, -24), e64 = std::ldexp(1.0, -53);
+    const double n1 = tp.w - 1.0, R = n1 * n1 / (2.0 * tp.w - 1.0);
+    const double M = 255.0, SM = 255.0;
+    const double IImax = 255.0 * tp.pw * (double)tp.ph, IQmax = 65025.0 * tp.pw * (double)tp.ph;
+    b.Em = 16.0 * e64 * tp.f * IImax;
+    b.Eq = 16.0 * e64 * tp.f * IQmax;
+    const double Ev = b.Eq + 2.0 * M * b.Em + b.Em * b.Em;
+    b.vthr = std::fmax(1e-2, 64.0 * Ev);
+    const double Es = 1.01 * Ev / std::sqrt(b.vthr - Ev);
+    b.kappa = (4.0 + 3.5 * R) * u * 1.1;
+    const double k = std::fabs(tp.k);
+    switch (tp.method) {
+    case PRL_SAUVOLA: {
+        const double a = std::fabs(tp.a), bb = std::fabs(tp.b), Dmax = a * SM + bb;
+        b.E1 = M * (a * SM * (b.kappa + 2 * u) + bb * u + u * Dmax) + 3 * u * M * Dmax + u * (256 + M * Dmax);
+        b.Elit = M * a * Es + Dmax * b.Em;
+        break;
+    }
+    case PRL_NIBLACK:
+        b.E1 = k * SM * (b.kappa + 2 * u) + 2 * u * M + u * (256 + M + k * SM);
+        b.Elit = k * Es + b.Em;
+        break;
+    case PRL_NICK: {
+        const double Ec = 1.01 * (b.Eq + 1e-10) / std::sqrt(b.vthr - b.Eq - 1e-10);
+        b.E1 = k * SM * 4.5 * u + 2 * u * M + u * (256 + M + k * SM);
+        b.Elit = b.Em + k * Ec;
+        break;
+    }
+    case PRL_FENG: {
+        const double gcoef = std::fabs(1.0 + tp.c1), c3 = 255.0 * (std::fabs(tp.k2) + 1.0);
+        b.E1 = gcoef * M * 3 * u + c3 * u + u * (256 + gcoef * M + c3);
+        b.Elit = gcoef * b.Em + 1e-10;
+        break;
+    }
+    default:
+        b.E1 = b.Elit = 1e30;
+    }
+    b.eps1 = 2.0 * (b.E1 + b.Elit) + 1e-6;
+    return b;
+}
+
+extern "C" int prl_hip_internal_fused_bounds(const prl_binarize_params* p, int width, int height, double* out8)
+{
+    // test hook (not in the public header): the decision margins for (params, page size)
+    prl_binarize_geometry g;
+    int st = prl_hip_binarize_geometry(p, width, height, &g);
+    if (st != PRL_OK) return st;
+    ThrParams tp{};
+    tp.method = p->method;
+    tp.w = g.w;
+    tp.pw = g.padded_w;
+    tp.ph = g.padded_h;
+    tp.f = 1.0 / (double)(g.w * g.w);
+    tp.k = p->k;
+    tp.a = p->k * (1.0 / 128.0);
+    tp.b = 1.0 - p->k;
+    tp.c1 = 1.0 - p->feng_alpha1;
+    tp.k2 = p->feng_k2;
+    const FusedBounds b = fused_bounds(tp);
+    out8[0] = b.Em; out8[1] = b.Eq; out8[2] = b.vthr; out8[3] = b.E1;
+    out8[4] = b.Elit; out8[5] = b.eps1; out8[6] = b.kappa; out8[7] = 0;
+    return PRL_OK;
+}
+
+bool fused_supports(const ThrParams& tp)
+{
+    if (tp.method == PRL_WOLFJOLION) return false;           // two-pass; literal pipeline for now
+    if (((tp.w - 1) & 1) != 0) return false;                 // even (clamped) window: rare, literal
+    if (tp.w - 1 > 256 || tp.w < 3) return false;            // window sums must stay exact in float32/u32
+    if (!std::isfinite(tp.k) || std::fabs(tp.k) > 1e3) return false;
+    if (tp.method == PRL_FENG && !(tp.gamma > 0.0)) return false;
+    if (tp.method == PRL_FENG && (!std::isfinite(tp.c1) || !std::isfinite(tp.k2) ||
+                                  std::fabs(tp.c1) > 1e3 || std::fabs(tp.k2) > 1e3)) return false;
+    return true;
+}
+
+size_t fused_small_bytes(int)
+{
+    return 256 + sizeof(RefItem) * (size_t)kRefineCap + sizeof(WorkItem) * (size_t)kWorkCap;
+}
+
+int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst, void* small,
+              PageGlobals* d_globals, hipStream_t stream)
+{
+    FusedParams fp{};
+    fp.tp = tp;
+    fp.uo = ((SW - (tp.w - 1)) / 8) * 8;
+    fp.n_strips = (tp.ow + fp.uo - 1) / fp.uo;
+    // rows per segment: long segments amortise the (w-1)-row warm-up, short ones fill the chip
+    int rps = 256;
+    const long long waves_at = (long long)n_pages * fp.n_strips * ((tp.oh + rps - 1) / rps);
+    if (waves_at < 8192) rps = 128;
+    if ((long long)n_pages * fp.n_strips * ((tp.oh + rps - 1) / rps) < 8192) rps = 64;
+    if (rps < tp.w) rps = ((tp.w + 63) / 64) * 64;
+    fp.rows_per_seg = rps;
+    fp.n_segs = (tp.oh + rps - 1) / rps;
+    fp.lane_off = (tp.w - 1) / 8;
+    const unsigned long long tw = (unsigned long long)n_pages * fp.n_strips * fp.n_segs;
+    if (tw > 0xfffffff0ull) return PRL_ERR_BAD_ARG;
+    fp.total_waves = (unsigned)tw;
+    const FusedBounds b = fused_bounds(tp);
+    fp.ff = (float)tp.f;
+    fp.Em = b.Em;
+    fp.Eq = b.Eq;
+    fp.vthr = b.vthr;
+    fp.vthr32 = (float)(b.vthr * 1.01);
+    fp.eps1 = (float)(b.eps1 * 1.01);
+    fp.ref_cap = kRefineCap;
+    fp.wl_cap = kWorkCap;
+    switch (tp.method) {
+    case PRL_SAUVOLA: fp.c0 = (float)tp.a; fp.c1 = (float)tp.b; break;
+    case PRL_NIBLACK: fp.c0 = (float)tp.k; break;
+    case PRL_NICK: fp.c0 = (float)tp.k; break;
+    case PRL_FENG: fp.c0 = (float)(1.0 + tp.c1); break;
+    default: return PRL_ERR_BAD_ARG;
+    }
+
+    auto* cnt = static_cast<unsigned*>(small);  // [0] refine-list length, [1] fix-up-list length
+    auto* rl = reinterpret_cast<RefItem*>(static_cast<uint8_t*>(small) + 256);
+    auto* wl = reinterpret_cast<WorkItem*>(static_cast<uint8_t*>(small) + 256 + sizeof(RefItem) * (size_t)kRefineCap);
+    PRL_HIP_CHECK(hipMemsetAsync(cnt, 0, 256, stream));
+
+    if (tp.method == PRL_FENG) {
+        int st = page_min_run(tp, src, n_pages, d_globals, stream);
+        if (st != PRL_OK) return st;
+    }
+    unsigned blocks = (fp.total_waves + 3) / 4;
+    blocks = (blocks + 7) / 8 * 8;
+    const int sh = (tp.w - 1) & 7;
+    switch (tp.method) {
+    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt);
+    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt);
+    case PRL_NICK: return launch_fused<PRL_NICK>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt);
+    case PRL_FENG: return launch_fused<PRL_FENG>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt);
+    default: return PRL_ERR_BAD_ARG;
+    }
 }
 
 }  // namespace prl_hip

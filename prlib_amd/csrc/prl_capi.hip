@@ -87,6 +87,20 @@ int ensure_scratch(DeviceCtx* ctx, size_t bytes)
     return PRL_OK;
 }
 
+int ensure_mask(DeviceCtx* ctx, size_t bytes)
+{
+    if (ctx->mask_bytes >= bytes) return PRL_OK;
+    if (ctx->mask) {
+        PRL_HIP_CHECK(hipDeviceSynchronize());
+        PRL_HIP_CHECK(hipFree(ctx->mask));
+        ctx->mask = nullptr;
+        ctx->mask_bytes = 0;
+    }
+    PRL_HIP_CHECK(hipMalloc(&ctx->mask, bytes));
+    ctx->mask_bytes = bytes;
+    return PRL_OK;
+}
+
 int ensure_small(DeviceCtx* ctx, size_t bytes)
 {
     if (ctx->small_bytes >= bytes) return PRL_OK;
@@ -252,22 +266,20 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
     const size_t mask_bytes = morph != 0 ? mask_page * (size_t)n_pages : 0;
 
     const bool use_fused = exec_mode() == PRL_MODE_AUTO && fused_supports(tp);
-    size_t literal_pages_per_chunk = 0, literal_bytes = 0;
+    const size_t literal_per_page = literal_scratch_per_page(tp);
+    size_t literal_pages_per_chunk = 0;
     if (!use_fused) {
-        const size_t per_page = literal_scratch_per_page(tp);
-        literal_pages_per_chunk = std::max<size_t>(1, literal_scratch_budget() / per_page);
+        literal_pages_per_chunk = std::max<size_t>(1, literal_scratch_budget() / literal_per_page);
         literal_pages_per_chunk = std::min<size_t>(literal_pages_per_chunk, (size_t)n_pages);
-        literal_bytes = per_page * literal_pages_per_chunk;
-    }
-    const size_t mask_off = (literal_bytes + 255) / 256 * 256;
-    if (mask_off + mask_bytes > 0) {
-        st = ensure_scratch(ctx, mask_off + mask_bytes);
+        st = ensure_scratch(ctx, literal_per_page * literal_pages_per_chunk);
         if (st != PRL_OK) return st;
     }
     PageSetOut thr_dst = dst;
     if (morph != 0) {
+        st = ensure_mask(ctx, mask_bytes);
+        if (st != PRL_OK) return st;
         thr_dst = PageSetOut{};
-        thr_dst.base = static_cast<uint8_t*>(ctx->scratch) + mask_off;
+        thr_dst.base = static_cast<uint8_t*>(ctx->mask);
         thr_dst.page_stride = mask_page;
         thr_dst.step = mask_step;
     }
@@ -284,6 +296,22 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
     if (use_fused) {
         st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream);
         if (st != PRL_OK) return st;
+        // Pages whose fix-up list overflowed (pathological: a large share of their pixels sits within
+        // ~1e-6 of the decision boundary) are redone by the literal pipeline.  Knowing that needs the
+        // per-page flags on the host, hence one stream synchronisation per call.
+        std::vector<PageGlobals> hg((size_t)n_pages);
+        PRL_HIP_CHECK(hipMemcpyAsync(hg.data(), d_globals, sizeof(PageGlobals) * (size_t)n_pages,
+                                     hipMemcpyDeviceToHost, stream));
+        PRL_HIP_CHECK(hipStreamSynchronize(stream));
+        for (int i = 0; i < n_pages; ++i) {
+            if (!hg[(size_t)i].worklist_overflow) continue;
+            st = ensure_scratch(ctx, literal_per_page);
+            if (st != PRL_OK) return st;
+            // (the page minimum Feng needs is already in the globals: fused_run reduced it)
+            st = literal_run(tp, src, i, 1, thr_dst, ctx->scratch, d_globals, stream);
+            if (st != PRL_OK) return st;
+            t_last.literal_pages += 1;
+        }
     } else {
         if (tp.method == PRL_WOLFJOLION || tp.method == PRL_FENG) {
             st = page_min_run(tp, src, n_pages, d_globals, stream);
@@ -381,6 +409,9 @@ int prl_hip_release_workspace(void)
     if (ctx->scratch) PRL_HIP_CHECK(hipFree(ctx->scratch));
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
+    if (ctx->mask) PRL_HIP_CHECK(hipFree(ctx->mask));
+    ctx->mask = nullptr;
+    ctx->mask_bytes = 0;
     if (ctx->small) PRL_HIP_CHECK(hipFree(ctx->small));
     ctx->small = nullptr;
     ctx->small_bytes = 0;
@@ -406,7 +437,6 @@ int prl_hip_last_stats(prl_binarize_stats* out)
     for (const auto& pg : g) {
         out->refined_pixels += pg.n_refined;
         out->exact_pixels += pg.n_exact;
-        out->literal_pages += pg.worklist_overflow ? 1 : 0;
     }
     return PRL_OK;
 }

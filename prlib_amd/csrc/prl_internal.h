@@ -28,8 +28,10 @@ void set_error_detail(const std::string& s);
 struct DeviceCtx {
     std::mutex mu;          // one binarize/denoise call at a time per device (scratch is shared)
     int device = -1;
-    void* scratch = nullptr;
+    void* scratch = nullptr;   // literal pipeline: float64 integral planes
     size_t scratch_bytes = 0;
+    void* mask = nullptr;      // thresholded masks waiting for the morphology pass
+    size_t mask_bytes = 0;
     void* small = nullptr;  // counters / work lists / per-page globals
     size_t small_bytes = 0;
     void* pinned = nullptr; // pinned host staging for tiny transfers
@@ -41,6 +43,7 @@ struct DeviceCtx {
 int current_device(int* dev);             // validates that a gfx950 device is usable
 DeviceCtx* device_ctx(int dev);
 int ensure_scratch(DeviceCtx* ctx, size_t bytes);
+int ensure_mask(DeviceCtx* ctx, size_t bytes);
 int ensure_small(DeviceCtx* ctx, size_t bytes);
 int ensure_pinned(DeviceCtx* ctx, size_t bytes);
 

@@ -175,3 +175,45 @@ def test_c2_full_page_sauvola_w15(prl, oracle, cuda_device):
     page = synth.page_numpy(4096, 4096, index=0)
     st = _check(prl, oracle, cuda_device, [page], SAUVOLA, 15, 0.34, 0)
     assert st.pixels == 4095 * 4095
+
+
+def _flat_boundary_k(c, w, p):
+    """k for which Sauvola's exact-arithmetic threshold on a flat page of value c equals p - 0.5."""
+    n = (w - 1) ** 2
+    f = 1.0 / (w * w)
+    m = f * c * n
+    v = f * c * c * n - m * m
+    s = v ** 0.5
+    return ((p - 0.5) / m - 1.0) / (s / 128.0 - 1.0)
+
+
+def test_undecidable_pixels_go_through_refine_and_fixup(prl, oracle, cuda_device):
+    """Flat page whose threshold sits within ~1e-13 of p - 0.5: every pixel defeats the float32 test
+    and the float64 interval test, so the absolute-integral fix-up decides all of them."""
+    w, c = 15, 200
+    k = _flat_boundary_k(c, w, c)
+    page = np.full((96, 120), c, np.uint8)
+    st = _check(prl, oracle, cuda_device, [page], SAUVOLA, w, k, 0)
+    assert st.exact_pixels > 0.9 * st.pixels
+    assert st.literal_pages == 0
+    # a few boundary pixels inside an ordinary page: only those take the slow stages
+    doc = _pages((128, 160), ["doc"], seed=23)[0]
+    doc[40:70, 50:100] = c
+    st = _check(prl, oracle, cuda_device, [doc], SAUVOLA, w, k, 0)
+    assert 0 < st.exact_pixels + st.refined_pixels < 0.2 * st.pixels
+
+
+def test_fixup_list_overflow_falls_back_to_literal_pipeline(prl, oracle, cuda_device):
+    w, c = 15, 200
+    k = _flat_boundary_k(c, w, c)
+    pages = [np.full((640, 700), c, np.uint8), _pages((640, 700), ["doc"], seed=29)[0]]
+    st = _check(prl, oracle, cuda_device, pages, SAUVOLA, w, k, 0)
+    assert st.literal_pages == 1
+    st = _check(prl, oracle, cuda_device, pages, SAUVOLA, w, k, 2)  # with morphology after the rerun
+    assert st.literal_pages == 1
+
+
+def test_auto_mode_uses_the_fused_kernel(prl, oracle, cuda_device):
+    pages = _pages((300, 600), ["doc", "doc"], seed=31)
+    st = _check(prl, oracle, cuda_device, pages, SAUVOLA, 31, 0.34, 0)
+    assert st.literal_pages == 0 and st.exact_pixels < 50
