@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixels/s of Sauvola w=31 on a batch of 4K pages (BASELINE.json metric).
+
+One "step" = one pass of prl_hip_binarize_batch_device over the whole resident batch (256 pages of
+4096x4096 u8 per GPU by default).  Pages are generated on the device before the timed region; every
+rank owns its own batch (independent pages => no data-path collective; weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).  `roofline.achieved` is the
+algorithmic byte count of one launch (1 B read + 1 B written per output pixel) over the average
+duration of the dominant kernel (k_fused), measured with HIP events inside the library on the
+stream the kernel runs on.  `cpu_baseline` times the CPU oracle (oracle/, the literal restatement of
+the reference) on a bounded sample of the same pages on this box's host cores; it is a reported
+baseline, never part of the measured path.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pages", type=int, default=256, help="pages per GPU")
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--method", default="sauvola")
+    ap.add_argument("--window", type=int, default=31)
+    ap.add_argument("--k", type=float, default=0.34)
+    ap.add_argument("--morph", type=int, default=0)
+    ap.add_argument("--mode", default="auto", choices=["auto", "literal"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--check-pages", type=int, default=1, help="pages verified against the oracle after timing")
+    return ap.parse_args()
+
+
+def cpu_baseline(pages_host, params_oracle, budget_s):
+    """Time the CPU oracle (kind 'port') on a bounded sample of the same pages, all host cores."""
+    from oracle import capi as oc
+
+    cores = os.cpu_count() or 1
+    n_avail, h, w = pages_host.shape
+    t0 = time.perf_counter()
+    out1 = oc.binarize_batch(pages_host[:1], params_oracle, threads=1)
+    t1 = time.perf_counter() - t0
+    px_page = out1.shape[1] * out1.shape[2]
+    # pages for roughly budget_s seconds with `cores` threads (assume ~linear up to memory bandwidth)
+    n = int(max(cores, min(n_avail, (budget_s / max(t1, 1e-3)) * max(1, cores // 2))))
+    n = min(n, n_avail)
+    t0 = time.perf_counter()
+    oc.binarize_batch(pages_host[:n], params_oracle, threads=cores)
+    tn = time.perf_counter() - t0
+    return {
+        "value": round(n * px_page / tn / 1e6, 2),
+        "unit": "Mpixels/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{n} of the benchmark's pages ({w}x{h}), oracle/prl_oracle.c with {cores} OpenMP threads, "
+                  f"{tn:.1f} s; single-thread 1 page: {px_page / t1 / 1e6:.2f} Mpixels/s",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path in prlib_amd)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import prlib_amd
+    from prlib_amd import _capi, synth
+
+    H = args.height or args.size
+    W = args.size
+    method = prlib_amd.binarizations.METHODS[args.method]
+    params = prlib_amd.make_params(method, args.window, args.k, args.morph)
+    g = prlib_amd.geometry(params, W, H)
+    prlib_amd.set_exec_mode(1 if args.mode == "literal" else 0)
+
+    # synthetic pages, resident in HBM before the timed region; each rank draws its own pages
+    pitch = (W + 255) // 256 * 256
+    pages = synth.pages_torch(args.pages, H, W, dev, seed=1000 + rank * args.pages, pitch=pitch)
+    out, out_pitch = prlib_amd.binarizations.alloc_output(args.pages, g.out_w, g.out_h, dev)
+    L = _capi.lib()
+
+    def step():
+        prlib_amd.binarize(pages, params, out=out)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant-kernel duration: HIP events recorded by the library around k_fused on the launch stream
+    _capi.check(L.prl_hip_set_profiling(1))
+    kms = []
+    for _ in range(max(3, min(args.steps, 10))):
+        step()
+        ms = C.c_float(0)
+        _capi.check(L.prl_hip_last_kernel_ms(C.byref(ms)))
+        kms.append(ms.value)
+    _capi.check(L.prl_hip_set_profiling(0))
+    kernel_ms = sum(kms) / len(kms)
+    stats = prlib_amd.last_stats()
+
+    px_per_step_rank = args.pages * g.out_w * g.out_h
+    bytes_per_px = 3 if method == prlib_amd.WOLFJOLION else 2
+    alg_bytes = args.pages * (H * W * (bytes_per_px - 1) + g.out_w * g.out_h)
+    achieved_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    # parity spot check (outside the timed region): first pages against the CPU oracle
+    mismatches = None
+    cpu = None
+    if rank == 0:
+        from oracle import capi as oc
+
+        po = oc.make_params(method, args.window, args.k, args.morph)
+        n_chk = min(args.check_pages, args.pages)
+        if n_chk > 0:
+            host = pages[:n_chk].cpu().numpy()
+            want = oc.binarize_batch(host.copy(), po, threads=os.cpu_count() or 1)
+            got = out[:n_chk, :, : g.out_w].cpu().numpy()
+            mismatches = int((want != got).sum())
+        if args.cpu_seconds > 0:
+            n_host = min(args.pages, 64)
+            cpu = cpu_baseline(pages[:n_host].cpu().numpy().copy(), po, args.cpu_seconds)
+
+    if rank == 0:
+        value = world * px_per_step_rank * args.steps / elapsed / 1e6
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        key = f"{args.method}_w{args.window}_{args.pages}x{W}x{H}_{args.mode}"
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(key)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mpixels/s Sauvola w=31 on batched 4K pages" if (args.method == "sauvola" and args.window == 31)
+            else f"Mpixels/s {args.method} w={args.window}",
+            "value": round(value, 1),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 in/out; exact u32 window sums; f32 decision with f64/literal refinement",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.pages} x {W}x{H} u8 pages per GPU, {args.method} k={args.k} w={args.window} "
+                            f"morph={args.morph}, mode={args.mode}",
+                "pages_per_gpu": args.pages,
+                "parallelism": f"pages sharded over {world} GPU(s), no collectives",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved_gbs, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "kernel": "k_fused" if args.mode == "auto" else "literal chain",
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_launch": alg_bytes,
+            },
+            "cpu_baseline": cpu,
+            "parity": {"checked_pages": min(args.check_pages, args.pages), "mismatching_pixels": mismatches,
+                       "refined_pixels": int(stats.refined_pixels), "exact_pixels": int(stats.exact_pixels),
+                       "literal_pages": int(stats.literal_pages)},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,6 +114,11 @@ int         prl_hip_set_exec_mode(int mode);           /* prl_exec_mode */
 int         prl_hip_get_exec_mode(void);
 int         prl_hip_last_stats(prl_binarize_stats* out);
 int         prl_hip_release_workspace(void);           /* free cached device scratch of the current device */
+/* Measurement aid: when enabled, HIP events bracket the dominant kernel of each binarize call
+ * (k_fused in PRL_MODE_AUTO, the whole integral+threshold chain in PRL_MODE_LITERAL) on the stream it
+ * is launched on; prl_hip_last_kernel_ms() waits for them and returns the elapsed milliseconds. */
+int         prl_hip_set_profiling(int enabled);
+int         prl_hip_last_kernel_ms(float* ms);
 
 /* ---- binarizers -------------------------------------------------------------------------- */
 

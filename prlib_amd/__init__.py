@@ -4,8 +4,8 @@ The product is libprlib_hip.so (hand-written HIP kernels behind the C ABI of inc
 This package is the thin Python host layer used by the tests and the benchmark; the C++ host layer
 with the reference's prl::binarize*(cv::Mat&, cv::Mat&, ...) signatures lives in csrc/prl/.
 """
-from . import _capi  # noqa: F401
-from .binarize import (  # noqa: F401
+from . import _capi, binarizations  # noqa: F401
+from .binarizations import (  # noqa: F401
     FENG, NICK, NIBLACK, SAUVOLA, WOLFJOLION, binarize, binarizeFeng, binarizeNICK, binarizeNiblack,
     binarizeSauvola, binarizeWolfJolion, default_params, geometry, last_stats, make_params, morph,
     set_exec_mode,

@@ -83,24 +83,6 @@ __device__ __forceinline__ unsigned byte_of(uint2 v, int c)
     return (w >> (8 * (c & 3))) & 0xffu;
 }
 
-// 8 consecutive pixels of one image row starting at column col0, replicate-clamped to [0, W-1]
-__device__ __forceinline__ uint2 load_row8(const uint8_t* __restrict__ row, int col0, int W, bool interior)
-{
-    uint2 v;
-    if (interior) {
-        __builtin_memcpy(&v, row + col0, 8);  // one (possibly unaligned) global_load_dwordx2
-    } else {
-        unsigned lo = 0, hi = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) lo |= (unsigned)row[clampi(col0 + c, 0, W - 1)] << (8 * c);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) hi |= (unsigned)row[clampi(col0 + 4 + c, 0, W - 1)] << (8 * c);
-        v.x = lo;
-        v.y = hi;
-    }
-    return v;
-}
-
 // ---- float32 evaluation: returns t = (p - 0.5) - T~ and the float32 variance v~ -----------------
 //   SAUVOLA  c0 = k/128, c1 = 1-k          T = m*(s*c0 + c1)
 //   NIBLACK  c0 = k                        T = s*c0 + m
@@ -176,61 +158,85 @@ __device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, 
     return 2;
 }
 
-template <int METHOD, int SH>
-__global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, FusedParams fp,
-                                              PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
-                                              unsigned* __restrict__ counters)
+typedef const uint8_t __attribute__((address_space(1)))* gcptr;  // known-global pointers: global_load, not flat_load
+typedef uint8_t __attribute__((address_space(1)))* gptr;
+
+__device__ __forceinline__ uint2 gload8(gcptr p)
+{
+    uint2 v;
+    __builtin_memcpy(&v, (const uint8_t*)p, 8);
+    return v;
+}
+
+// Per-lane constants of the replicate clamp for an 8-byte row fetch: the fetch address is clamped
+// into the row and the bytes are shifted/filled afterwards (edge strips only).
+struct EdgeFix {
+    int colc;   // clamped fetch column
+    int sh;     // wanted column - fetch column: <0 fill from the left edge, >0 from the right edge
+};
+
+__device__ __forceinline__ EdgeFix make_edge(int col, int W)
+{
+    EdgeFix e;
+    e.colc = clampi(col, 0, W - 8);
+    e.sh = col - e.colc;
+    return e;
+}
+
+__device__ __forceinline__ uint2 apply_edge(uint2 v, int sh)
+{
+    if (sh != 0) {
+        unsigned long long x = ((unsigned long long)v.y << 32) | v.x;
+        const unsigned long long ones = 0x0101010101010101ull;
+        if (sh < 0) {
+            const int k = min(-sh, 8);
+            const unsigned long long b0 = (x & 0xffull) * ones;
+            x = (k >= 8) ? b0 : ((x << (8 * k)) | (b0 & ((1ull << (8 * k)) - 1ull)));
+        } else {
+            const int k = min(sh, 8);
+            const unsigned long long b7 = (x >> 56) * ones;
+            x = (k >= 8) ? b7 : ((x >> (8 * k)) | (b7 << (64 - 8 * k)));
+        }
+        v.x = (unsigned)x;
+        v.y = (unsigned)(x >> 32);
+    }
+    return v;
+}
+
+// One wavefront: a strip of SW padded columns x a segment of output rows.
+//   EDGE  : the strip touches the left/right page border (replicate clamp, partial stores)
+template <int METHOD, int SH, bool EDGE>
+__device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, size_t ostep,
+                                           const FusedParams& fp, int page, int xs, int ys, int ye, int lane,
+                                           float c1page, PageGlobals* __restrict__ g,
+                                           RefItem* __restrict__ rl, unsigned* __restrict__ counters)
 {
     const ThrParams& tp = fp.tp;
-    const int lane = threadIdx.x & (kWave - 1);
-    // XCD-aware block order: hardware deals blocks round-robin over the 8 XCDs, so blocks b and b+8
-    // share an L2.  Give each XCD a contiguous range of logical blocks (= neighbouring strips and
-    // segments of the same pages) so halo re-reads hit that XCD's L2.  Speed only, never correctness.
-    const unsigned nb = gridDim.x;
-    const unsigned lb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
-    const unsigned wid = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
-    if (wid >= fp.total_waves) return;
-    const int per_page = fp.n_strips * fp.n_segs;
-    const int page = (int)(wid / (unsigned)per_page);
-    const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
-    const int seg = rem / fp.n_strips;
-    const int strip = rem - seg * fp.n_strips;
-
-    const uint8_t* __restrict__ img = src.page(page);
-    uint8_t* __restrict__ out = dst.page(page);
-    const size_t istep = src.step, ostep = dst.step;
     const int W = tp.width, H = tp.height, h = tp.half, w = tp.w;
-
-    const int xs = strip * fp.uo;                 // first output column of the strip
-    const int ys = seg * fp.rows_per_seg;         // first output row of the segment
-    const int ye = min(ys + fp.rows_per_seg, tp.oh);
-    const int col0 = xs + 1 - h + CPL * lane;     // image column of this lane's sub-column 0
-    const bool interior = (col0 >= 0) && (col0 + CPL <= W);
-    const int x0 = xs + CPL * lane;               // first output column of this lane
+    const int col0 = xs + 1 - h + CPL * lane;  // image column of this lane's sub-column 0
+    const int x0 = xs + CPL * lane;            // first output column of this lane
     const bool lane_has_out = (CPL * lane < fp.uo) && (x0 < tp.ow);
     const bool full8 = lane_has_out && (x0 + CPL <= tp.ow);
-    // lane that holds E(j0 + w - 1): byte address for ds_bpermute
-    const int far_addr0 = (lane + fp.lane_off) * 4;
+    const EdgeFix ew = EDGE ? make_edge(col0, W) : EdgeFix{col0, 0};
+    const EdgeFix ep = make_edge(x0, W);  // lanes without output fetch a clamped (ignored) location
+    const int far_addr0 = (lane + fp.lane_off) * 4;  // ds_bpermute byte address of the lane holding E(j0+w-1)
     const int far_addr1 = far_addr0 + 4;
 
-    float c1page = fp.c1;
-    if (METHOD == PRL_FENG) {
-        const double imin = (double)g[page].imin;
-        const double c3 = (tp.k2 * imin + (-imin)) + 0.0;  // binarizeFeng.cpp:137 with r2 = c2 = 1
-        c1page = (float)c3;
-    }
+    auto load_win = [&](int padded_row) -> uint2 {
+        const size_t ro = (size_t)clampi(padded_row - h, 0, H - 1) * istep;  // wave-uniform
+        uint2 v = gload8(img + ro + ew.colc);
+        if (EDGE) v = apply_edge(v, ew.sh);
+        return v;
+    };
 
     unsigned VS[CPL], VQ[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) VS[c] = VQ[c] = 0;
 
-    auto row_ptr = [&](int padded_row) -> const uint8_t* {
-        return img + (size_t)clampi(padded_row - h, 0, H - 1) * istep;
-    };
-
     // warm-up: vertical sums over padded rows ys+1 .. ys+w-1
+#pragma unroll 2
     for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
-        const uint2 v = load_row8(row_ptr(pr), col0, W, interior);
+        const uint2 v = load_win(pr);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const unsigned b = byte_of(v, c);
@@ -239,24 +245,13 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
         }
     }
 
+#pragma unroll 1
     for (int y = ys; y < ye; ++y) {
-        // issue next iteration's loads early: entering row y+w, leaving row y+1
-        uint2 vnew = make_uint2(0, 0), vold = make_uint2(0, 0);
-        const bool more = (y + 1 < ye);
-        if (more) {
-            vnew = load_row8(row_ptr(y + w), col0, W, interior);
-            vold = load_row8(row_ptr(y + 1), col0, W, interior);
-        }
-        // compared pixels p = page(y, x0..x0+7)
-        uint2 pv = make_uint2(0, 0);
-        if (lane_has_out) {
-            const uint8_t* prow = img + (size_t)y * istep;
-            if (x0 + CPL <= W) {
-                __builtin_memcpy(&pv, prow + x0, 8);
-            } else {
-                pv = load_row8(prow, x0, W, false);
-            }
-        }
+        // loads of this iteration: compared pixels now, entering/leaving rows for the slide at the end
+        uint2 pv = gload8(img + (size_t)y * istep + ep.colc);
+        const uint2 vnew = load_win(y + w);   // clamped row index: harmless on the last iteration
+        const uint2 vold = load_win(y + 1);
+        if (EDGE) pv = apply_edge(pv, ep.sh);
 
         // horizontal window sums: E = exclusive prefix over the strip, S(j0) = E(j0+w-1) - E(j0)
         unsigned ES[CPL], EQ[CPL];
@@ -280,41 +275,57 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
         unsigned Ssum[CPL], Qsum[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int sub = (c + SH) & 7;                 // compile-time
+            const int sub = (c + SH) & 7;  // compile-time
             const int addr = (c + SH) >= 8 ? far_addr1 : far_addr0;
-            const unsigned fs = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)ES[sub]);
-            const unsigned fq = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)EQ[sub]);
-            Ssum[c] = fs - ES[c];
-            Qsum[c] = fq - EQ[c];
+            Ssum[c] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)ES[sub]) - ES[c];
+            Qsum[c] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)EQ[sub]) - EQ[c];
         }
 
-        // float32 decision; what it cannot settle is queued with its exact sums for k_refine
+        // float32 decision; tmin/vmin track the smallest margin / variance of the lane's 8 pixels
         unsigned lo = 0, hi = 0;
+        float tmin = 3.0e38f, vmin = 3.0e38f;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const unsigned p = byte_of(pv, c);
             const float P = (float)p - 0.5f;
             float v32;
             const float t = eval32<METHOD>(fp, Ssum[c], Qsum[c], P, c1page, &v32);
-            const bool sure = ((fabsf(t) > fp.eps1) && (v32 > fp.vthr32)) || (p == 0);
+            tmin = fminf(tmin, fabsf(t));
+            vmin = fminf(vmin, v32);
             const bool white = (t > 0.0f) && (p != 0);
-            const unsigned o = white ? 0xffu : 0u;
-            if (c < 4) lo |= o << (8 * c); else hi |= o << (8 * (c - 4));
-            if (!sure && lane_has_out && (x0 + c < tp.ow)) {
-                const unsigned idx = atomicAdd(&counters[0], 1u);
-                if (idx < fp.ref_cap) {
-                    RefItem it;
-                    it.page = page;
-                    it.y = y;
-                    it.x = x0 + c;
-                    it.S = Ssum[c];
-                    it.Q = Qsum[c];
-                    it.p = p;
-                    rl[idx] = it;
-                } else {
-                    atomicOr(&g[page].worklist_overflow, 1u);
+            const unsigned o = white ? (0xffu << (8 * (c & 3))) : 0u;
+            if (c < 4) lo |= o; else hi |= o;
+        }
+
+        // rare: some pixel of this lane is not settled by the float32 test -> queue it for k_refine
+        const bool unsure = lane_has_out && !((tmin > fp.eps1) && (vmin > fp.vthr32));
+        if (__ballot(unsure) != 0ull) {
+            if (unsure) {
+#pragma unroll 1
+                for (int c = 0; c < CPL; ++c) {
+                    if (x0 + c >= tp.ow) break;
+                    const unsigned p = (c < 4 ? pv.x >> (8 * c) : pv.y >> (8 * (c - 4))) & 0xffu;
+                    if (p == 0) continue;  // 0 > T8 is false whatever T is
+                    const unsigned S = c == 0 ? Ssum[0] : c == 1 ? Ssum[1] : c == 2 ? Ssum[2] : c == 3 ? Ssum[3]
+                                     : c == 4 ? Ssum[4] : c == 5 ? Ssum[5] : c == 6 ? Ssum[6] : Ssum[7];
+                    const unsigned Q = c == 0 ? Qsum[0] : c == 1 ? Qsum[1] : c == 2 ? Qsum[2] : c == 3 ? Qsum[3]
+                                     : c == 4 ? Qsum[4] : c == 5 ? Qsum[5] : c == 6 ? Qsum[6] : Qsum[7];
+                    float v32;
+                    const float t = eval32<METHOD>(fp, S, Q, (float)p - 0.5f, c1page, &v32);
+                    if ((fabsf(t) > fp.eps1) && (v32 > fp.vthr32)) continue;
+                    const unsigned idx = atomicAdd(&counters[0], 1u);
+                    if (idx < fp.ref_cap) {
+                        RefItem it;
+                        it.page = page;
+                        it.y = y;
+                        it.x = x0 + c;
+                        it.S = S;
+                        it.Q = Q;
+                        it.p = p;
+                        rl[idx] = it;
+                    } else {
+                        atomicOr(&g[page].worklist_overflow, 1u);
+                    }
                 }
             }
         }
@@ -322,24 +333,65 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
         // store 8 mask bytes
         if (full8) {
             uint2 o = make_uint2(lo, hi);
-            __builtin_memcpy(out + (size_t)y * ostep + x0, &o, 8);
-        } else if (lane_has_out) {
+            __builtin_memcpy((uint8_t*)(out + (size_t)y * ostep + x0), &o, 8);
+        } else if (EDGE && lane_has_out) {
             for (int c = 0; c < CPL && x0 + c < tp.ow; ++c)
                 out[(size_t)y * ostep + x0 + c] = (uint8_t)(c < 4 ? (lo >> (8 * c)) : (hi >> (8 * (c - 4))));
         }
 
         // slide the window one row down
-        if (more) {
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const int nbv = (int)byte_of(vnew, c), obv = (int)byte_of(vold, c);
-                const int d = nbv - obv, sm = nbv + obv;
-                VS[c] += (unsigned)d;
-                VQ[c] += (unsigned)(d * sm);
-            }
+        for (int c = 0; c < CPL; ++c) {
+            const int nbv = (int)byte_of(vnew, c), obv = (int)byte_of(vold, c);
+            const int d = nbv - obv, sm = nbv + obv;
+            VS[c] += (unsigned)d;
+            VQ[c] += (unsigned)(d * sm);
         }
     }
+}
 
+template <int METHOD, int SH>
+__global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, FusedParams fp,
+                                              PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
+                                              unsigned* __restrict__ counters)
+{
+    const ThrParams& tp = fp.tp;
+    const int lane = threadIdx.x & (kWave - 1);
+    // XCD-aware block order: hardware deals blocks round-robin over the 8 XCDs, so blocks b and b+8
+    // share an L2.  Give each XCD a contiguous range of logical blocks (= neighbouring strips and
+    // segments of the same pages) so halo re-reads hit that XCD's L2.  Speed only, never correctness.
+    const unsigned nb = gridDim.x;
+    const unsigned lb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+    const unsigned wid = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
+    if (wid >= fp.total_waves) return;
+    const int per_page = fp.n_strips * fp.n_segs;
+    const int page = (int)(wid / (unsigned)per_page);
+    const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
+    const int seg = rem / fp.n_strips;
+    const int strip = rem - seg * fp.n_strips;
+
+    gcptr img = (gcptr)src.page(page);
+    gptr out = (gptr)dst.page(page);
+
+    const int xs = strip * fp.uo;          // first output column of the strip
+    const int ys = seg * fp.rows_per_seg;  // first output row of the segment
+    const int ye = min(ys + fp.rows_per_seg, tp.oh);
+
+    float c1page = fp.c1;
+    if (METHOD == PRL_FENG) {
+        const double imin = (double)g[page].imin;
+        const double c3 = (tp.k2 * imin + (-imin)) + 0.0;  // binarizeFeng.cpp:137 with r2 = c2 = 1
+        c1page = (float)c3;
+    }
+
+    // interior strip: every lane's 8-byte window fetch and the whole 512-column output span lie inside
+    // the page, so no clamp, no partial store
+    const int first_col = xs + 1 - tp.half;
+    const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
+    if (interior)
+        strip_loop<METHOD, SH, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, c1page, g, rl, counters);
+    else
+        strip_loop<METHOD, SH, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, c1page, g, rl, counters);
 }
 
 // ---- second stage: float64 interval test of the queued pixels, one thread per pixel ----------------
@@ -440,8 +492,10 @@ __global__ void __launch_bounds__(256) k_fixup(PageSet src, PageSetOut dst, Fuse
 
 template <int METHOD>
 int launch_fused(int sh, dim3 grid, hipStream_t stream, const PageSet& src, const PageSetOut& dst,
-                 const FusedParams& fp, PageGlobals* g, RefItem* rl, WorkItem* wl, unsigned* cnt)
+                 const FusedParams& fp, PageGlobals* g, RefItem* rl, WorkItem* wl, unsigned* cnt,
+                 hipEvent_t ev_start, hipEvent_t ev_stop)
 {
+    if (ev_start) PRL_HIP_CHECK(hipEventRecord(ev_start, stream));
     switch (sh) {
     case 0: hipLaunchKernelGGL((k_fused<METHOD, 0>), grid, dim3(256), 0, stream, src, dst, fp, g, rl, cnt); break;
     case 2: hipLaunchKernelGGL((k_fused<METHOD, 2>), grid, dim3(256), 0, stream, src, dst, fp, g, rl, cnt); break;
@@ -450,6 +504,7 @@ int launch_fused(int sh, dim3 grid, hipStream_t stream, const PageSet& src, cons
     default: return PRL_ERR_BAD_ARG;
     }
     PRL_HIP_CHECK(hipGetLastError());
+    if (ev_stop) PRL_HIP_CHECK(hipEventRecord(ev_stop, stream));
     hipLaunchKernelGGL((k_refine<METHOD>), dim3(64), dim3(256), 0, stream, dst, fp, g, rl, wl, cnt);
     PRL_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL((k_fixup<METHOD>), dim3(512), dim3(256), 0, stream, src, dst, fp, g, wl, cnt);
@@ -547,6 +602,7 @@ bool fused_supports(const ThrParams& tp)
     if (tp.method == PRL_WOLFJOLION) return false;           // two-pass; literal pipeline for now
     if (((tp.w - 1) & 1) != 0) return false;                 // even (clamped) window: rare, literal
     if (tp.w - 1 > 256 || tp.w < 3) return false;            // window sums must stay exact in float32/u32
+    if (tp.width < 16) return false;                         // the 8-byte row fetch needs a row to clamp into
     if (!std::isfinite(tp.k) || std::fabs(tp.k) > 1e3) return false;
     if (tp.method == PRL_FENG && !(tp.gamma > 0.0)) return false;
     if (tp.method == PRL_FENG && (!std::isfinite(tp.c1) || !std::isfinite(tp.k2) ||
@@ -560,7 +616,7 @@ size_t fused_small_bytes(int)
 }
 
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst, void* small,
-              PageGlobals* d_globals, hipStream_t stream)
+              PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     FusedParams fp{};
     fp.tp = tp;
@@ -608,10 +664,10 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     blocks = (blocks + 7) / 8 * 8;
     const int sh = (tp.w - 1) & 7;
     switch (tp.method) {
-    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt);
-    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt);
-    case PRL_NICK: return launch_fused<PRL_NICK>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt);
-    case PRL_FENG: return launch_fused<PRL_FENG>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt);
+    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
+    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
+    case PRL_NICK: return launch_fused<PRL_NICK>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
+    case PRL_FENG: return launch_fused<PRL_FENG>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
     default: return PRL_ERR_BAD_ARG;
     }
 }

@@ -34,6 +34,7 @@ thread_local LastCall t_last;
 std::mutex g_ctx_mu;
 std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
 int g_exec_mode = -1;  // -1: read PRL_HIP_MODE once
+bool g_profiling = false;
 
 }  // namespace
 
@@ -293,8 +294,18 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
     t_last.n_pages = n_pages;
     t_last.pixels = (uint64_t)g.out_w * g.out_h * (uint64_t)n_pages;
 
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ctx->prof_valid = false;
+    if (g_profiling) {
+        if (!ctx->prof_start) {
+            PRL_HIP_CHECK(hipEventCreate(&ctx->prof_start));
+            PRL_HIP_CHECK(hipEventCreate(&ctx->prof_stop));
+        }
+        ev0 = ctx->prof_start;
+        ev1 = ctx->prof_stop;
+    }
     if (use_fused) {
-        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream);
+        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1);
         if (st != PRL_OK) return st;
         // Pages whose fix-up list overflowed (pathological: a large share of their pixels sits within
         // ~1e-6 of the decision boundary) are redone by the literal pipeline.  Knowing that needs the
@@ -317,11 +328,13 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
             st = page_min_run(tp, src, n_pages, d_globals, stream);
             if (st != PRL_OK) return st;
         }
+        if (ev0) PRL_HIP_CHECK(hipEventRecord(ev0, stream));
         for (int first = 0; first < n_pages; first += (int)literal_pages_per_chunk) {
             const int cnt = std::min<int>((int)literal_pages_per_chunk, n_pages - first);
             st = literal_run(tp, src, first, cnt, thr_dst, ctx->scratch, d_globals, stream);
             if (st != PRL_OK) return st;
         }
+        if (ev1) PRL_HIP_CHECK(hipEventRecord(ev1, stream));
         t_last.literal_pages = (uint64_t)n_pages;
     }
 
@@ -334,6 +347,7 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         if (st != PRL_OK) return st;
     }
     PRL_HIP_CHECK(hipEventRecord(ctx->last_use, stream));
+    ctx->prof_valid = (ev0 != nullptr);
     t_last.valid = true;
     return PRL_OK;
 }
@@ -397,6 +411,26 @@ int prl_hip_set_exec_mode(int mode)
 }
 
 int prl_hip_get_exec_mode(void) { return exec_mode(); }
+
+int prl_hip_set_profiling(int enabled)
+{
+    g_profiling = enabled != 0;
+    return PRL_OK;
+}
+
+int prl_hip_last_kernel_ms(float* ms)
+{
+    if (!ms) return PRL_ERR_BAD_ARG;
+    *ms = 0.0f;
+    if (!t_last.valid) return PRL_ERR_BAD_ARG;
+    PRL_HIP_CHECK(hipSetDevice(t_last.device));
+    DeviceCtx* ctx = device_ctx(t_last.device);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->prof_valid) return PRL_ERR_BAD_ARG;
+    PRL_HIP_CHECK(hipEventSynchronize(ctx->prof_stop));
+    PRL_HIP_CHECK(hipEventElapsedTime(ms, ctx->prof_start, ctx->prof_stop));
+    return PRL_OK;
+}
 
 int prl_hip_release_workspace(void)
 {

@@ -37,6 +37,8 @@ struct DeviceCtx {
     void* pinned = nullptr; // pinned host staging for tiny transfers
     size_t pinned_bytes = 0;
     int cu_count = 0;
+    hipEvent_t prof_start = nullptr, prof_stop = nullptr;  // prl_hip_set_profiling
+    bool prof_valid = false;
     hipEvent_t last_use = nullptr;  // recorded after each call; the next call's stream waits on it
 };
 
@@ -104,7 +106,8 @@ int literal_run(const ThrParams& tp, const PageSet& src, int first_page, int n_p
 struct FusedWork;  // opaque
 size_t fused_small_bytes(int n_pages);
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst,
-              void* small, PageGlobals* d_globals, hipStream_t stream);
+              void* small, PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start,
+              hipEvent_t ev_stop);
 bool fused_supports(const ThrParams& tp);
 
 // ---- morphology (morph.hip) ------------------------------------------------------------------
