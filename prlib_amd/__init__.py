@@ -5,6 +5,7 @@ This package is the thin Python host layer used by the tests and the benchmark; 
 with the reference's prl::binarize*(cv::Mat&, cv::Mat&, ...) signatures lives in csrc/prl/.
 """
 from . import _capi, binarizations  # noqa: F401
+from .denoise import denoise, nlm_planes  # noqa: F401
 from .binarizations import (  # noqa: F401
     FENG, NICK, NIBLACK, SAUVOLA, WOLFJOLION, binarize, binarizeFeng, binarizeNICK, binarizeNiblack,
     binarizeSauvola, binarizeWolfJolion, default_params, geometry, last_stats, make_params, morph,
@@ -13,6 +14,6 @@ from .binarizations import (  # noqa: F401
 
 __all__ = [
     "binarize", "binarizeSauvola", "binarizeNiblack", "binarizeWolfJolion", "binarizeNICK", "binarizeFeng",
-    "make_params", "default_params", "geometry", "last_stats", "morph", "set_exec_mode",
+    "denoise", "nlm_planes", "make_params", "default_params", "geometry", "last_stats", "morph", "set_exec_mode",
     "SAUVOLA", "NIBLACK", "WOLFJOLION", "NICK", "FENG",
 ]

@@ -1,27 +1,521 @@
-// nlm.hip — NL-means entry points (implementation lands in a later commit of this round).
+// nlm.hip — prl::denoise (src/denoise/denoiseNLM.cpp:29-32) = cv::fastNlMeansDenoisingColored(in, out,
+// h = strength) with OpenCV's defaults hColor = 3, template 7x7, search 21x21.
+//
+// [upstream] semantics restated in SURVEY.md Appendix C and oracle/prl_oracle_nlm.c:
+//   LBGR -> Lab (8-bit fixed point), NLM on the L plane with h, NLM on the interleaved ab planes with
+//   h = 3, Lab -> LBGR.  The NLM core is all-integer (SSD over the 7x7 template for each of the 441
+//   offsets, `>> 6` binning, host-built weight LUT, int32 accumulation, rounding division), so the
+//   device result is bit-identical to the CPU restatement given the same LUT.
+//
+// Kernel shape (k_nlm).  NL-means is ALU-bound by construction (441 offsets x 49 taps per pixel and
+// channel against 2 B/px of traffic), so the design minimises instructions per (pixel, offset):
+//   - a workgroup stages a 64x64 tile plus its 13-pixel reflect-101 halo in LDS as raw bytes, plus
+//     SB(pos) = sum over the 7x7 template around pos of E^2 (int32) and the non-zero part of the LUT;
+//   - SSD = SA + SB - 2*AB with AB = sum over the template of E(p+t)*E(q+t).  A thread owns one column
+//     and walks down 16 output rows per offset; the 7 horizontally adjacent template taps are 7
+//     consecutive bytes of one LDS row, so one (unaligned) wide LDS read per side and V_DOT4_U32_U8
+//     gives a whole template row of AB in 2 instructions per channel-dword; the vertical 7-row sum is a
+//     sliding sum in registers (ring of 7).  No cross-lane traffic, ~13 VALU instructions per
+//     (pixel, offset) for one channel.
+// Roofline: bound by integer VALU issue, not HBM; bench reports the HBM fraction because the metric
+// asks for it (algorithmic 2 B/px per plane byte) and states the ALU bound next to it.
+#include <algorithm>
+#include <cmath>
+#include <climits>
+#include <vector>
+
 #include "prl_internal.h"
+
+namespace prl_hip {
+
+namespace {
+
+constexpr int kT = 7, kS = 21, kTH = 3, kSH = 10, kBorder = kTH + kSH;  // 13
+constexpr int TILE_W = 64, ROWS = 16, WAVES = 4, TILE_H = ROWS * WAVES;   // 64 x 64 outputs per workgroup
+constexpr int EXT_W = TILE_W + 2 * kBorder, EXT_H = TILE_H + 2 * kBorder; // 90 x 90 staged pixels
+constexpr int SB_W = TILE_W + 2 * kSH, SB_H = TILE_H + 2 * kSH;           // 84 x 84 template energies
+constexpr int kLutMax = 1024;  // non-zero LUT entries kept in LDS (h <= ~13 for 1 channel); else global
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+struct NlmParams {
+    int width, height;
+    int n_lut;              // number of leading LUT entries that may be non-zero; lut[n_lut] == 0
+    const int* lut;         // device copy of almost_dist2weight_ (n_lut + 1 entries)
+};
+
+template <int CH>
+struct Nb {  // the 7-pixel horizontal neighbourhood of one position: 7*CH bytes in NB dwords
+    static constexpr int NB = (7 * CH + 3) / 4;
+    unsigned d[NB];
+};
+
+template <int CH>
+__device__ __forceinline__ Nb<CH> lds_nb(const unsigned char* p)
+{
+    Nb<CH> v;
+    __builtin_memcpy(v.d, p, sizeof(unsigned) * Nb<CH>::NB);  // unaligned ds_read_b64 / b128
+    return v;
+}
+
+// sum over the 7*CH bytes of a.b ; `a` has its padding bytes (beyond 7*CH) zeroed
+template <int CH>
+__device__ __forceinline__ unsigned dot_nb(const Nb<CH>& a, const Nb<CH>& b, unsigned acc)
+{
+#pragma unroll
+    for (int k = 0; k < Nb<CH>::NB; ++k) acc = __builtin_amdgcn_udot4(a.d[k], b.d[k], acc, false);
+    return acc;
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256) k_nlm(PageSet src, PageSetOut dst, NlmParams np)
+{
+    constexpr int NB = Nb<CH>::NB;
+    constexpr int PITCH = (EXT_W * CH + 16 + 3) / 4 * 4;  // bytes per staged row (+16: wide reads may overrun)
+    __shared__ __attribute__((aligned(16))) unsigned char tile[EXT_H * PITCH + 32];
+    __shared__ int sb[SB_H * SB_W];
+    __shared__ int lut_s[kLutMax + 1];
+
+    const int page = blockIdx.z;
+    const uint8_t* __restrict__ img = src.page(page);
+    uint8_t* __restrict__ out = dst.page(page);
+    const int W = np.width, H = np.height;
+    const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+
+    // stage the tile with its reflect-101 halo (copyMakeBorder(BORDER_DEFAULT) by 13)
+    for (int i = threadIdx.x; i < EXT_H * EXT_W; i += blockDim.x) {
+        const int r = i / EXT_W, c = i - r * EXT_W;
+        const int sy = reflect101(y0 - kBorder + r, H), sx = reflect101(x0 - kBorder + c, W);
+        const uint8_t* s = img + (size_t)sy * src.step + (size_t)sx * CH;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) tile[r * PITCH + c * CH + k] = s[k];
+    }
+    for (int i = threadIdx.x; i < EXT_H * (PITCH - EXT_W * CH); i += blockDim.x) {
+        const int r = i / (PITCH - EXT_W * CH), c = i - r * (PITCH - EXT_W * CH);
+        tile[r * PITCH + EXT_W * CH + c] = 0;
+    }
+    const int n_lut_s = min(np.n_lut, kLutMax);
+    for (int i = threadIdx.x; i <= n_lut_s; i += blockDim.x) lut_s[i] = (i < np.n_lut) ? np.lut[i] : 0;
+    __syncthreads();
+
+    // SB(r, c) = sum over the 7x7 template centred at staged position (r + 3, c + 3) of E^2
+    for (int i = threadIdx.x; i < SB_H * SB_W; i += blockDim.x) {
+        const int r = i / SB_W, c = i - r * SB_W;
+        unsigned s = 0;
+        for (int ty = 0; ty < kT; ++ty) {
+            const unsigned char* p = tile + (r + ty) * PITCH + c * CH;
+            for (int k = 0; k < kT * CH; ++k) s += (unsigned)p[k] * p[k];
+        }
+        sb[i] = (int)s;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int oy0 = wv * ROWS;  // first output row of this wavefront inside the tile
+    // staged coordinates: output (oy, lane) sits at staged (oy + 13, lane + 13); its template row ty
+    // starts at staged column lane + 10.
+    const unsigned char* abase = tile + (oy0 + kSH) * PITCH + (lane + kSH) * CH;  // template row 0 of output row 0
+    const int* sa_base = sb + (oy0 + kSH) * SB_W + (lane + kSH);
+
+    // own-pixel template energies
+    int SA[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) SA[i] = sa_base[i * SB_W];
+
+    unsigned est[ROWS][CH], wsum[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        wsum[i] = 0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) est[i][k] = 0;
+    }
+    // mask that zeroes the padding bytes of the last neighbourhood dword on the own side
+    constexpr unsigned kPadBytes = NB * 4 - 7 * CH;
+    constexpr unsigned kLastMask = kPadBytes == 0 ? 0xffffffffu : (0xffffffffu >> (8 * kPadBytes));
+    const bool lut_in_lds = np.n_lut <= kLutMax;
+
+#pragma unroll 1
+    for (int o = 0; o < kS * kS; ++o) {
+        const int dy = o / kS - kSH, dx = o - (o / kS) * kS - kSH;
+        const unsigned char* bbase = abase + dy * PITCH + dx * CH;
+        const int* sb_o = sa_base + dy * SB_W + dx;
+        unsigned ring[kT];
+        unsigned qring[4][CH];
+        unsigned AB = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS + kT - 1; ++r) {
+            Nb<CH> a = lds_nb<CH>(abase + r * PITCH);
+            const Nb<CH> b = lds_nb<CH>(bbase + r * PITCH);
+            a.d[NB - 1] &= kLastMask;
+            const unsigned hd = dot_nb<CH>(a, b, 0u);
+            AB += hd;
+            if (r >= kT) AB -= ring[r % kT];
+            ring[r % kT] = hd;
+            // centre pixel of the other patch's row r: bytes 3*CH .. 4*CH-1 of its neighbourhood
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int byte = 3 * CH + k;
+                qring[r % 4][k] = (b.d[byte / 4] >> (8 * (byte % 4))) & 0xffu;
+            }
+            if (r >= kT - 1) {
+                const int i = r - (kT - 1);  // output row; its centre row was fetched at step i + 3 = r - 3
+                const int D = SA[i] + sb_o[i * SB_W] - 2 * (int)AB;
+                int idx = D >> 6;            // almost_template_window_size_sq_bin_shift_
+                idx = min(idx, np.n_lut);
+                const unsigned wgt = (unsigned)(lut_in_lds ? lut_s[idx] : np.lut[idx]);
+                wsum[i] += wgt;
+#pragma unroll
+                for (int k = 0; k < CH; ++k) est[i][k] += wgt * qring[(r - 3) % 4][k];
+            }
+        }
+    }
+
+    // divByWeightsSum + saturate_cast<uchar>
+    const int gx = x0 + lane;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int gy = y0 + oy0 + i;
+        if (gx < W && gy < H) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const unsigned v = (est[i][k] + wsum[i] / 2u) / wsum[i];
+                out[(size_t)gy * dst.step + (size_t)gx * CH + k] = (uint8_t)(v > 255u ? 255u : v);
+            }
+        }
+    }
+}
+
+// ---- 8-bit LBGR <-> Lab (cv::cvtColor COLOR_LBGR2Lab / COLOR_Lab2LBGR), see oracle for the restatement
+constexpr int kLabShift = 12, kGammaShift = 3, kLabShift2 = kLabShift + kGammaShift;
+constexpr int kCbrtTabSize = 256 * 3 / 2 * (1 << kGammaShift);
+
+struct LabTables {
+    int fwd[9];
+    float inv[9];
+    const unsigned short* cbrt_tab;  // device, kCbrtTabSize entries
+};
+
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+__device__ __forceinline__ unsigned char sat8(int v) { return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// BGR(A) -> L plane + interleaved ab plane (the mixChannels split is fused into the conversion)
+__global__ void __launch_bounds__(256) k_lbgr2lab(PageSet src, int channels, int width, int height,
+                                                 LabTables lt, uint8_t* __restrict__ lpl,
+                                                 uint8_t* __restrict__ abpl, size_t plane_px)
+{
+    const int page = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= width) return;
+    const uint8_t* s = src.page(page) + (size_t)y * src.step + (size_t)x * channels;
+    const int R = s[0] << kGammaShift, G = s[1] << kGammaShift, B = s[2] << kGammaShift;
+    const int* C = lt.fwd;
+    const int fX = lt.cbrt_tab[descale(R * C[0] + G * C[1] + B * C[2], kLabShift)];
+    const int fY = lt.cbrt_tab[descale(R * C[3] + G * C[4] + B * C[5], kLabShift)];
+    const int fZ = lt.cbrt_tab[descale(R * C[6] + G * C[7] + B * C[8], kLabShift)];
+    const int Lscale = (116 * 255 + 50) / 100;
+    const int Lshift = -((16 * 255 * (1 << kLabShift2) + 50) / 100);
+    const size_t i = (size_t)page * plane_px + (size_t)y * width + x;
+    lpl[i] = sat8(descale(Lscale * fY + Lshift, kLabShift2));
+    abpl[2 * i] = sat8(descale(500 * (fX - fY) + 128 * (1 << kLabShift2), kLabShift2));
+    abpl[2 * i + 1] = sat8(descale(200 * (fY - fZ) + 128 * (1 << kLabShift2), kLabShift2));
+}
+
+__device__ __forceinline__ float clip01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+
+// L plane + ab plane -> BGR(A); float path of Lab2RGB_f with gamma disabled, one rounding per operation
+__global__ void __launch_bounds__(256) k_lab2lbgr(const uint8_t* __restrict__ lpl,
+                                                 const uint8_t* __restrict__ abpl, size_t plane_px,
+                                                 int channels, int width, int height, LabTables lt,
+                                                 PageSetOut dst)
+{
+    const int page = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= width) return;
+    const size_t i = (size_t)page * plane_px + (size_t)y * width + x;
+    const float lThresh = 0.008856f * 903.3f;
+    const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
+    const float li = lpl[i] * (100.f / 255.f);
+    const float ai = (float)((int)abpl[2 * i] - 128);
+    const float bi = (float)((int)abpl[2 * i + 1] - 128);
+    float Y, fy;
+    if (li <= lThresh) {
+        Y = li / 903.3f;
+        fy = 7.787f * Y + 16.0f / 116.0f;
+    } else {
+        fy = (li + 16.0f) / 116.0f;
+        Y = fy * fy * fy;
+    }
+    float fx = ai / 500.0f + fy, fz = fy - bi / 200.0f;
+    fx = (fx <= fThresh) ? (fx - 16.0f / 116.0f) / 7.787f : fx * fx * fx;
+    fz = (fz <= fThresh) ? (fz - 16.0f / 116.0f) / 7.787f : fz * fz * fz;
+    const float* C = lt.inv;
+    float c0 = C[0] * fx + C[1] * Y + C[2] * fz;
+    float c1 = C[3] * fx + C[4] * Y + C[5] * fz;
+    float c2 = C[6] * fx + C[7] * Y + C[8] * fz;
+    c0 = clip01(c0);
+    c1 = clip01(c1);
+    c2 = clip01(c2);
+    uint8_t* d = dst.page(page) + (size_t)y * dst.step + (size_t)x * channels;
+    d[0] = sat8((int)rintf(c0 * 255.f));
+    d[1] = sat8((int)rintf(c1 * 255.f));
+    d[2] = sat8((int)rintf(c2 * 255.f));
+    if (channels == 4) d[3] = 255;
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+
+// almost_dist2weight_ of FastNlMeansDenoisingInvoker<..., DistSquared, int> (host, once per call)
+std::vector<int> build_weights(int channels, float h)
+{
+    const int max_estimate_sum_value = kS * kS * 255;
+    const int fixed_point_mult = INT_MAX / max_estimate_sum_value;  // 19096
+    const int tw_sq = kT * kT;
+    int bin_shift = 0;
+    while ((1 << bin_shift) < tw_sq) ++bin_shift;
+    const double mult = ((double)(1 << bin_shift)) / tw_sq;
+    const int max_dist = 255 * 255 * channels;
+    const int almost_max_dist = (int)(max_dist / mult + 1);
+    const float hh = h * h * channels;  // float arithmetic, as upstream
+    std::vector<int> lut((size_t)almost_max_dist);
+    for (int i = 0; i < almost_max_dist; ++i) {
+        const double dist = i * mult;
+        double w = std::exp(-dist / hh);
+        if (w != w) w = 1.0;
+        int weight = (int)std::nearbyint(fixed_point_mult * w);
+        if (weight < 0.001 * fixed_point_mult) weight = 0;
+        lut[(size_t)i] = weight;
+    }
+    return lut;
+}
+
+struct HostLab {
+    std::vector<unsigned short> cbrt_tab;
+    int fwd[9];
+    float inv[9];
+};
+
+const HostLab& host_lab()
+{
+    static HostLab t = [] {
+        HostLab h;
+        static const float sRGB2XYZ_D65[9] = {0.412453f, 0.357580f, 0.180423f, 0.212671f, 0.715160f,
+                                              0.072169f, 0.019334f, 0.119193f, 0.950227f};
+        static const float XYZ2sRGB_D65[9] = {3.240479f, -1.53715f, -0.498535f, -0.969256f, 1.875991f,
+                                              0.041556f, 0.055648f, -0.204043f, 1.057311f};
+        static const float D65[3] = {0.950456f, 1.f, 1.088754f};
+        h.cbrt_tab.resize(kCbrtTabSize);
+        for (int i = 0; i < kCbrtTabSize; ++i) {
+            const float x = i * (1.f / (255.f * (1 << kGammaShift)));
+            const float v = (1 << kLabShift2) * (x < 0.008856f ? x * 7.787f + 0.13793103448275862f : cbrtf(x));
+            const int iv = (int)std::nearbyint((double)v);
+            h.cbrt_tab[(size_t)i] = (unsigned short)(iv < 0 ? 0 : (iv > 65535 ? 65535 : iv));
+        }
+        const float scale[3] = {(1 << kLabShift) / D65[0], (float)(1 << kLabShift), (1 << kLabShift) / D65[2]};
+        for (int i = 0; i < 3; ++i) {  // blueIdx = 0
+            h.fwd[i * 3 + 2] = (int)std::nearbyint((double)(sRGB2XYZ_D65[i * 3] * scale[i]));
+            h.fwd[i * 3 + 1] = (int)std::nearbyint((double)(sRGB2XYZ_D65[i * 3 + 1] * scale[i]));
+            h.fwd[i * 3 + 0] = (int)std::nearbyint((double)(sRGB2XYZ_D65[i * 3 + 2] * scale[i]));
+            h.inv[i + 6] = XYZ2sRGB_D65[i] * D65[i];
+            h.inv[i + 3] = XYZ2sRGB_D65[i + 3] * D65[i];
+            h.inv[i + 0] = XYZ2sRGB_D65[i + 6] * D65[i];
+        }
+        return h;
+    }();
+    return t;
+}
+
+// Device copies of the LUT(s) / cbrt table live in the small workspace: [lutA 512 KiB][lutB 512 KiB][cbrt 8 KiB]
+constexpr size_t kLutSlot = 512 * 1024;
+
+int upload_lut(DeviceCtx* ctx, int slot, int channels, float h, hipStream_t stream, NlmParams* np)
+{
+    std::vector<int> lut = build_weights(channels, h);
+    int n = (int)lut.size();
+    while (n > 0 && lut[(size_t)n - 1] == 0) --n;  // weights are non-increasing: trailing zeros collapse
+    lut.resize((size_t)n + 1);
+    lut[(size_t)n] = 0;
+    if ((size_t)(n + 1) * sizeof(int) > kLutSlot) {
+        set_error_detail("NLM weight table too large for the workspace (h too large)");
+        return PRL_ERR_BAD_ARG;
+    }
+    int* d = reinterpret_cast<int*>(static_cast<uint8_t*>(ctx->small) + (size_t)slot * kLutSlot);
+    // pageable source: hipMemcpyAsync stages it before returning, so `lut` may die after this call
+    PRL_HIP_CHECK(hipMemcpyAsync(d, lut.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+    PRL_HIP_CHECK(hipStreamSynchronize(stream));
+    np->n_lut = n;
+    np->lut = d;
+    return PRL_OK;
+}
+
+template <int CH>
+int launch_nlm(const PageSet& src, const PageSetOut& dst, int n_pages, const NlmParams& np, hipStream_t stream)
+{
+    const dim3 grid((np.width + TILE_W - 1) / TILE_W, (np.height + TILE_H - 1) / TILE_H, n_pages);
+    hipLaunchKernelGGL((k_nlm<CH>), grid, dim3(256), 0, stream, src, dst, np);
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
+int nlm_planes_locked(DeviceCtx* ctx, int slot, int n_pages, int channels, float h, const PageSet& src, int width,
+                      int height, const PageSetOut& dst, hipStream_t stream)
+{
+    NlmParams np{};
+    np.width = width;
+    np.height = height;
+    int st = upload_lut(ctx, slot, channels, h, stream, &np);
+    if (st != PRL_OK) return st;
+    switch (channels) {
+    case 1: return launch_nlm<1>(src, dst, n_pages, np, stream);
+    case 2: return launch_nlm<2>(src, dst, n_pages, np, stream);
+    case 3: return launch_nlm<3>(src, dst, n_pages, np, stream);
+    default: return PRL_ERR_BAD_CHANNELS;
+    }
+}
+
+}  // namespace
+}  // namespace prl_hip
 
 using namespace prl_hip;
 
 extern "C" {
 
-int prl_hip_nlm_planes_device(int, int, float, const uint8_t*, size_t, size_t, int, int, uint8_t*, size_t,
-                              size_t, void*)
+int prl_hip_nlm_planes_device(int n_pages, int channels, float h, const uint8_t* d_src, size_t src_page_stride,
+                              size_t src_step, int width, int height, uint8_t* d_dst, size_t dst_page_stride,
+                              size_t dst_step, void* stream)
 {
-    set_error_detail("prl_hip_nlm_planes_device: not implemented yet");
-    return PRL_ERR_HIP;
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    if (channels < 1 || channels > 3) return PRL_ERR_BAD_CHANNELS;
+    if (n_pages < 0 || !d_src || !d_dst || d_src == d_dst) return PRL_ERR_BAD_ARG;
+    if (src_step < (size_t)width * channels || dst_step < (size_t)width * channels) return PRL_ERR_BAD_ARG;
+    if (n_pages == 0) return PRL_OK;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    st = ensure_small(ctx, 2 * kLutSlot + 64 * 1024);
+    if (st != PRL_OK) return st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(s, ctx->last_use, 0));
+    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+    PageSet ps{};
+    ps.base = d_src;
+    ps.page_stride = src_page_stride;
+    ps.step = src_step;
+    PageSetOut pd{};
+    pd.base = d_dst;
+    pd.page_stride = dst_page_stride;
+    pd.step = dst_step;
+    st = nlm_planes_locked(ctx, 0, n_pages, channels, h, ps, width, height, pd, s);
+    if (st != PRL_OK) return st;
+    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, s));
+    return PRL_OK;
 }
 
-int prl_hip_denoise_batch_device(int, int, float, const uint8_t*, size_t, size_t, int, int, uint8_t*,
-                                 size_t, size_t, void*)
+int prl_hip_denoise_batch_device(int n_pages, int channels, float strength, const uint8_t* d_src,
+                                 size_t src_page_stride, size_t src_step, int width, int height, uint8_t* d_dst,
+                                 size_t dst_page_stride, size_t dst_step, void* stream)
 {
-    set_error_detail("prl_hip_denoise_batch_device: not implemented yet");
-    return PRL_ERR_HIP;
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    // "Type of input image should be CV_8UC3 or CV_8UC4!" [upstream fastNlMeansDenoisingColored]
+    if (channels != 3 && channels != 4) return PRL_ERR_BAD_CHANNELS;
+    if (n_pages < 0 || !d_src || !d_dst) return PRL_ERR_BAD_ARG;
+    if (src_step < (size_t)width * channels || dst_step < (size_t)width * channels) return PRL_ERR_BAD_ARG;
+    if (n_pages == 0) return PRL_OK;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t cbrt_off = 2 * kLutSlot;
+    st = ensure_small(ctx, cbrt_off + 64 * 1024);
+    if (st != PRL_OK) return st;
+    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(s, ctx->last_use, 0));
+    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+
+    const HostLab& hl = host_lab();
+    auto* d_cbrt = reinterpret_cast<unsigned short*>(static_cast<uint8_t*>(ctx->small) + cbrt_off);
+    PRL_HIP_CHECK(hipMemcpyAsync(d_cbrt, hl.cbrt_tab.data(), hl.cbrt_tab.size() * sizeof(unsigned short),
+                                 hipMemcpyHostToDevice, s));
+    LabTables lt{};
+    std::copy(hl.fwd, hl.fwd + 9, lt.fwd);
+    std::copy(hl.inv, hl.inv + 9, lt.inv);
+    lt.cbrt_tab = d_cbrt;
+
+    // planes: L, ab, L', ab'  (1 + 2 + 1 + 2 bytes per pixel), processed in page chunks of bounded size
+    const size_t px = (size_t)width * height;
+    const size_t budget = (size_t)2 << 30;
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, budget / (6 * px)));
+    st = ensure_scratch(ctx, 6 * px * (size_t)chunk);
+    if (st != PRL_OK) return st;
+    auto* base = static_cast<uint8_t*>(ctx->scratch);
+    for (int first = 0; first < n_pages; first += chunk) {
+        const int cnt = std::min(chunk, n_pages - first);
+        uint8_t* L = base;
+        uint8_t* AB = L + px * (size_t)cnt;
+        uint8_t* L2 = AB + 2 * px * (size_t)cnt;
+        uint8_t* AB2 = L2 + px * (size_t)cnt;
+        PageSet ps{};
+        ps.base = d_src + (size_t)first * src_page_stride;
+        ps.page_stride = src_page_stride;
+        ps.step = src_step;
+        PageSetOut pd{};
+        pd.base = d_dst + (size_t)first * dst_page_stride;
+        pd.page_stride = dst_page_stride;
+        pd.step = dst_step;
+        const dim3 grid((width + 255) / 256, height, cnt);
+        hipLaunchKernelGGL(k_lbgr2lab, grid, dim3(256), 0, s, ps, channels, width, height, lt, L, AB, px);
+        PRL_HIP_CHECK(hipGetLastError());
+        PageSet sl{}, sab{};
+        sl.base = L; sl.page_stride = px; sl.step = (size_t)width;
+        sab.base = AB; sab.page_stride = 2 * px; sab.step = 2 * (size_t)width;
+        PageSetOut dl{}, dab{};
+        dl.base = L2; dl.page_stride = px; dl.step = (size_t)width;
+        dab.base = AB2; dab.page_stride = 2 * px; dab.step = 2 * (size_t)width;
+        st = nlm_planes_locked(ctx, 0, cnt, 1, strength, sl, width, height, dl, s);
+        if (st != PRL_OK) return st;
+        st = nlm_planes_locked(ctx, 1, cnt, 2, 3.0f, sab, width, height, dab, s);  // hForColorComponents = 3
+        if (st != PRL_OK) return st;
+        hipLaunchKernelGGL(k_lab2lbgr, grid, dim3(256), 0, s, L2, AB2, px, channels, width, height, lt, pd);
+        PRL_HIP_CHECK(hipGetLastError());
+    }
+    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, s));
+    return PRL_OK;
 }
 
-int prl_hip_denoise_host(int, float, const uint8_t*, size_t, int, int, uint8_t*, size_t)
+int prl_hip_denoise_host(int channels, float strength, const uint8_t* src, size_t src_step, int width, int height,
+                         uint8_t* dst, size_t dst_step)
 {
-    set_error_detail("prl_hip_denoise_host: not implemented yet");
-    return PRL_ERR_HIP;
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    if (channels != 3 && channels != 4) return PRL_ERR_BAD_CHANNELS;
+    if (!src || !dst || src_step < (size_t)width * channels || dst_step < (size_t)width * channels) return PRL_ERR_BAD_ARG;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    const size_t row = (size_t)width * channels, pitch = (row + 255) / 256 * 256;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    PRL_HIP_CHECK(hipMalloc(&d_in, pitch * (size_t)height));
+    if (hipMalloc(&d_out, pitch * (size_t)height) != hipSuccess) {
+        (void)hipFree(d_in);
+        return PRL_ERR_NOMEM;
+    }
+    auto cleanup = [&]() { (void)hipFree(d_in); (void)hipFree(d_out); };
+    if (hipMemcpy2D(d_in, pitch, src, src_step, row, (size_t)height, hipMemcpyHostToDevice) != hipSuccess) {
+        cleanup();
+        return PRL_ERR_HIP;
+    }
+    st = prl_hip_denoise_batch_device(1, channels, strength, d_in, pitch * (size_t)height, pitch, width, height, d_out,
+                                      pitch * (size_t)height, pitch, nullptr);
+    if (st == PRL_OK && hipMemcpy2D(dst, dst_step, d_out, pitch, row, (size_t)height, hipMemcpyDeviceToHost) != hipSuccess)
+        st = PRL_ERR_HIP;
+    cleanup();
+    return st;
 }
-}
+
+}  // extern "C"
