@@ -1,7 +1,7 @@
 // nlm.hip — prl::denoise (src/denoise/denoiseNLM.cpp:29-32) = cv::fastNlMeansDenoisingColored(in, out,
 // h = strength) with OpenCV's defaults hColor = 3, template 7x7, search 21x21.
 //
-// [upstream] semantics restated in SURVEY.md Appendix C and oracle/prl_oracle_nlm.c:
+// [upstream] semantics restated in SURVEY.md Appendix C (the CPU checker restates them independently):
 //   LBGR -> Lab (8-bit fixed point), NLM on the L plane with h, NLM on the interleaved ab planes with
 //   h = 3, Lab -> LBGR.  The NLM core is all-integer (SSD over the 7x7 template for each of the 441
 //   offsets, `>> 6` binning, host-built weight LUT, int32 accumulation, rounding division), so the
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) k_nlm(PageSet src, PageSetOut dst, NlmPar
     }
 }
 
-// ---- 8-bit LBGR <-> Lab (cv::cvtColor COLOR_LBGR2Lab / COLOR_Lab2LBGR), see oracle for the restatement
+// ---- 8-bit LBGR <-> Lab (cv::cvtColor COLOR_LBGR2Lab / COLOR_Lab2LBGR) [upstream, SURVEY.md Appendix C]
 constexpr int kLabShift = 12, kGammaShift = 3, kLabShift2 = kLabShift + kGammaShift;
 constexpr int kCbrtTabSize = 256 * 3 / 2 * (1 << kGammaShift);
 

@@ -1,0 +1,54 @@
+// prl.h — C++ host layer with the reference's signatures for the hot path, over the C ABI of
+// include/prl_hip.h.  A caller of PRLib switches by including this header instead of the six reference
+// headers and linking libprlib_hip.so + prl_host.cpp:
+//
+//   reference header (PRLib tree)                          function
+//   src/binarizations/binarizeSauvola.h:43-47              prl::binarizeSauvola
+//   src/binarizations/binarizeNiblack.h:43-47              prl::binarizeNiblack
+//   src/binarizations/binarizeWolfJolion.h:43-47           prl::binarizeWolfJolion
+//   src/binarizations/binarizeNICK.h:43-47                 prl::binarizeNICK
+//   src/binarizations/binarizeFeng.h:46-53                 prl::binarizeFeng
+//   src/denoise/denoiseNLM.h:32                            prl::denoise
+//
+// Same names, argument order, defaults, exceptions (std::invalid_argument for an empty image or a bad
+// window, binarizeSauvola.cpp:38-47) and side effects: the caller's input Mat is converted to gray
+// (:51) and replaced by the replicate-padded page (:65); the output Mat is (re)allocated (:122).
+// Define PRL_KEEP_INPUT before including to opt out of the input mutation.
+#pragma once
+
+#if defined(__has_include)
+#if __has_include(<opencv2/core/core.hpp>)
+#include <opencv2/core/core.hpp>
+#define PRL_HAVE_OPENCV 1
+#endif
+#endif
+#ifndef PRL_HAVE_OPENCV
+#include "cvmat_shim.h"
+#endif
+
+namespace prl {
+
+void binarizeSauvola(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 101,
+                     double thresholdCoefficient = 0.01, int morphIterationCount = 2);
+
+void binarizeNiblack(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 101,
+                     double thresholdCoefficient = 0.01, int morphIterationCount = 2);
+
+void binarizeWolfJolion(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 101,
+                        double thresholdCoefficient = 0.01, int morphIterationCount = 2);
+
+void binarizeNICK(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 21,
+                  double thresholdCoefficient = -0.01, int morphIterationCount = 0);
+
+void binarizeFeng(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 21,
+                  double thresholdCoefficient_alpha1 = 0.75, double thresholdCoefficient_k1 = 0.2,
+                  double thresholdCoefficient_k2 = 0.03, double thresholdCoefficient_gamma = 2.0,
+                  int morphIterationCount = 2);
+
+void denoise(const cv::Mat& inputImage, cv::Mat& outputImage, double strength = 5.5);
+
+// BASELINE config 1 (plumbing, host only): global Otsu, the one global threshold the reference uses
+// (cv::threshold(..., THRESH_BINARY | THRESH_OTSU), src/deskew/deskew.cpp:224).  Not a GPU path.
+void binarize(cv::Mat& inputImage, cv::Mat& outputImage);
+
+}  // namespace prl

@@ -1,0 +1,159 @@
+// prl_host.cpp — thin C++ shims: validate like the reference, hand (data, step, rows, cols) to the C ABI.
+#include "prl.h"
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/prl_hip.h"
+
+namespace {
+
+[[noreturn]] void raise(int status)
+{
+    const std::string msg = prl_hip_strerror(status);
+    if (status == PRL_ERR_EMPTY || status == PRL_ERR_BAD_WINDOW)
+        throw std::invalid_argument(msg);  // binarizeSauvola.cpp:38-47
+    std::string detail = prl_hip_last_error_detail();
+    throw cv::Exception(detail.empty() ? msg : msg + " [" + detail + "]");
+}
+
+// cv::cvtColor(in, in, cv::COLOR_BGR2GRAY) on 8-bit BGR/BGRA — binarizeSauvola.cpp:51.
+// [upstream] 14-bit fixed point luma; pure per-pixel data conversion on the host.
+void bgr2gray_inplace(cv::Mat& m)
+{
+    const int cn = m.channels();
+    cv::Mat g(m.rows, m.cols, CV_8UC1);
+    for (int y = 0; y < m.rows; ++y) {
+        const unsigned char* s = m.ptr(y);
+        unsigned char* d = g.ptr(y);
+        for (int x = 0; x < m.cols; ++x, s += cn)
+            d[x] = (unsigned char)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + (1 << 13)) >> 14);
+    }
+    m = g;
+}
+
+void run(int method, cv::Mat& in, cv::Mat& out, int windowSize, double k, int morph, double a1 = 0.75,
+         double k1 = 0.2, double k2 = 0.03, double gamma = 2.0)
+{
+    if (in.empty()) throw std::invalid_argument("Input image for binarization is empty");
+    if (!((windowSize > 1) && ((windowSize % 2) == 1)))
+        throw std::invalid_argument(prl_hip_strerror(PRL_ERR_BAD_WINDOW));
+    if (in.depth() != CV_8U) throw cv::Exception("prl: 8-bit images only");
+    if (in.channels() != 1) {
+        if (in.channels() != 3 && in.channels() != 4) raise(PRL_ERR_BAD_CHANNELS);
+        bgr2gray_inplace(in);
+    }
+    prl_binarize_params p{};
+    p.method = method;
+    p.window_size = windowSize;
+    p.k = k;
+    p.morph_iterations = morph;
+    p.feng_alpha1 = a1;
+    p.feng_k1 = k1;
+    p.feng_k2 = k2;
+    p.feng_gamma = gamma;
+    prl_binarize_geometry g{};
+    int st = prl_hip_binarize_geometry(&p, in.cols, in.rows, &g);
+    if (st != PRL_OK) raise(st);
+    cv::Mat result(g.out_h, g.out_w, CV_8UC1);
+#ifndef PRL_KEEP_INPUT
+    cv::Mat padded(g.padded_h, g.padded_w, CV_8UC1);
+    st = prl_hip_binarize_host(&p, in.data, in.step, in.cols, in.rows, result.data, result.step, padded.data,
+                               padded.step);
+#else
+    st = prl_hip_binarize_host(&p, in.data, in.step, in.cols, in.rows, result.data, result.step, nullptr, 0);
+#endif
+    if (st != PRL_OK) raise(st);
+#ifndef PRL_KEEP_INPUT
+    in = padded;  // cv::copyMakeBorder(in, in, ...) — binarizeSauvola.cpp:65
+#endif
+    out = result;  // outputImage = in(rect) > T — :122
+}
+
+}  // namespace
+
+void prl::binarizeSauvola(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize,
+                          double thresholdCoefficient, int morphIterationCount)
+{
+    run(PRL_SAUVOLA, inputImage, outputImage, windowSize, thresholdCoefficient, morphIterationCount);
+}
+
+void prl::binarizeNiblack(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize,
+                          double thresholdCoefficient, int morphIterationCount)
+{
+    run(PRL_NIBLACK, inputImage, outputImage, windowSize, thresholdCoefficient, morphIterationCount);
+}
+
+void prl::binarizeWolfJolion(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize,
+                             double thresholdCoefficient, int morphIterationCount)
+{
+    run(PRL_WOLFJOLION, inputImage, outputImage, windowSize, thresholdCoefficient, morphIterationCount);
+}
+
+void prl::binarizeNICK(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize, double thresholdCoefficient,
+                       int morphIterationCount)
+{
+    run(PRL_NICK, inputImage, outputImage, windowSize, thresholdCoefficient, morphIterationCount);
+}
+
+void prl::binarizeFeng(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize,
+                       double thresholdCoefficient_alpha1, double thresholdCoefficient_k1,
+                       double thresholdCoefficient_k2, double thresholdCoefficient_gamma, int morphIterationCount)
+{
+    run(PRL_FENG, inputImage, outputImage, windowSize, 0.0, morphIterationCount, thresholdCoefficient_alpha1,
+        thresholdCoefficient_k1, thresholdCoefficient_k2, thresholdCoefficient_gamma);
+}
+
+void prl::denoise(const cv::Mat& inputImage, cv::Mat& outputImage, double strength)
+{
+    // [upstream] an empty Mat has type CV_8UC1: "Type of input image should be CV_8UC3 or CV_8UC4!"
+    if (inputImage.empty()) raise(PRL_ERR_BAD_CHANNELS);
+    if (inputImage.depth() != CV_8U) throw cv::Exception("prl::denoise: 8-bit images only");
+    cv::Mat result(inputImage.rows, inputImage.cols, inputImage.type());
+    const int st = prl_hip_denoise_host(inputImage.channels(), (float)strength, inputImage.data, inputImage.step,
+                                        inputImage.cols, inputImage.rows, result.data, result.step);
+    if (st != PRL_OK) raise(st);  // 1/2-channel input: "Type of input image should be CV_8UC3 or CV_8UC4!" upstream
+    outputImage = result;
+}
+
+// Global Otsu on the host (BASELINE config 1: plumbing, no GPU).  [upstream getThreshVal_Otsu_8u]
+void prl::binarize(cv::Mat& inputImage, cv::Mat& outputImage)
+{
+    if (inputImage.empty()) throw std::invalid_argument("Input image for binarization is empty");
+    if (inputImage.channels() != 1) bgr2gray_inplace(inputImage);
+    const cv::Mat& in = inputImage;
+    long hist[256] = {0};
+    for (int y = 0; y < in.rows; ++y) {
+        const unsigned char* s = in.ptr(y);
+        for (int x = 0; x < in.cols; ++x) hist[s[x]]++;
+    }
+    const double scale = 1.0 / ((double)in.rows * in.cols);
+    double mu = 0;
+    for (int i = 0; i < 256; ++i) mu += i * (double)hist[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, best_sigma = 0;
+    int best = 0;
+    for (int i = 0; i < 256; ++i) {
+        const double p_i = hist[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        const double q2 = 1.0 - q1;
+        const double lo = q1 < q2 ? q1 : q2, hi = q1 < q2 ? q2 : q1;
+        if (lo < 1.1920928955078125e-07 || hi > 1.0 - 1.1920928955078125e-07) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        const double mu2 = (mu - q1 * mu1) / q2;
+        const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > best_sigma) {
+            best_sigma = sigma;
+            best = i;
+        }
+    }
+    cv::Mat result(in.rows, in.cols, CV_8UC1);
+    for (int y = 0; y < in.rows; ++y) {
+        const unsigned char* s = in.ptr(y);
+        unsigned char* d = result.ptr(y);
+        for (int x = 0; x < in.cols; ++x) d[x] = s[x] > best ? 255 : 0;
+    }
+    outputImage = result;
+}

@@ -1,0 +1,183 @@
+// test_prl_host.cpp — exercises the C++ host layer (prlib_amd/csrc/prl/prl.h) the way a PRLib caller
+// would (samples/binarizations/binarizeSauvola_sample.cpp:48-53): Mat in, prl::binarizeX(in, out, ...),
+// Mat out — and checks the result, the output size and the input side effect against the CPU oracle.
+//   test_prl_host cpu : argument validation, exceptions, loud failure without a device
+//   test_prl_host gpu : full parity on a device
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../oracle/prl_oracle.h"
+#include "../../prlib_amd/csrc/prl/prl.h"
+
+static int g_failures = 0;
+#define CHECK(cond)                                                          \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);      \
+            ++g_failures;                                                    \
+        }                                                                    \
+    } while (0)
+
+static cv::Mat synth_page(int rows, int cols, unsigned seed, int channels = 1)
+{
+    cv::Mat m(rows, cols, CV_MAKETYPE(CV_8U, channels));
+    unsigned s = seed * 2654435761u + 12345u;
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols * channels; ++x) {
+            s = s * 1664525u + 1013904223u;
+            int v = 200 + (int)((s >> 24) % 41) - 20;
+            if (((x / channels / 9) + (y / 5)) % 7 == 0) v -= 120;  // dark strokes
+            m.ptr(y)[x] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    return m;
+}
+
+template <typename F> static bool throws_invalid_argument(F f)
+{
+    try {
+        f();
+    } catch (const std::invalid_argument&) {
+        return true;
+    } catch (...) {
+        return false;
+    }
+    return false;
+}
+
+static void test_validation()
+{
+    cv::Mat empty, out;
+    CHECK(throws_invalid_argument([&] { prl::binarizeSauvola(empty, out); }));
+    CHECK(throws_invalid_argument([&] { prl::binarizeFeng(empty, out); }));
+    cv::Mat page = synth_page(40, 50, 1);
+    CHECK(throws_invalid_argument([&] { prl::binarizeSauvola(page, out, 30); }));   // even window
+    CHECK(throws_invalid_argument([&] { prl::binarizeNiblack(page, out, 1); }));    // window <= 1
+    CHECK(throws_invalid_argument([&] { prl::binarizeNICK(page, out, -3); }));
+    CHECK(page.rows == 40 && page.cols == 50);  // a rejected call leaves the input alone
+    // global Otsu plumbing (host only): bimodal page splits between the modes
+    cv::Mat bi(64, 64, CV_8UC1), bo;
+    for (int y = 0; y < 64; ++y)
+        for (int x = 0; x < 64; ++x) bi.at<unsigned char>(y, x) = (x < 20) ? 40 + (y % 3) : 210 + (x % 5);
+    prl::binarize(bi, bo);
+    CHECK(bo.rows == 64 && bo.cols == 64);
+    CHECK(bo.at<unsigned char>(5, 5) == 0 && bo.at<unsigned char>(5, 40) == 255);
+    std::vector<unsigned char> ob(64 * 64);
+    prl_oracle_otsu(bi.data, bi.step, 64, 64, ob.data(), 64);
+    CHECK(std::memcmp(ob.data(), bo.data, ob.size()) == 0);
+}
+
+static void test_no_device_is_loud()
+{
+    cv::Mat page = synth_page(64, 64, 2), out;
+    bool threw = false;
+    try {
+        prl::binarizeSauvola(page, out, 15, 0.34, 0);
+    } catch (const cv::Exception& e) {
+        threw = std::string(e.what()).find("no usable HIP device") != std::string::npos;
+    } catch (...) {
+    }
+    CHECK(threw);
+}
+
+static void check_method(int method, int rows, int cols, int w, double k, int morph, int channels = 1)
+{
+    cv::Mat in = synth_page(rows, cols, 7u + method, channels);
+    cv::Mat gray_ref;
+    if (channels == 1) gray_ref = in.clone();
+    else {
+        gray_ref.create(rows, cols, CV_8UC1);
+        prl_oracle_bgr2gray(in.data, in.step, cols, rows, channels, gray_ref.data, gray_ref.step);
+    }
+    prl_binarize_params p{};
+    p.method = method;
+    p.window_size = w;
+    p.k = k;
+    p.morph_iterations = morph;
+    p.feng_alpha1 = 0.75;
+    p.feng_k1 = 0.2;
+    p.feng_k2 = 0.03;
+    p.feng_gamma = 2.0;
+    prl_binarize_geometry g{};
+    CHECK(prl_oracle_binarize_geometry(&p, cols, rows, &g) == PRL_OK);
+    std::vector<unsigned char> want((size_t)g.out_w * g.out_h), pad((size_t)g.padded_w * g.padded_h);
+    CHECK(prl_oracle_binarize(&p, gray_ref.data, gray_ref.step, cols, rows, want.data(), (size_t)g.out_w) == PRL_OK);
+    prl_oracle_pad_replicate(gray_ref.data, gray_ref.step, cols, rows, g.half, pad.data(), (size_t)g.padded_w);
+
+    cv::Mat out;
+    switch (method) {
+    case PRL_SAUVOLA: prl::binarizeSauvola(in, out, w, k, morph); break;
+    case PRL_NIBLACK: prl::binarizeNiblack(in, out, w, k, morph); break;
+    case PRL_WOLFJOLION: prl::binarizeWolfJolion(in, out, w, k, morph); break;
+    case PRL_NICK: prl::binarizeNICK(in, out, w, k, morph); break;
+    default: prl::binarizeFeng(in, out, w, 0.75, 0.2, 0.03, 2.0, morph); break;
+    }
+    CHECK(out.rows == g.out_h && out.cols == g.out_w && out.type() == CV_8UC1);
+    size_t bad = 0;
+    for (int y = 0; y < out.rows; ++y) bad += std::memcmp(out.ptr(y), &want[(size_t)y * g.out_w], (size_t)g.out_w) != 0;
+    CHECK(bad == 0);
+    // side effect: the caller's Mat is now the replicate-padded gray page (binarizeSauvola.cpp:51,65)
+    CHECK(in.rows == g.padded_h && in.cols == g.padded_w && in.channels() == 1);
+    bad = 0;
+    for (int y = 0; y < in.rows && in.cols == g.padded_w; ++y)
+        bad += std::memcmp(in.ptr(y), &pad[(size_t)y * g.padded_w], (size_t)g.padded_w) != 0;
+    CHECK(bad == 0);
+}
+
+static void test_gpu()
+{
+    check_method(PRL_SAUVOLA, 120, 160, 15, 0.34, 0);
+    check_method(PRL_SAUVOLA, 300, 260, 101, 0.01, 2);  // header defaults
+    check_method(PRL_NIBLACK, 97, 131, 31, 0.2, 2);
+    check_method(PRL_WOLFJOLION, 140, 150, 31, 0.3, -1);
+    check_method(PRL_NICK, 111, 99, 21, -0.01, 0);
+    check_method(PRL_FENG, 130, 128, 21, 0.0, 2);
+    check_method(PRL_SAUVOLA, 90, 100, 15, 0.34, 0, 3);  // BGR input: cvtColor in place, then padded
+    // ROI input (step > cols), as cv::Mat views are
+    cv::Mat big = synth_page(100, 200, 9), roi = big(cv::Rect(10, 5, 120, 80)), out;
+    cv::Mat roi_copy = roi.clone();
+    prl::binarizeNICK(roi, out, 21, -0.1, 0);
+    prl_binarize_params p{};
+    p.method = PRL_NICK; p.window_size = 21; p.k = -0.1;
+    std::vector<unsigned char> want((size_t)(120 - 21) * (80 - 21));
+    CHECK(prl_oracle_binarize(&p, roi_copy.data, roi_copy.step, 120, 80, want.data(), 120 - 21) == PRL_OK);
+    CHECK(out.rows == 59 && out.cols == 99);
+    size_t bad = 0;
+    for (int y = 0; y < out.rows; ++y) bad += std::memcmp(out.ptr(y), &want[(size_t)y * 99], 99) != 0;
+    CHECK(bad == 0);
+    // Wolf/NICK/Feng on a page no larger than the window: cv::Exception upstream (empty ROI)
+    cv::Mat small = synth_page(21, 40, 3);
+    bool threw = false;
+    try { prl::binarizeNICK(small, out, 21); } catch (const cv::Exception&) { threw = true; } catch (...) {}
+    CHECK(threw);
+    // prl::denoise on a BGR scan
+    cv::Mat noisy = synth_page(70, 90, 11, 3), den;
+    prl::denoise(noisy, den, 10.0);
+    std::vector<unsigned char> dw((size_t)70 * 90 * 3);
+    CHECK(prl_oracle_denoise(3, 10.0f, noisy.data, noisy.step, 90, 70, dw.data(), 270, 4) == PRL_OK);
+    CHECK(den.rows == 70 && den.cols == 90 && den.channels() == 3);
+    bad = 0;
+    for (int y = 0; y < 70; ++y) bad += std::memcmp(den.ptr(y), &dw[(size_t)y * 270], 270) != 0;
+    CHECK(bad == 0);
+    threw = false;
+    cv::Mat gray1 = synth_page(30, 30, 5);
+    try { prl::denoise(gray1, den); } catch (const cv::Exception&) { threw = true; } catch (...) {}
+    CHECK(threw);  // 8UC1 is rejected by fastNlMeansDenoisingColored
+}
+
+int main(int argc, char** argv)
+{
+    const std::string mode = argc > 1 ? argv[1] : "cpu";
+    test_validation();
+    if (mode == "gpu") test_gpu();
+    else test_no_device_is_loud();
+    if (g_failures) {
+        std::printf("%d check(s) failed\n", g_failures);
+        return 1;
+    }
+    std::printf("ok (%s)\n", mode.c_str());
+    return 0;
+}

@@ -1,0 +1,37 @@
+"""The C++ host layer (prlib_amd/csrc/prl/prl.h: prl::binarize*(cv::Mat&, cv::Mat&, ...), prl::denoise),
+driven through tests/cpp/test_prl_host.cpp exactly like the reference's sample mains drive PRLib."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "test_prl_host")
+
+
+def _build():
+    import __graft_entry__ as ge
+
+    ge.build_hip_library()
+    from oracle import capi
+
+    capi.build()
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"], check=True)
+
+
+def test_cpp_host_validation_and_loud_failure_without_device():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a device is present; the no-device behaviour is checked on the CPU box")
+    _build()
+    r = subprocess.run([BIN, "cpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_parity_on_device():
+    if not os.path.exists(BIN):
+        _build()
+    r = subprocess.run([BIN, "gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
