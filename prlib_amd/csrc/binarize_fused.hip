@@ -23,6 +23,7 @@
 // "leaving" row of the sliding window are re-read from L2.  Bound: HBM; in practice VALU issue
 // (~30 lane-ops/px) is the co-limiter, see DESIGN.md.
 #include <cmath>
+#include <cstdlib>
 
 #include "prl_device_math.h"
 #include "prl_internal.h"
@@ -59,6 +60,8 @@ struct FusedParams {
     double vthr;       // same floor for the float64 interval test
     double Em, Eq;     // |m_literal - f*S| <= Em, |q_literal - f*Q| <= Eq
     unsigned ref_cap, wl_cap;
+    int need_p0;       // T may be negative: mask bytes of p == 0 pixels must be cleared explicitly
+    int ring_rows;     // > 0: LDS ring variant with this many rows per wavefront
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -205,8 +208,10 @@ __device__ __forceinline__ uint2 apply_edge(uint2 v, int sh)
 
 // One wavefront: a strip of SW padded columns x a segment of output rows.
 //   EDGE  : the strip touches the left/right page border (replicate clamp, partial stores)
-template <int METHOD, int SH, bool EDGE>
-__device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, size_t ostep,
+//   RING  : the last w-1 window rows of the strip live in a per-wavefront LDS ring (512 B per row), so
+//           the leaving row and the compared pixels are never re-read from memory
+template <int METHOD, int SH, bool EDGE, bool RING>
+__device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, size_t ostep, unsigned char* ring,
                                            const FusedParams& fp, int page, int xs, int ys, int ye, int lane,
                                            float c1page, PageGlobals* __restrict__ g,
                                            RefItem* __restrict__ rl, unsigned* __restrict__ counters)
@@ -233,10 +238,11 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
 #pragma unroll
     for (int c = 0; c < CPL; ++c) VS[c] = VQ[c] = 0;
 
-    // warm-up: vertical sums over padded rows ys+1 .. ys+w-1
+    // warm-up: vertical sums over padded rows ys+1 .. ys+w-1 (ring slot r holds padded row ys+1+r)
 #pragma unroll 2
     for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
         const uint2 v = load_win(pr);
+        if (RING) *reinterpret_cast<uint2*>(ring + (size_t)(pr - ys - 1) * SW + CPL * lane) = v;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const unsigned b = byte_of(v, c);
@@ -245,13 +251,24 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
         }
     }
 
+    // ring slot of the leaving row y+1 / of the compared row y+h (both advance by one per iteration)
+    int slot_old = 0, slot_p = RING ? (h - 1) % (w - 1) : 0;
+    uint2 vnew_n = load_win(ys + w);  // entering row of the first iteration, fetched one iteration ahead
 #pragma unroll 1
     for (int y = ys; y < ye; ++y) {
-        // loads of this iteration: compared pixels now, entering/leaving rows for the slide at the end
-        uint2 pv = gload8(img + (size_t)y * istep + ep.colc);
-        const uint2 vnew = load_win(y + w);   // clamped row index: harmless on the last iteration
-        const uint2 vold = load_win(y + 1);
-        if (EDGE) pv = apply_edge(pv, ep.sh);
+        uint2 pv, vold;
+        const uint2 vnew = vnew_n;
+        if (RING) {
+            vnew_n = load_win(y + 1 + w);  // next iteration's entering row (row index clamps at the page end)
+            vold = *reinterpret_cast<const uint2*>(ring + (size_t)slot_old * SW + CPL * lane);
+            // compared pixels: strip columns 8*lane + h-1 .. +7 of padded row y+h (unaligned LDS read)
+            __builtin_memcpy(&pv, ring + (size_t)slot_p * SW + CPL * lane + (h - 1), 8);
+        } else {
+            pv = gload8(img + (size_t)y * istep + ep.colc);
+            vnew_n = load_win(y + 1 + w);
+            vold = load_win(y + 1);
+            if (EDGE) pv = apply_edge(pv, ep.sh);
+        }
 
         // horizontal window sums: E = exclusive prefix over the strip, S(j0) = E(j0+w-1) - E(j0)
         unsigned ES[CPL], EQ[CPL];
@@ -281,7 +298,9 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             Qsum[c] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)EQ[sub]) - EQ[c];
         }
 
-        // float32 decision; tmin/vmin track the smallest margin / variance of the lane's 8 pixels
+        // float32 decision; tmin/vmin track the smallest margin / variance of the lane's 8 pixels.
+        // Mask bytes: every settled pixel has |t| > eps1 >= 1e-6, so t * 2^30 saturates the float->u8
+        // conversion to 255 (white, t > 0) or 0; unsettled pixels are overwritten by k_refine/k_fixup.
         unsigned lo = 0, hi = 0;
         float tmin = 3.0e38f, vmin = 3.0e38f;
 #pragma unroll
@@ -292,9 +311,16 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             const float t = eval32<METHOD>(fp, Ssum[c], Qsum[c], P, c1page, &v32);
             tmin = fminf(tmin, fabsf(t));
             vmin = fminf(vmin, v32);
-            const bool white = (t > 0.0f) && (p != 0);
-            const unsigned o = white ? (0xffu << (8 * (c & 3))) : 0u;
-            if (c < 4) lo |= o; else hi |= o;
+            const float ts = t * 1073741824.0f;
+            if (c < 4) lo = __builtin_amdgcn_cvt_pk_u8_f32(ts, c, lo);
+            else hi = __builtin_amdgcn_cvt_pk_u8_f32(ts, c - 4, hi);
+        }
+        if (fp.need_p0) {
+            // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative)
+            const unsigned nzl = (((pv.x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | pv.x) & 0x80808080u;
+            const unsigned nzh = (((pv.y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | pv.y) & 0x80808080u;
+            lo &= (nzl >> 7) * 255u;
+            hi &= (nzh >> 7) * 255u;
         }
 
         // rare: some pixel of this lane is not settled by the float32 test -> queue it for k_refine
@@ -347,22 +373,31 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             VS[c] += (unsigned)d;
             VQ[c] += (unsigned)(d * sm);
         }
+        if (RING) {
+            *reinterpret_cast<uint2*>(ring + (size_t)slot_old * SW + CPL * lane) = vnew;  // row y+w replaces row y+1
+            slot_old = (slot_old + 1 == w - 1) ? 0 : slot_old + 1;
+            slot_p = (slot_p + 1 == w - 1) ? 0 : slot_p + 1;
+        }
     }
 }
 
-template <int METHOD, int SH>
+extern __shared__ __attribute__((aligned(16))) unsigned char fused_ring_lds[];
+
+template <int METHOD, int SH, bool RING>
 __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, FusedParams fp,
                                               PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
                                               unsigned* __restrict__ counters)
 {
     const ThrParams& tp = fp.tp;
     const int lane = threadIdx.x & (kWave - 1);
+    const unsigned wpb = blockDim.x >> 6;  // wavefronts per block
     // XCD-aware block order: hardware deals blocks round-robin over the 8 XCDs, so blocks b and b+8
     // share an L2.  Give each XCD a contiguous range of logical blocks (= neighbouring strips and
     // segments of the same pages) so halo re-reads hit that XCD's L2.  Speed only, never correctness.
     const unsigned nb = gridDim.x;
     const unsigned lb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
-    const unsigned wid = __builtin_amdgcn_readfirstlane(lb * 4u + (threadIdx.x >> 6));
+    const unsigned wv = threadIdx.x >> 6;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(lb * wpb + wv);
     if (wid >= fp.total_waves) return;
     const int per_page = fp.n_strips * fp.n_segs;
     const int page = (int)(wid / (unsigned)per_page);
@@ -383,15 +418,17 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
         const double c3 = (tp.k2 * imin + (-imin)) + 0.0;  // binarizeFeng.cpp:137 with r2 = c2 = 1
         c1page = (float)c3;
     }
+    // per-wavefront ring: ring_rows rows of SW bytes (+32 so the unaligned read of the last row stays inside)
+    unsigned char* ring = RING ? fused_ring_lds + (size_t)wv * ((size_t)fp.ring_rows * SW + 32) : nullptr;
 
     // interior strip: every lane's 8-byte window fetch and the whole 512-column output span lie inside
     // the page, so no clamp, no partial store
     const int first_col = xs + 1 - tp.half;
     const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
     if (interior)
-        strip_loop<METHOD, SH, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, c1page, g, rl, counters);
+        strip_loop<METHOD, SH, false, RING>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, c1page, g, rl, counters);
     else
-        strip_loop<METHOD, SH, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, c1page, g, rl, counters);
+        strip_loop<METHOD, SH, true, RING>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, c1page, g, rl, counters);
 }
 
 // ---- second stage: float64 interval test of the queued pixels, one thread per pixel ----------------
@@ -491,18 +528,32 @@ __global__ void __launch_bounds__(256) k_fixup(PageSet src, PageSetOut dst, Fuse
 }
 
 template <int METHOD>
-int launch_fused(int sh, dim3 grid, hipStream_t stream, const PageSet& src, const PageSetOut& dst,
+int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst,
                  const FusedParams& fp, PageGlobals* g, RefItem* rl, WorkItem* wl, unsigned* cnt,
                  hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     if (ev_start) PRL_HIP_CHECK(hipEventRecord(ev_start, stream));
+    const bool ring = fp.ring_rows > 0;
+    const unsigned wpb = ring ? 2u : 4u;
+    unsigned blocks = (fp.total_waves + wpb - 1) / wpb;
+    blocks = (blocks + 7) / 8 * 8;
+    const dim3 grid(blocks), block(64 * wpb);
+    const size_t lds = ring ? (size_t)wpb * ((size_t)fp.ring_rows * SW + 32) : 0;
+#define PRL_LAUNCH_FUSED(SHV)                                                                              \
+    do {                                                                                                   \
+        if (ring)                                                                                          \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, true>), grid, block, lds, stream, src, dst, fp, g, rl, cnt);  \
+        else                                                                                               \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, false>), grid, block, 0, stream, src, dst, fp, g, rl, cnt);   \
+    } while (0)
     switch (sh) {
-    case 0: hipLaunchKernelGGL((k_fused<METHOD, 0>), grid, dim3(256), 0, stream, src, dst, fp, g, rl, cnt); break;
-    case 2: hipLaunchKernelGGL((k_fused<METHOD, 2>), grid, dim3(256), 0, stream, src, dst, fp, g, rl, cnt); break;
-    case 4: hipLaunchKernelGGL((k_fused<METHOD, 4>), grid, dim3(256), 0, stream, src, dst, fp, g, rl, cnt); break;
-    case 6: hipLaunchKernelGGL((k_fused<METHOD, 6>), grid, dim3(256), 0, stream, src, dst, fp, g, rl, cnt); break;
+    case 0: PRL_LAUNCH_FUSED(0); break;
+    case 2: PRL_LAUNCH_FUSED(2); break;
+    case 4: PRL_LAUNCH_FUSED(4); break;
+    case 6: PRL_LAUNCH_FUSED(6); break;
     default: return PRL_ERR_BAD_ARG;
     }
+#undef PRL_LAUNCH_FUSED
     PRL_HIP_CHECK(hipGetLastError());
     if (ev_stop) PRL_HIP_CHECK(hipEventRecord(ev_stop, stream));
     hipLaunchKernelGGL((k_refine<METHOD>), dim3(64), dim3(256), 0, stream, dst, fp, g, rl, wl, cnt);
@@ -643,11 +694,11 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.eps1 = (float)(b.eps1 * 1.01);
     fp.ref_cap = kRefineCap;
     fp.wl_cap = kWorkCap;
-    switch (tp.method) {
-    case PRL_SAUVOLA: fp.c0 = (float)tp.a; fp.c1 = (float)tp.b; break;
-    case PRL_NIBLACK: fp.c0 = (float)tp.k; break;
-    case PRL_NICK: fp.c0 = (float)tp.k; break;
-    case PRL_FENG: fp.c0 = (float)(1.0 + tp.c1); break;
+    switch (tp.method) {  // need_p0 = 0 only where T >= 0 for every window, so p == 0 can never come out white
+    case PRL_SAUVOLA: fp.c0 = (float)tp.a; fp.c1 = (float)tp.b; fp.need_p0 = !(tp.a >= 0.0 && tp.b >= 0.0); break;
+    case PRL_NIBLACK: fp.c0 = (float)tp.k; fp.need_p0 = !(tp.k >= 0.0); break;
+    case PRL_NICK: fp.c0 = (float)tp.k; fp.need_p0 = !(tp.k >= 0.0); break;
+    case PRL_FENG: fp.c0 = (float)(1.0 + tp.c1); fp.need_p0 = 1; break;
     default: return PRL_ERR_BAD_ARG;
     }
 
@@ -660,16 +711,46 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         int st = page_min_run(tp, src, n_pages, d_globals, stream);
         if (st != PRL_OK) return st;
     }
-    unsigned blocks = (fp.total_waves + 3) / 4;
-    blocks = (blocks + 7) / 8 * 8;
+    // LDS ring variant (PRL_HIP_RING=1): a wavefront's w-1 rows of 512 B must fit a 16 KiB slice (w <= 33).
+    // Measured on MI355X (256 x 4K, w=31): 5.49 ms vs 4.58 ms without the ring — the kernel is bound by
+    // VALU issue, the ring caps occupancy at 2.5 waves/SIMD, and the re-reads it removes are served by the
+    // Infinity Cache anyway.  Kept for windows/pages where the L2/MALL working set no longer fits.
+    const char* ring_env = std::getenv("PRL_HIP_RING");
+    fp.ring_rows = ((size_t)(tp.w - 1) * SW <= 16384 && ring_env && ring_env[0] == '1') ? tp.w - 1 : 0;
     const int sh = (tp.w - 1) & 7;
     switch (tp.method) {
-    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
-    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
-    case PRL_NICK: return launch_fused<PRL_NICK>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
-    case PRL_FENG: return launch_fused<PRL_FENG>(sh, dim3(blocks), stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
+    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
+    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
+    case PRL_NICK: return launch_fused<PRL_NICK>(sh, stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
+    case PRL_FENG: return launch_fused<PRL_FENG>(sh, stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
     default: return PRL_ERR_BAD_ARG;
     }
 }
 
 }  // namespace prl_hip
+
+// ---- counter calibration hook (not in the public header) -------------------------------------------
+// Streams `bytes` with the access shape k_fused uses (8 B per lane, wave-contiguous) so that
+// rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on a known byte count (MI355X_MICROARCH.md:
+// FETCH_SIZE is only calibrated for 16 B/lane streams on gfx950).
+namespace prl_hip {
+namespace {
+__global__ void __launch_bounds__(256) k_calib_stream8(const uint2* __restrict__ src, uint2* __restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint2 v = src[i];
+        v.x ^= 0x01010101u;
+        dst[i] = v;
+    }
+}
+}  // namespace
+}  // namespace prl_hip
+
+extern "C" int prl_hip_internal_calib_stream8(const void* d_src, void* d_dst, size_t bytes, void* stream)
+{
+    using namespace prl_hip;
+    hipLaunchKernelGGL(k_calib_stream8, dim3(256 * 16), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint2*>(d_src), static_cast<uint2*>(d_dst), bytes / 8);
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}

@@ -18,4 +18,12 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
     --output-format csv -d "$OUT/pmc_sq2" -- python3 bench.py $ARGS > "$OUT/pmc_sq2.log" 2>&1
 python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+# keep what is judged (stats + summary), drop the bulky per-dispatch traces so gpurun_out stays < 64 MiB
+mkdir -p "$OUT/keep"
+find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/keep/kernel_stats.csv" \;
+for d in pmc_fetch pmc_write pmc_sq pmc_sq2; do
+  f=$(find "$OUT/$d" -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && grep -E "Counter_Name|k_fused|k_threshold|k_nlm" "$f" | head -400 > "$OUT/keep/${d}_counters_head.csv"
+done
+rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/pmc_sq2"
 cat "$OUT/summary.txt"
