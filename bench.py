@@ -79,14 +79,10 @@ def cpu_baseline(pages_host, params_oracle, budget_s):
 def main():
     args = parse()
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    from prlib_amd import dist as pdist
+
+    world, rank, local_rank = pdist.init()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path in prlib_amd)")
     dev = torch.device("cuda", local_rank)
@@ -102,9 +98,11 @@ def main():
     g = prlib_amd.geometry(params, W, H)
     prlib_amd.set_exec_mode(1 if args.mode == "literal" else 0)
 
-    # synthetic pages, resident in HBM before the timed region; each rank draws its own pages
+    # synthetic pages, resident in HBM before the timed region.  The job's page list has
+    # world * pages_per_gpu pages (weak scaling); this rank owns a contiguous block of it.
+    mine = pdist.page_range(world * args.pages, world, rank)
     pitch = (W + 255) // 256 * 256
-    pages = synth.pages_torch(args.pages, H, W, dev, seed=1000 + rank * args.pages, pitch=pitch)
+    pages = synth.pages_torch(len(mine), H, W, dev, seed=1000 + mine.start, pitch=pitch)
     out, out_pitch = prlib_amd.binarizations.alloc_output(args.pages, g.out_w, g.out_h, dev)
     L = _capi.lib()
 
@@ -113,8 +111,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        pdist.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -122,14 +119,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    barrier()
+    elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)
 
     # dominant-kernel duration: HIP events recorded by the library around k_fused on the launch stream
     _capi.check(L.prl_hip_set_profiling(1))
@@ -212,9 +203,7 @@ def main():
                        "literal_pages": int(stats.literal_pages)},
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    pdist.finish()
 
 
 if __name__ == "__main__":

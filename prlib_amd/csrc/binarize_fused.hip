@@ -36,7 +36,7 @@ constexpr int kWave = 64;
 constexpr int CPL = 8;                 // columns per lane
 constexpr int SW = kWave * CPL;        // padded columns per wavefront strip
 constexpr unsigned kRefineCap = 1u << 20;  // pixels the float32 test may leave undecided per call
-constexpr unsigned kWorkCap = 1u << 18;    // pixels the float64 interval test may leave undecided
+constexpr unsigned kWorkCap = 1u << 14;    // pixels the float64 interval test may leave undecided (more: literal page)
 
 struct RefItem {   // undecided after the float32 test: exact window sums travel with the pixel
     int page, y, x;
@@ -45,6 +45,16 @@ struct RefItem {   // undecided after the float32 test: exact window sums travel
 struct WorkItem {  // undecided after the float64 interval test
     int page, y, x;
     int pad;
+};
+
+// pseudo-methods of the two extra Wolf-Jolion sweeps (max deviation search)
+constexpr int kWolfMax = 100;      // sweep A: float32 variance maximum per page and per wavefront
+constexpr int kWolfCollect = 101;  // sweep B: queue every pixel whose variance could be the literal maximum
+
+struct PageK {  // per-page constants of the float32 test
+    float c1;    // Feng: k2*Imin - Imin ; Wolf: k / devianceMax ; Wolf sweep B: candidate threshold on v~
+    float imin;  // Wolf: cv::minMaxLoc(imageInput) minimum
+    float eps1;  // decision margin (Wolf: page dependent through k / devianceMax)
 };
 
 struct FusedParams {
@@ -62,6 +72,10 @@ struct FusedParams {
     unsigned ref_cap, wl_cap;
     int need_p0;       // T may be negative: mask bytes of p == 0 pixels must be cleared explicitly
     int ring_rows;     // > 0: LDS ring variant with this many rows per wavefront
+    float es_max;      // Wolf: bound on |s_literal - s*| for v* >= vthr (enters eps1 scaled by |k/devianceMax|)
+    float rho;         // Wolf: relative error bound of the float32 variance v~
+    float ev2;         // Wolf: 2 * Ev (literal variance noise)
+    float* segmax;     // Wolf: per-wavefront maximum of v~ (sweep A -> sweep B)
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -92,7 +106,7 @@ __device__ __forceinline__ unsigned byte_of(uint2 v, int c)
 //   NICK     c0 = k                        T = m + c0*sqrt(q)            (m*m + s*s == q)
 //   FENG     c0 = 1 + (1-alpha1), c1 = k2*Imin - Imin (per page)   T = c0*m + c1   (s > 0)
 template <int METHOD>
-__device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsigned Q, float P, float c1page,
+__device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsigned Q, float P, const PageK& pk,
                                         float* v_out)
 {
     const float Sf = (float)S, Qf = (float)Q;
@@ -110,8 +124,16 @@ __device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsig
     } else if (METHOD == PRL_NICK) {
         const float c = __builtin_amdgcn_sqrtf(q);
         return P - fmaf(c, fp.c0, m);
-    } else {  // FENG
-        return P - fmaf(m, fp.c0, c1page);
+    } else if (METHOD == PRL_WOLFJOLION) {
+        //   WOLF     c0 = k, pk.c1 = k/max(s), pk.imin         T = m + (s*c1 - k)*(m - Imin)
+        const float s = __builtin_amdgcn_sqrtf(v);
+        const float d = fmaf(s, pk.c1, -fp.c0);
+        const float e = m - pk.imin;
+        return P - fmaf(d, e, m);
+    } else if (METHOD == PRL_FENG) {
+        return P - fmaf(m, fp.c0, pk.c1);
+    } else {  // Wolf sweeps: only v~ is used
+        return 0.0f;
     }
 }
 
@@ -119,7 +141,8 @@ __device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsig
 // T* is the threshold in exact arithmetic from the exact window sums; the literal sequence differs
 // from it by at most ET (propagated from Em, Eq, the host-side bounds on the 4-tap rounding noise).
 template <int METHOD>
-__device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, unsigned Q, unsigned p, double imin)
+__device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, unsigned Q, unsigned p, double imin,
+                                             double coeff)
 {
     if (p == 0) return 0;  // 0 > T8 is false for every T8 (also for NaN -> 0)
     const ThrParams& tp = fp.tp;
@@ -147,6 +170,16 @@ __device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, 
         const double Ec = 1.001 * EC / sqrt(q - EC) + tiny * c;
         T = m + c * tp.k;
         ET = fp.Em + fabs(tp.k) * Ec + tiny * (fabs(T) + m);
+    } else if (METHOD == PRL_WOLFJOLION) {
+        if (!(fabs(coeff) < 1e300)) return 2;  // devianceMax == 0 or no finite deviation: literal decides
+        const double d = s * coeff + (-tp.k);
+        const double Ed = fabs(coeff) * Es + tiny * (fabs(coeff) * s + fabs(tp.k));
+        const double e = m - imin;
+        const double Ee = fp.Em + tiny * (m + imin);
+        const double gg = d * e;
+        const double Eg = fabs(d) * Ee + fabs(e) * Ed + Ed * Ee + tiny * fabs(gg);
+        T = m + gg;
+        ET = fp.Em + Eg + tiny * (fabs(T) + m);
     } else {  // FENG with s > 0 (guaranteed by v > 4 Ev): r = r2 = c2 = 1
         const double c3 = (tp.k2 * imin + (-imin)) + 0.0;
         const double g = 1.0 + tp.c1;
@@ -213,9 +246,11 @@ __device__ __forceinline__ uint2 apply_edge(uint2 v, int sh)
 template <int METHOD, int SH, bool EDGE, bool RING>
 __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, size_t ostep, unsigned char* ring,
                                            const FusedParams& fp, int page, int xs, int ys, int ye, int lane,
-                                           float c1page, PageGlobals* __restrict__ g,
-                                           RefItem* __restrict__ rl, unsigned* __restrict__ counters)
+                                           const PageK& pk, unsigned wid, PageGlobals* __restrict__ g,
+                                           RefItem* __restrict__ rl, WorkItem* __restrict__ cand,
+                                           unsigned* __restrict__ counters)
 {
+    constexpr bool SWEEP = (METHOD == kWolfMax || METHOD == kWolfCollect);
     const ThrParams& tp = fp.tp;
     const int W = tp.width, H = tp.height, h = tp.half, w = tp.w;
     const int col0 = xs + 1 - h + CPL * lane;  // image column of this lane's sub-column 0
@@ -253,6 +288,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
 
     // ring slot of the leaving row y+1 / of the compared row y+h (both advance by one per iteration)
     int slot_old = 0, slot_p = RING ? (h - 1) % (w - 1) : 0;
+    float vmax_lane = 0.0f;  // Wolf sweep A
     uint2 vnew_n = load_win(ys + w);  // entering row of the first iteration, fetched one iteration ahead
 #pragma unroll 1
     for (int y = ys; y < ye; ++y) {
@@ -264,10 +300,10 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             // compared pixels: strip columns 8*lane + h-1 .. +7 of padded row y+h (unaligned LDS read)
             __builtin_memcpy(&pv, ring + (size_t)slot_p * SW + CPL * lane + (h - 1), 8);
         } else {
-            pv = gload8(img + (size_t)y * istep + ep.colc);
+            if (!SWEEP) pv = gload8(img + (size_t)y * istep + ep.colc);
             vnew_n = load_win(y + 1 + w);
             vold = load_win(y + 1);
-            if (EDGE) pv = apply_edge(pv, ep.sh);
+            if (EDGE && !SWEEP) pv = apply_edge(pv, ep.sh);
         }
 
         // horizontal window sums: E = exclusive prefix over the strip, S(j0) = E(j0+w-1) - E(j0)
@@ -298,71 +334,108 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             Qsum[c] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)EQ[sub]) - EQ[c];
         }
 
-        // float32 decision; tmin/vmin track the smallest margin / variance of the lane's 8 pixels.
-        // Mask bytes: every settled pixel has |t| > eps1 >= 1e-6, so t * 2^30 saturates the float->u8
-        // conversion to 255 (white, t > 0) or 0; unsettled pixels are overwritten by k_refine/k_fixup.
-        unsigned lo = 0, hi = 0;
-        float tmin = 3.0e38f, vmin = 3.0e38f;
+        if (METHOD == kWolfMax) {
+            // Wolf sweep A: running maximum of the float32 variance over the wavefront's valid pixels
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const unsigned p = byte_of(pv, c);
-            const float P = (float)p - 0.5f;
-            float v32;
-            const float t = eval32<METHOD>(fp, Ssum[c], Qsum[c], P, c1page, &v32);
-            tmin = fminf(tmin, fabsf(t));
-            vmin = fminf(vmin, v32);
-            const float ts = t * 1073741824.0f;
-            if (c < 4) lo = __builtin_amdgcn_cvt_pk_u8_f32(ts, c, lo);
-            else hi = __builtin_amdgcn_cvt_pk_u8_f32(ts, c - 4, hi);
-        }
-        if (fp.need_p0) {
-            // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative)
-            const unsigned nzl = (((pv.x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | pv.x) & 0x80808080u;
-            const unsigned nzh = (((pv.y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | pv.y) & 0x80808080u;
-            lo &= (nzl >> 7) * 255u;
-            hi &= (nzh >> 7) * 255u;
-        }
-
-        // rare: some pixel of this lane is not settled by the float32 test -> queue it for k_refine
-        const bool unsure = lane_has_out && !((tmin > fp.eps1) && (vmin > fp.vthr32));
-        if (__ballot(unsure) != 0ull) {
-            if (unsure) {
-#pragma unroll 1
+            for (int c = 0; c < CPL; ++c) {
+                float v32;
+                (void)eval32<METHOD>(fp, Ssum[c], Qsum[c], 0.0f, pk, &v32);
+                if (lane_has_out && (x0 + c < tp.ow)) vmax_lane = fmaxf(vmax_lane, v32);
+            }
+        } else if (METHOD == kWolfCollect) {
+            // Wolf sweep B: queue the pixels whose literal deviation could be the page maximum
+            float vm = 0.0f;
+            float vv[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                (void)eval32<METHOD>(fp, Ssum[c], Qsum[c], 0.0f, pk, &vv[c]);
+                if (lane_has_out && (x0 + c < tp.ow)) vm = fmaxf(vm, vv[c]);
+            }
+            if (__ballot(vm >= pk.c1) != 0ull) {
+#pragma unroll
                 for (int c = 0; c < CPL; ++c) {
-                    if (x0 + c >= tp.ow) break;
-                    const unsigned p = (c < 4 ? pv.x >> (8 * c) : pv.y >> (8 * (c - 4))) & 0xffu;
-                    if (p == 0) continue;  // 0 > T8 is false whatever T is
-                    const unsigned S = c == 0 ? Ssum[0] : c == 1 ? Ssum[1] : c == 2 ? Ssum[2] : c == 3 ? Ssum[3]
-                                     : c == 4 ? Ssum[4] : c == 5 ? Ssum[5] : c == 6 ? Ssum[6] : Ssum[7];
-                    const unsigned Q = c == 0 ? Qsum[0] : c == 1 ? Qsum[1] : c == 2 ? Qsum[2] : c == 3 ? Qsum[3]
-                                     : c == 4 ? Qsum[4] : c == 5 ? Qsum[5] : c == 6 ? Qsum[6] : Qsum[7];
-                    float v32;
-                    const float t = eval32<METHOD>(fp, S, Q, (float)p - 0.5f, c1page, &v32);
-                    if ((fabsf(t) > fp.eps1) && (v32 > fp.vthr32)) continue;
-                    const unsigned idx = atomicAdd(&counters[0], 1u);
-                    if (idx < fp.ref_cap) {
-                        RefItem it;
-                        it.page = page;
-                        it.y = y;
-                        it.x = x0 + c;
-                        it.S = S;
-                        it.Q = Q;
-                        it.p = p;
-                        rl[idx] = it;
-                    } else {
-                        atomicOr(&g[page].worklist_overflow, 1u);
+                    if (lane_has_out && (x0 + c < tp.ow) && vv[c] >= pk.c1) {
+                        const unsigned idx = atomicAdd(&counters[2], 1u);
+                        if (idx < fp.wl_cap) {
+                            WorkItem it;
+                            it.page = page;
+                            it.y = y;
+                            it.x = x0 + c;
+                            it.pad = 0;
+                            cand[idx] = it;
+                        } else {
+                            atomicOr(&g[page].worklist_overflow, 1u);
+                        }
                     }
                 }
             }
-        }
+        } else {
+            // float32 decision; tmin/vmin track the smallest margin / variance of the lane's 8 pixels.
+            // Mask bytes: every settled pixel has |t| > eps1 >= 1e-6, so t * 2^30 saturates the float->u8
+            // conversion to 255 (white, t > 0) or 0; unsettled pixels are overwritten by k_refine/k_fixup.
+            unsigned lo = 0, hi = 0;
+            float tmin = 3.0e38f, vmin = 3.0e38f;
+    #pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const unsigned p = byte_of(pv, c);
+                const float P = (float)p - 0.5f;
+                float v32;
+                const float t = eval32<METHOD>(fp, Ssum[c], Qsum[c], P, pk, &v32);
+                tmin = fminf(tmin, fabsf(t));
+                vmin = fminf(vmin, v32);
+                const float ts = t * 1073741824.0f;
+                if (c < 4) lo = __builtin_amdgcn_cvt_pk_u8_f32(ts, c, lo);
+                else hi = __builtin_amdgcn_cvt_pk_u8_f32(ts, c - 4, hi);
+            }
+            if (fp.need_p0) {
+                // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative)
+                const unsigned nzl = (((pv.x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | pv.x) & 0x80808080u;
+                const unsigned nzh = (((pv.y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | pv.y) & 0x80808080u;
+                lo &= (nzl >> 7) * 255u;
+                hi &= (nzh >> 7) * 255u;
+            }
 
-        // store 8 mask bytes
-        if (full8) {
-            uint2 o = make_uint2(lo, hi);
-            __builtin_memcpy((uint8_t*)(out + (size_t)y * ostep + x0), &o, 8);
-        } else if (EDGE && lane_has_out) {
-            for (int c = 0; c < CPL && x0 + c < tp.ow; ++c)
-                out[(size_t)y * ostep + x0 + c] = (uint8_t)(c < 4 ? (lo >> (8 * c)) : (hi >> (8 * (c - 4))));
+            // rare: some pixel of this lane is not settled by the float32 test -> queue it for k_refine
+            const bool unsure = lane_has_out && !((tmin > pk.eps1) && (vmin > fp.vthr32));
+            if (__ballot(unsure) != 0ull) {
+                if (unsure) {
+    #pragma unroll 1
+                    for (int c = 0; c < CPL; ++c) {
+                        if (x0 + c >= tp.ow) break;
+                        const unsigned p = (c < 4 ? pv.x >> (8 * c) : pv.y >> (8 * (c - 4))) & 0xffu;
+                        if (p == 0) continue;  // 0 > T8 is false whatever T is
+                        const unsigned S = c == 0 ? Ssum[0] : c == 1 ? Ssum[1] : c == 2 ? Ssum[2] : c == 3 ? Ssum[3]
+                                         : c == 4 ? Ssum[4] : c == 5 ? Ssum[5] : c == 6 ? Ssum[6] : Ssum[7];
+                        const unsigned Q = c == 0 ? Qsum[0] : c == 1 ? Qsum[1] : c == 2 ? Qsum[2] : c == 3 ? Qsum[3]
+                                         : c == 4 ? Qsum[4] : c == 5 ? Qsum[5] : c == 6 ? Qsum[6] : Qsum[7];
+                        float v32;
+                        const float t = eval32<METHOD>(fp, S, Q, (float)p - 0.5f, pk, &v32);
+                        if ((fabsf(t) > pk.eps1) && (v32 > fp.vthr32)) continue;
+                        const unsigned idx = atomicAdd(&counters[0], 1u);
+                        if (idx < fp.ref_cap) {
+                            RefItem it;
+                            it.page = page;
+                            it.y = y;
+                            it.x = x0 + c;
+                            it.S = S;
+                            it.Q = Q;
+                            it.p = p;
+                            rl[idx] = it;
+                        } else {
+                            atomicOr(&g[page].worklist_overflow, 1u);
+                        }
+                    }
+                }
+            }
+
+            // store 8 mask bytes
+            if (full8) {
+                uint2 o = make_uint2(lo, hi);
+                __builtin_memcpy((uint8_t*)(out + (size_t)y * ostep + x0), &o, 8);
+            } else if (EDGE && lane_has_out) {
+                for (int c = 0; c < CPL && x0 + c < tp.ow; ++c)
+                    out[(size_t)y * ostep + x0 + c] = (uint8_t)(c < 4 ? (lo >> (8 * c)) : (hi >> (8 * (c - 4))));
+            }
         }
 
         // slide the window one row down
@@ -379,6 +452,14 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             slot_p = (slot_p + 1 == w - 1) ? 0 : slot_p + 1;
         }
     }
+    if (METHOD == kWolfMax) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) vmax_lane = fmaxf(vmax_lane, __shfl_xor(vmax_lane, d, kWave));
+        if (lane == 0) {
+            fp.segmax[wid] = vmax_lane;
+            atomicMax(&g[page].v32max_bits, __float_as_uint(vmax_lane));  // v~ >= 0: bit order == value order
+        }
+    }
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fused_ring_lds[];
@@ -386,7 +467,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char fused_ring_lds[];
 template <int METHOD, int SH, bool RING>
 __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, FusedParams fp,
                                               PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
-                                              unsigned* __restrict__ counters)
+                                              WorkItem* __restrict__ cand, unsigned* __restrict__ counters)
 {
     const ThrParams& tp = fp.tp;
     const int lane = threadIdx.x & (kWave - 1);
@@ -412,11 +493,26 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     const int ys = seg * fp.rows_per_seg;  // first output row of the segment
     const int ye = min(ys + fp.rows_per_seg, tp.oh);
 
-    float c1page = fp.c1;
+    PageK pk;
+    pk.c1 = fp.c1;
+    pk.imin = 0.0f;
+    pk.eps1 = fp.eps1;
     if (METHOD == PRL_FENG) {
         const double imin = (double)g[page].imin;
         const double c3 = (tp.k2 * imin + (-imin)) + 0.0;  // binarizeFeng.cpp:137 with r2 = c2 = 1
-        c1page = (float)c3;
+        pk.c1 = (float)c3;
+    } else if (METHOD == PRL_WOLFJOLION) {
+        const double coeff = g[page].coeff;                // k / devianceMax, binarizeWolfJolion.cpp:121
+        pk.c1 = (float)coeff;
+        pk.imin = (float)g[page].imin;
+        // |T_literal - T*| grows with |coeff| through the sqrt noise; not finite -> nothing is settled here
+        const float ac = fabsf(pk.c1);
+        pk.eps1 = (ac < 3.0e38f) ? fp.eps1 + 2.02f * 255.0f * ac * fp.es_max : __builtin_inff();
+    } else if (METHOD == kWolfCollect) {
+        // a pixel can only carry the literal maximum if v~ >= (1-rho) (Vmax/(1+rho) - 2 Ev)
+        const float vmax = __uint_as_float(g[page].v32max_bits);
+        pk.c1 = (1.0f - fp.rho) * (vmax / (1.0f + fp.rho) - fp.ev2) * 0.999999f;
+        if (!(fp.segmax[wid] >= pk.c1)) return;            // nothing in this wavefront's segment qualifies
     }
     // per-wavefront ring: ring_rows rows of SW bytes (+32 so the unaligned read of the last row stays inside)
     unsigned char* ring = RING ? fused_ring_lds + (size_t)wv * ((size_t)fp.ring_rows * SW + 32) : nullptr;
@@ -426,9 +522,9 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     const int first_col = xs + 1 - tp.half;
     const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
     if (interior)
-        strip_loop<METHOD, SH, false, RING>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, c1page, g, rl, counters);
+        strip_loop<METHOD, SH, false, RING>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
     else
-        strip_loop<METHOD, SH, true, RING>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, c1page, g, rl, counters);
+        strip_loop<METHOD, SH, true, RING>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
 }
 
 // ---- second stage: float64 interval test of the queued pixels, one thread per pixel ----------------
@@ -440,7 +536,7 @@ __global__ void __launch_bounds__(256) k_refine(PageSetOut dst, FusedParams fp, 
     const unsigned n = min(counters[0], fp.ref_cap);
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const RefItem it = rl[i];
-        const unsigned r = refine64<METHOD>(fp, it.S, it.Q, it.p, (double)g[it.page].imin);
+        const unsigned r = refine64<METHOD>(fp, it.S, it.Q, it.p, (double)g[it.page].imin, g[it.page].coeff);
         if (r != 2) {
             dst.page(it.page)[(size_t)it.y * dst.step + it.x] = (uint8_t)r;
             atomicAdd(&g[it.page].n_refined, 1u);
@@ -465,86 +561,166 @@ __global__ void __launch_bounds__(256) k_refine(PageSetOut dst, FusedParams fp, 
 // One workgroup per queued pixel.  The four absolute corners of cv::integral are rebuilt from the
 // page: II'(Y,X) = sum of the replicate-padded image over rows <= Y, cols <= X (exact integers), then
 // the literal float64 sequence of prl_device_math.h decides.  Rare by construction (see header).
-template <int METHOD>
-__global__ void __launch_bounds__(256) k_fixup(PageSet src, PageSetOut dst, FusedParams fp,
-                                              const PageGlobals* __restrict__ g,
-                                              const WorkItem* __restrict__ wl,
-                                              const unsigned* __restrict__ counters)
+// ---- absolute integral corners of queued pixels ----------------------------------------------------------
+// cv::integral's value at padded (Y, X) is the sum of the replicate-padded page over rows <= Y, cols <= X.
+// For a queued output pixel (y, x) the literal 4-tap filter reads the corners (y, x), (y, x+w-1),
+// (y+w-1, x), (y+w-1, x+w-1) of both integrals.  They are rebuilt exactly from the page: the padded
+// region [0..y+w-1] x [0..x+w-1] is cut into (top|bottom) x (left|right); every page row is read once
+// (16 workgroups per pixel share the rows, dword loads + V_DOT4_U32_U8 for sum and sum of squares) and
+// weighted by how many padded rows/columns replicate it.  Integer arithmetic: exact.
+constexpr int kSplit = 16;
+struct CornerAcc {
+    unsigned long long a[8];  // [0..3] sums of P over top-left, top-right, bottom-left, bottom-right; [4..7] of P*P
+};
+
+// number of padded indices i in [lo, hi] that replicate-clamp to page index r (page size n, padding h)
+__device__ __forceinline__ int pad_count(int lo, int hi, int r, int n, int h)
+{
+    int a = r + h, b = r + h;          // i - h == r
+    if (r == 0) a = 0;                 // i < h clamps to 0
+    if (r == n - 1) b = 0x3fffffff;    // i > h + n - 1 clamps to n - 1
+    a = max(a, lo);
+    b = min(b, hi);
+    return b >= a ? b - a + 1 : 0;
+}
+
+// sum and sum of squares of page[row][ca..cb] (inclusive, ca <= cb) over the lanes of one wavefront
+__device__ __forceinline__ void row_range_sums(const uint8_t* row, int ca, int cb, int lane, unsigned* s_out,
+                                               unsigned* q_out)
+{
+    unsigned s = 0, q = 0;
+    const int nbytes = cb - ca + 1;
+    for (int t = lane * 4; t < nbytes; t += kWave * 4) {
+        unsigned v;
+        if (t + 4 <= nbytes) {
+            __builtin_memcpy(&v, row + ca + t, 4);
+        } else {
+            v = 0;
+            for (int k = 0; t + k < nbytes; ++k) v |= (unsigned)row[ca + t + k] << (8 * k);
+        }
+        s = __builtin_amdgcn_udot4(v, 0x01010101u, s, false);
+        q = __builtin_amdgcn_udot4(v, v, q, false);
+    }
+    *s_out = s;
+    *q_out = q;
+}
+
+__global__ void __launch_bounds__(256) k_corner_partial(PageSet src, FusedParams fp, const WorkItem* __restrict__ items,
+                                                       const unsigned* __restrict__ counters, int which,
+                                                       CornerAcc* __restrict__ acc)
 {
     const ThrParams& tp = fp.tp;
-    const unsigned n = min(counters[1], fp.wl_cap);
-    __shared__ unsigned long long red[4][8];
+    const unsigned n = min(counters[which], fp.wl_cap);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-    for (unsigned it = blockIdx.x; it < n; it += gridDim.x) {
-        const WorkItem wi = wl[it];
+    const int W = tp.width, H = tp.height, h = tp.half;
+    for (unsigned it = blockIdx.y; it < n; it += gridDim.y) {
+        const WorkItem wi = items[it];
         const uint8_t* img = src.page(wi.page);
         const int Y0 = wi.y, X0 = wi.x, Y1 = wi.y + tp.w - 1, X1 = wi.x + tp.w - 1;
-        // acc[0..3] = sums of P over (top|bottom) x (left|right); acc[4..7] same for P*P
-        unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = wv; i <= Y1; i += 4) {
-            const uint8_t* row = img + (size_t)clampi(i - tp.half, 0, tp.height - 1) * src.step;
-            unsigned sl = 0, sr = 0, ql = 0, qr = 0;
-            for (int j = lane; j <= X1; j += kWave) {
-                const unsigned v = row[clampi(j - tp.half, 0, tp.width - 1)];
-                if (j <= X0) {
-                    sl += v;
-                    ql += v * v;
-                } else {
-                    sr += v;
-                    qr += v * v;
-                }
+        // page rows that appear in padded rows [0..Y1], split over the kSplit workgroups of this pixel
+        const int r_last = clampi(Y1 - h, 0, H - 1);
+        const int per = (r_last + 1 + kSplit - 1) / kSplit;
+        const int r_begin = blockIdx.x * per, r_end = min(r_begin + per, r_last + 1);
+        // page columns of the left part [0..X0] and the right part [X0+1..X1] (interior + replicated edges)
+        const int lca = 0, lcb = clampi(X0 - h, 0, W - 1);
+        const int rca = clampi(X0 + 1 - h, 0, W - 1), rcb = clampi(X1 - h, 0, W - 1);
+        // multiplicities of the two edge columns inside each part (interior columns count once)
+        const int l_m0 = pad_count(0, X0, 0, W, h), l_mW = pad_count(0, X0, W - 1, W, h);
+        const int r_m0 = pad_count(X0 + 1, X1, 0, W, h), r_mW = pad_count(X0 + 1, X1, W - 1, W, h);
+        unsigned long long a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = r_begin + wv; r < r_end; r += 4) {
+            const uint8_t* row = img + (size_t)r * src.step;
+            unsigned sl, ql, sr, qr;
+            row_range_sums(row, lca, lcb, lane, &sl, &ql);
+            row_range_sums(row, rca, rcb, lane, &sr, &qr);
+            if (lane == 0) {  // replicated edge columns: add the missing (multiplicity - 1) copies
+                const unsigned e0 = row[0], eW = row[W - 1];
+                // a part contains page column 0 (resp. W-1) once through its range iff its multiplicity > 0
+                if (l_m0 > 0) { sl += (unsigned)(l_m0 - 1) * e0; ql += (unsigned)(l_m0 - 1) * e0 * e0; }
+                if (l_mW > 0 && lcb == W - 1) { sl += (unsigned)(l_mW - 1) * eW; ql += (unsigned)(l_mW - 1) * eW * eW; }
+                if (r_m0 > 0 && rca == 0) { sr += (unsigned)(r_m0 - 1) * e0; qr += (unsigned)(r_m0 - 1) * e0 * e0; }
+                if (r_mW > 0) { sr += (unsigned)(r_mW - 1) * eW; qr += (unsigned)(r_mW - 1) * eW * eW; }
             }
-            const int o = (i <= Y0) ? 0 : 2;
-            acc[o] += sl;
-            acc[o + 1] += sr;
-            acc[4 + o] += ql;
-            acc[4 + o + 1] += qr;
+            const unsigned long long ct = (unsigned long long)pad_count(0, Y0, r, H, h);
+            const unsigned long long cb2 = (unsigned long long)pad_count(Y0 + 1, Y1, r, H, h);
+            a[0] += ct * sl;  a[1] += ct * sr;  a[2] += cb2 * sl;  a[3] += cb2 * sr;
+            a[4] += ct * ql;  a[5] += ct * qr;  a[6] += cb2 * ql;  a[7] += cb2 * qr;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            unsigned long long v = acc[k];
+            unsigned long long v = a[k];
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
-            if (lane == 0) red[wv][k] = v;
+            if (lane == 0 && v != 0) atomicAdd(&acc[it].a[k], v);
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long t[8];
-            for (int k = 0; k < 8; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-            const double A = (double)t[0], B = (double)(t[0] + t[1]), C = (double)(t[0] + t[2]),
-                         D = (double)(t[0] + t[1] + t[2] + t[3]);
-            const double AQ = (double)t[4], BQ = (double)(t[4] + t[5]), CQ = (double)(t[4] + t[6]),
-                         DQ = (double)(t[4] + t[5] + t[6] + t[7]);
-            const double m = box4_literal(A, B, C, D, tp.f);
-            const double q = box4_literal(AQ, BQ, CQ, DQ, tp.f);
-            const double s = dev_from(m, q);
-            const PageGlobals& pg = g[wi.page];
-            const double T = threshold_literal(tp, m, s, (double)pg.imin, pg.coeff);
-            const unsigned p = img[(size_t)wi.y * src.step + wi.x];
-            dst.page(wi.page)[(size_t)wi.y * dst.step + wi.x] = decide_literal(p, T);
+    }
+}
+
+__device__ __forceinline__ void literal_mq(const CornerAcc& c, double f, double* m, double* q)
+{
+    const unsigned long long* t = c.a;
+    const double A = (double)t[0], B = (double)(t[0] + t[1]), C = (double)(t[0] + t[2]),
+                 D = (double)(t[0] + t[1] + t[2] + t[3]);
+    const double AQ = (double)t[4], BQ = (double)(t[4] + t[5]), CQ = (double)(t[4] + t[6]),
+                 DQ = (double)(t[4] + t[5] + t[6] + t[7]);
+    *m = box4_literal(A, B, C, D, f);
+    *q = box4_literal(AQ, BQ, CQ, DQ, f);
+}
+
+// ---- fix-up: literal evaluation of the queued pixels (prl_device_math.h) from their absolute corners ----
+__global__ void __launch_bounds__(256) k_fixup_final(PageSet src, PageSetOut dst, FusedParams fp,
+                                                    const PageGlobals* __restrict__ g,
+                                                    const WorkItem* __restrict__ wl, const CornerAcc* __restrict__ acc,
+                                                    const unsigned* __restrict__ counters)
+{
+    const ThrParams& tp = fp.tp;
+    const unsigned n = min(counters[1], fp.wl_cap);
+    for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < n; it += gridDim.x * blockDim.x) {
+        const WorkItem wi = wl[it];
+        double m, q;
+        literal_mq(acc[it], tp.f, &m, &q);
+        const double s = dev_from(m, q);
+        const PageGlobals& pg = g[wi.page];
+        const double T = threshold_literal(tp, m, s, (double)pg.imin, pg.coeff);
+        const unsigned p = src.page(wi.page)[(size_t)wi.y * src.step + wi.x];
+        dst.page(wi.page)[(size_t)wi.y * dst.step + wi.x] = decide_literal(p, T);
+    }
+}
+
+// Wolf-Jolion: literal deviation of every candidate of sweep B; their maximum is exactly
+// cv::minMaxLoc(localDevianceValues)'s devianceMax (binarizeWolfJolion.cpp:118-119).
+__global__ void __launch_bounds__(256) k_wolf_final(FusedParams fp, PageGlobals* __restrict__ g,
+                                                   const WorkItem* __restrict__ cand, const CornerAcc* __restrict__ acc,
+                                                   const unsigned* __restrict__ counters)
+{
+    const unsigned n = min(counters[2], fp.wl_cap);
+    for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < n; it += gridDim.x * blockDim.x) {
+        double m, q;
+        literal_mq(acc[it], fp.tp.f, &m, &q);
+        const double s = dev_from(m, q);
+        if (s == s) {  // NaN never wins minMaxLoc
+            atomicMax(&g[cand[it].page].smax_bits, (unsigned long long)__double_as_longlong(s) & 0x7fffffffffffffffull);
+            atomicOr(&g[cand[it].page].smax_found, 1);
         }
-        __syncthreads();
     }
 }
 
 template <int METHOD>
-int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst,
-                 const FusedParams& fp, PageGlobals* g, RefItem* rl, WorkItem* wl, unsigned* cnt,
-                 hipEvent_t ev_start, hipEvent_t ev_stop)
+int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
+                 PageGlobals* g, RefItem* rl, WorkItem* cand, unsigned* cnt)
 {
-    if (ev_start) PRL_HIP_CHECK(hipEventRecord(ev_start, stream));
     const bool ring = fp.ring_rows > 0;
     const unsigned wpb = ring ? 2u : 4u;
     unsigned blocks = (fp.total_waves + wpb - 1) / wpb;
     blocks = (blocks + 7) / 8 * 8;
     const dim3 grid(blocks), block(64 * wpb);
     const size_t lds = ring ? (size_t)wpb * ((size_t)fp.ring_rows * SW + 32) : 0;
-#define PRL_LAUNCH_FUSED(SHV)                                                                              \
-    do {                                                                                                   \
-        if (ring)                                                                                          \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, true>), grid, block, lds, stream, src, dst, fp, g, rl, cnt);  \
-        else                                                                                               \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, false>), grid, block, 0, stream, src, dst, fp, g, rl, cnt);   \
+#define PRL_LAUNCH_FUSED(SHV)                                                                                    \
+    do {                                                                                                         \
+        if (ring)                                                                                                \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, true>), grid, block, lds, stream, src, dst, fp, g, rl, cand, cnt);  \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, false>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);   \
     } while (0)
     switch (sh) {
     case 0: PRL_LAUNCH_FUSED(0); break;
@@ -555,10 +731,24 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     }
 #undef PRL_LAUNCH_FUSED
     PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
+template <int METHOD>
+int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
+                 PageGlobals* g, RefItem* rl, WorkItem* wl, WorkItem* cand, CornerAcc* acc, unsigned* cnt,
+                 hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    if (ev_start) PRL_HIP_CHECK(hipEventRecord(ev_start, stream));
+    int st = launch_sweep<METHOD>(sh, stream, src, dst, fp, g, rl, cand, cnt);
+    if (st != PRL_OK) return st;
     if (ev_stop) PRL_HIP_CHECK(hipEventRecord(ev_stop, stream));
     hipLaunchKernelGGL((k_refine<METHOD>), dim3(64), dim3(256), 0, stream, dst, fp, g, rl, wl, cnt);
     PRL_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL((k_fixup<METHOD>), dim3(512), dim3(256), 0, stream, src, dst, fp, g, wl, cnt);
+    PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, stream));
+    hipLaunchKernelGGL(k_corner_partial, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc);
+    PRL_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_fixup_final, dim3(16), dim3(256), 0, stream, src, dst, fp, g, wl, acc, cnt);
     PRL_HIP_CHECK(hipGetLastError());
     return PRL_OK;
 }
@@ -579,6 +769,8 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
 //   eps1     : 2 (E1 + Elit) + 1e-6.
 struct FusedBounds {
     double Em, Eq, vthr, E1, Elit, eps1, kappa;
+    double Ev, Es;   // worst-case literal noise of v and (for v* >= vthr) of s
+    double rho;      // relative error bound of the float32 variance v~
 };
 
 static FusedBounds fused_bounds(const ThrParams& tp)
@@ -594,6 +786,9 @@ static FusedBounds fused_bounds(const ThrParams& tp)
     b.vthr = std::fmax(1e-2, 64.0 * Ev);
     const double Es = 1.01 * Ev / std::sqrt(b.vthr - Ev);
     b.kappa = (4.0 + 3.5 * R) * u * 1.1;
+    b.Ev = Ev;
+    b.Es = Es;
+    b.rho = (4.0 + 7.0 * R) * u * 1.1;  // |v~ - v*| <= (4 u v* + 7 u m*^2) <= rho v*
     const double k = std::fabs(tp.k);
     switch (tp.method) {
     case PRL_SAUVOLA: {
@@ -612,6 +807,12 @@ static FusedBounds fused_bounds(const ThrParams& tp)
         b.Elit = b.Em + k * Ec;
         break;
     }
+    case PRL_WOLFJOLION:
+        // T = m + (s c - k)(m - Imin), |c| s <= |k| (1 + tiny) because s <= max(s); the part of Elit that
+        // scales with |c| = |k / devianceMax| is added per page in the kernel (FusedParams::es_max).
+        b.E1 = M * k * (b.kappa + 8 * u) + 3 * u * M + u * (512 + M * k);
+        b.Elit = (2.0 + 2.0 * k) * b.Em;
+        break;
     case PRL_FENG: {
         const double gcoef = std::fabs(1.0 + tp.c1), c3 = 255.0 * (std::fabs(tp.k2) + 1.0);
         b.E1 = gcoef * M * 3 * u + c3 * u + u * (256 + gcoef * M + c3);
@@ -650,7 +851,6 @@ extern "C" int prl_hip_internal_fused_bounds(const prl_binarize_params* p, int w
 
 bool fused_supports(const ThrParams& tp)
 {
-    if (tp.method == PRL_WOLFJOLION) return false;           // two-pass; literal pipeline for now
     if (((tp.w - 1) & 1) != 0) return false;                 // even (clamped) window: rare, literal
     if (tp.w - 1 > 256 || tp.w < 3) return false;            // window sums must stay exact in float32/u32
     if (tp.width < 16) return false;                         // the 8-byte row fetch needs a row to clamp into
@@ -661,9 +861,13 @@ bool fused_supports(const ThrParams& tp)
     return true;
 }
 
+constexpr size_t kSegmaxCap = 1u << 20;  // wavefronts per call whose sweep-A maxima can be kept (Wolf)
+
 size_t fused_small_bytes(int)
 {
-    return 256 + sizeof(RefItem) * (size_t)kRefineCap + sizeof(WorkItem) * (size_t)kWorkCap;
+    // [counters 256 B][refine list][fix-up list][Wolf candidate list][corner sums][Wolf per-wavefront maxima]
+    return 256 + sizeof(RefItem) * (size_t)kRefineCap + 2 * sizeof(WorkItem) * (size_t)kWorkCap +
+           sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(float) * kSegmaxCap;
 }
 
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst, void* small,
@@ -699,15 +903,23 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     case PRL_NIBLACK: fp.c0 = (float)tp.k; fp.need_p0 = !(tp.k >= 0.0); break;
     case PRL_NICK: fp.c0 = (float)tp.k; fp.need_p0 = !(tp.k >= 0.0); break;
     case PRL_FENG: fp.c0 = (float)(1.0 + tp.c1); fp.need_p0 = 1; break;
+    case PRL_WOLFJOLION: fp.c0 = (float)tp.k; fp.need_p0 = 1; break;
     default: return PRL_ERR_BAD_ARG;
     }
+    fp.es_max = (float)(b.Es * 1.01);
+    fp.rho = (float)(b.rho * 1.01);
+    fp.ev2 = (float)(2.0 * b.Ev * 1.01);
 
-    auto* cnt = static_cast<unsigned*>(small);  // [0] refine-list length, [1] fix-up-list length
+    // [0] refine-list length, [1] fix-up-list length, [2] Wolf candidate-list length
+    auto* cnt = static_cast<unsigned*>(small);
     auto* rl = reinterpret_cast<RefItem*>(static_cast<uint8_t*>(small) + 256);
     auto* wl = reinterpret_cast<WorkItem*>(static_cast<uint8_t*>(small) + 256 + sizeof(RefItem) * (size_t)kRefineCap);
+    auto* cand = wl + kWorkCap;
+    auto* acc = reinterpret_cast<CornerAcc*>(cand + kWorkCap);
+    fp.segmax = reinterpret_cast<float*>(acc + kWorkCap);
     PRL_HIP_CHECK(hipMemsetAsync(cnt, 0, 256, stream));
 
-    if (tp.method == PRL_FENG) {
+    if (tp.method == PRL_FENG || tp.method == PRL_WOLFJOLION) {
         int st = page_min_run(tp, src, n_pages, d_globals, stream);
         if (st != PRL_OK) return st;
     }
@@ -718,11 +930,29 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     const char* ring_env = std::getenv("PRL_HIP_RING");
     fp.ring_rows = ((size_t)(tp.w - 1) * SW <= 16384 && ring_env && ring_env[0] == '1') ? tp.w - 1 : 0;
     const int sh = (tp.w - 1) & 7;
+    if (tp.method == PRL_WOLFJOLION) {
+        // devianceMax first (binarizeWolfJolion.cpp:118-121): sweep A finds the float32 variance maximum,
+        // sweep B revisits only the wavefront segments that can hold the literal maximum and queues their
+        // candidate pixels, k_wolf_exact evaluates those literally, k_wolf_coeff forms k / devianceMax.
+        if (fp.total_waves > kSegmaxCap) return PRL_ERR_BAD_ARG;
+        int st = launch_sweep<kWolfMax>(sh, stream, src, dst, fp, d_globals, rl, cand, cnt);
+        if (st != PRL_OK) return st;
+        st = launch_sweep<kWolfCollect>(sh, stream, src, dst, fp, d_globals, rl, cand, cnt);
+        if (st != PRL_OK) return st;
+        PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, stream));
+        hipLaunchKernelGGL(k_corner_partial, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, cand, cnt, 2, acc);
+        PRL_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(k_wolf_final, dim3(16), dim3(256), 0, stream, fp, d_globals, cand, acc, cnt);
+        PRL_HIP_CHECK(hipGetLastError());
+        st = wolf_coeff_run(tp, d_globals, 0, n_pages, stream);
+        if (st != PRL_OK) return st;
+        return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop);
+    }
     switch (tp.method) {
-    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
-    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
-    case PRL_NICK: return launch_fused<PRL_NICK>(sh, stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
-    case PRL_FENG: return launch_fused<PRL_FENG>(sh, stream, src, dst, fp, d_globals, rl, wl, cnt, ev_start, ev_stop);
+    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop);
+    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop);
+    case PRL_NICK: return launch_fused<PRL_NICK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop);
+    case PRL_FENG: return launch_fused<PRL_FENG>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop);
     default: return PRL_ERR_BAD_ARG;
     }
 }

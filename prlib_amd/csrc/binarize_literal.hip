@@ -46,30 +46,46 @@ __global__ void k_init_globals(PageGlobals* g, int n)
         g[i].n_refined = 0;
         g[i].n_exact = 0;
         g[i].worklist_overflow = 0;
-        g[i].reserved = 0;
+        g[i].v32max_bits = 0;
     }
 }
 
 // Page minimum (cv::minMaxLoc(imageInput, &imageMin), binarizeWolfJolion.cpp:115-116).  The padded
-// image has the same minimum as the page, so the page itself is reduced.
+// image has the same minimum as the page, so the page itself is reduced.  One wavefront per row chunk,
+// 16 B per lane per load (rows are walked with their own alignment; head/tail bytes one by one).
+__device__ __forceinline__ unsigned min4(unsigned mn, unsigned w)
+{
+    mn = min(mn, w & 0xffu);
+    mn = min(mn, (w >> 8) & 0xffu);
+    mn = min(mn, (w >> 16) & 0xffu);
+    return min(mn, w >> 24);
+}
+
 __global__ void __launch_bounds__(256) k_page_min(PageSet src, int width, int height, PageGlobals* g)
 {
     const int page = blockIdx.y;
     const uint8_t* img = src.page(page);
     unsigned mn = 255;
-    const long long total = (long long)width * height;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(i / width), x = (int)(i - (long long)y * width);
-        const unsigned v = img[(size_t)y * src.step + x];
-        mn = v < mn ? v : mn;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave, n_waves = gridDim.x * blockDim.x / kWave;
+    for (int y = wave; y < height; y += n_waves) {
+        const uint8_t* row = img + (size_t)y * src.step;
+        const int head = (int)((16 - ((size_t)row & 15)) & 15);
+        const int nvec = (width - min(head, width)) / 16;
+        for (int x = lane; x < min(head, width); x += kWave) mn = min(mn, (unsigned)row[x]);
+        const uint4* v = reinterpret_cast<const uint4*>(row + head);
+        for (int i = lane; i < nvec; i += kWave) {
+            const uint4 q = v[i];
+            mn = min4(min4(min4(min4(mn, q.x), q.y), q.z), q.w);
+        }
+        for (int x = head + nvec * 16 + lane; x < width; x += kWave) mn = min(mn, (unsigned)row[x]);
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         const unsigned o = __shfl_xor(mn, d, kWave);
         mn = o < mn ? o : mn;
     }
-    if ((threadIdx.x & (kWave - 1)) == 0) atomicMin(&g[page].imin, (int)mn);
+    if (lane == 0) atomicMin(&g[page].imin, (int)mn);
 }
 
 // Row half of cv::integral over the replicate-padded page.  One wavefront per padded row; each lane
@@ -217,6 +233,14 @@ __global__ void __launch_bounds__(256) k_threshold(PageSet src, ThrParams tp, in
 
 }  // namespace
 
+int wolf_coeff_run(const ThrParams& tp, PageGlobals* d_globals, int first_page, int n_pages, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_wolf_coeff, dim3((n_pages + 63) / 64), dim3(64), 0, stream, tp, d_globals, first_page,
+                       n_pages);
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
 size_t literal_scratch_per_page(const ThrParams& tp)
 {
     return 2 * sizeof(double) * (size_t)tp.pw * (size_t)tp.ph;
@@ -233,9 +257,8 @@ int init_globals_run(PageGlobals* d_globals, int n_pages, hipStream_t stream)
 int page_min_run(const ThrParams& tp, const PageSet& src, int n_pages, PageGlobals* d_globals,
                  hipStream_t stream)
 {
-    const long long total = (long long)tp.width * tp.height;
-    int blocks = (int)((total + 256 * 16 - 1) / (256 * 16));
-    if (blocks > 512) blocks = 512;
+    int blocks = (tp.height + 15) / 16;  // 4 wavefronts per block, ~4 rows each
+    if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_page_min, dim3(blocks, n_pages), dim3(256), 0, stream, src, tp.width,
                        tp.height, d_globals);

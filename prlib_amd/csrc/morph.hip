@@ -108,11 +108,165 @@ __global__ void __launch_bounds__(256) k_morph(PageSet src, PageSetOut dst, int 
     }
 }
 
+
+// ---- binary masks: 4 pixels per operation ------------------------------------------------------------
+// The binarizers only ever emit 0 / 255, and for such bytes max == bitwise OR and min == bitwise AND, so a
+// dword carries 4 pixels through every step.  The horizontal pass ORs/ANDs 2n+1 dwords read from LDS at
+// consecutive BYTE offsets (unaligned ds_read_b32), the vertical pass 2n+1 row-aligned dwords.
+constexpr int BND = 64;   // staged dwords per row = one wavefront; output tile width = 256 - 2*halo pixels
+constexpr int BTH = 32;   // output tile height
+
+template <bool IS_OR> __device__ __forceinline__ unsigned comb(unsigned a, unsigned b) { return IS_OR ? (a | b) : (a & b); }
+
+// One wavefront per row, lane = dword.  Horizontal rectangle: dwords 2..61 (the outer two dwords on each
+// side are halo that is never consumed).
+template <bool IS_OR>
+__device__ __forceinline__ void brow_pass(const unsigned char* src, unsigned char* dst, int pitch, int r_begin, int r_end,
+                                          int n, int lane, int wv)
+{
+    if (lane < 2 || lane >= BND - 2) return;
+    for (int r = r_begin + wv; r < r_end; r += 4) {
+        // five ALIGNED dwords around this lane's pixels; the 2n shifted views are funnel shifts of them
+        // (unaligned ds_read is legal on gfx950 but measured several times slower than this)
+        const unsigned* p = reinterpret_cast<const unsigned*>(src + r * pitch + 4 * lane);
+        const unsigned p2 = p[-2], p1 = p[-1], c0 = p[0], n1 = p[1], n2 = p[2];
+        const unsigned long long R = ((unsigned long long)n1 << 32) | c0, R2 = ((unsigned long long)n2 << 32) | n1;
+        const unsigned long long L = ((unsigned long long)c0 << 32) | p1, L2 = ((unsigned long long)p1 << 32) | p2;
+        unsigned v = c0;
+        for (int k = 1; k <= n; ++k) {
+            const unsigned right = k <= 4 ? (unsigned)(R >> (8 * k)) : (unsigned)(R2 >> (8 * (k - 4)));
+            const unsigned left = k <= 4 ? (unsigned)(L >> (32 - 8 * k)) : (unsigned)(L2 >> (32 - 8 * (k - 4)));
+            v = comb<IS_OR>(v, comb<IS_OR>(left, right));
+        }
+        *reinterpret_cast<unsigned*>(dst + r * pitch + 4 * lane) = v;
+    }
+}
+
+// Vertical rectangle: output rows r_begin..r_end-1, each from source rows r-n..r+n.
+template <bool IS_OR>
+__device__ __forceinline__ void bcol_pass(const unsigned char* src, unsigned char* dst, int pitch, int r_begin, int r_end,
+                                          int n, int lane, int wv)
+{
+    for (int r = r_begin + wv; r < r_end; r += 4) {
+        const unsigned char* p = src + (r - n) * pitch + 4 * lane;
+        unsigned v = *reinterpret_cast<const unsigned*>(p);
+        for (int k = 1; k <= 2 * n; ++k) v = comb<IS_OR>(v, *reinterpret_cast<const unsigned*>(p + k * pitch));
+        *reinterpret_cast<unsigned*>(dst + r * pitch + 4 * lane) = v;
+    }
+}
+
+template <bool FIRST_OR>
+__global__ void __launch_bounds__(256) k_morph_binary(PageSet src, PageSetOut dst, int width, int height, int n, int btw)
+{
+    constexpr int PITCH = BND * 4 + 16;             // bytes per staged row (+16: bank spread)
+    constexpr int MAXROWS = BTH + 4 * kMaxN;        // 64
+    __shared__ __attribute__((aligned(16))) unsigned char bufA[MAXROWS * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char bufB[MAXROWS * PITCH];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int page = blockIdx.z;
+    const uint8_t* in = src.page(page);
+    uint8_t* out = dst.page(page);
+    const int h4 = (BND * 4 - btw) / 2;             // horizontal halo in pixels: >= 2n + 8, multiple of 4
+    const int x0 = blockIdx.x * btw, y0 = blockIdx.y * BTH;
+    const int rows = BTH + 4 * n;                   // staged rows: y0 - 2n .. y0 + BTH + 2n - 1
+    const unsigned neutral1 = FIRST_OR ? 0u : 0xffffffffu, neutral2 = ~neutral1;
+
+    // stage: dword loads where the dword lies inside the page row, bytes (or the neutral value) elsewhere
+    const bool aligned_src = (((size_t)in | src.step) & 3) == 0;
+    const int gx = x0 - h4 + 4 * lane;
+    for (int r = wv; r < rows; r += 4) {
+        const int gy = y0 - 2 * n + r;
+        unsigned v = neutral1;
+        if (gy >= 0 && gy < height) {
+            const uint8_t* row = in + (size_t)gy * src.step;
+            if (aligned_src && gx >= 0 && gx + 4 <= width) {
+                v = *reinterpret_cast<const unsigned*>(row + gx);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (gx + b >= 0 && gx + b < width)
+                        v = (v & ~(0xffu << (8 * b))) | ((unsigned)row[gx + b] << (8 * b));
+            }
+        }
+        *reinterpret_cast<unsigned*>(bufA + r * PITCH + 4 * lane) = v;
+    }
+    __syncthreads();
+
+    // first operator: rows (all staged rows), then columns (rows n .. rows-n-1)
+    brow_pass<FIRST_OR>(bufA, bufB, PITCH, 0, rows, n, lane, wv);
+    __syncthreads();
+    bcol_pass<FIRST_OR>(bufB, bufA, PITCH, n, rows - n, n, lane, wv);
+    __syncthreads();
+
+    // pixels outside the page do not exist for the second operator: make them neutral for it
+    const bool touches_border = (x0 - h4 < 0) || (x0 + btw + h4 > width) || (y0 - n < 0) || (y0 + BTH + n > height);
+    if (touches_border) {
+        for (int r = n + wv; r < rows - n; r += 4) {
+            const int gy = y0 - 2 * n + r;
+            unsigned* p = reinterpret_cast<unsigned*>(bufA + r * PITCH + 4 * lane);
+            if (gy < 0 || gy >= height) {
+                *p = neutral2;
+            } else if (gx < 0 || gx + 4 > width) {
+                unsigned v = *p;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (gx + b < 0 || gx + b >= width) v = (v & ~(0xffu << (8 * b))) | (neutral2 & (0xffu << (8 * b)));
+                *p = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    // second operator: rows n .. rows-n-1, then columns -> tile rows 2n .. 2n+BTH-1
+    brow_pass<!FIRST_OR>(bufA, bufB, PITCH, n, rows - n, n, lane, wv);
+    __syncthreads();
+    bcol_pass<!FIRST_OR>(bufB, bufA, PITCH, 2 * n, 2 * n + BTH, n, lane, wv);
+    __syncthreads();
+
+    const bool aligned_dst = (((size_t)out | dst.step) & 3) == 0;
+    const int ox = gx;  // this lane's pixels; inside the output tile iff h4 <= 4*lane < h4 + btw
+    if (4 * lane >= h4 && 4 * lane < h4 + btw && ox < width) {
+        for (int r = wv; r < BTH; r += 4) {
+            const int gy = y0 + r;
+            if (gy >= height) break;
+            const unsigned v = *reinterpret_cast<const unsigned*>(bufA + (2 * n + r) * PITCH + 4 * lane);
+            uint8_t* o = out + (size_t)gy * dst.step + ox;
+            if (aligned_dst && ox + 4 <= width) {
+                *reinterpret_cast<unsigned*>(o) = v;
+            } else {
+                for (int b = 0; b < 4 && ox + b < width; ++b) o[b] = (uint8_t)(v >> (8 * b));
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // The rectangle of n iterations equals n applications of the 3x3 one, and a closing/opening with
 // radius n cannot be split into smaller closings — so radii above kMaxN are rejected here and
 // handled by the caller (PRL_ERR_BAD_ARG); the reference's defaults are n in {0, 2}.
+// binary (0/255) masks: the pipeline's own threshold output
+int morph_binary_run(int iterations, const PageSet& src, int n_pages, int width, int height,
+                     const PageSetOut& dst, hipStream_t stream)
+{
+    const int n = iterations > 0 ? iterations : -iterations;
+    if (n == 0 || n > kMaxN) {
+        set_error_detail("morph_iterations out of range (1.." + std::to_string(kMaxN) + ")");
+        return PRL_ERR_BAD_ARG;
+    }
+    const int h4 = ((2 * n + 3) / 4) * 4 + 8;  // halo: the window (2n) rounded to dwords + 2 guard dwords
+    const int btw = BND * 4 - 2 * h4;          // output pixels per tile row (232 for n <= 2)
+    const dim3 grid((width + btw - 1) / btw, (height + BTH - 1) / BTH, n_pages);
+    if (iterations > 0)
+        hipLaunchKernelGGL(k_morph_binary<true>, grid, dim3(256), 0, stream, src, dst, width, height, n, btw);
+    else
+        hipLaunchKernelGGL(k_morph_binary<false>, grid, dim3(256), 0, stream, src, dst, width, height, n, btw);
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
+// any 8-bit image (max / min): the public prl_hip_morph_batch_device entry
 int morph_run(int iterations, const PageSet& src, int n_pages, int width, int height,
               const PageSetOut& dst, hipStream_t stream)
 {

@@ -55,11 +55,17 @@ struct Nb {  // the 7-pixel horizontal neighbourhood of one position: 7*CH bytes
     unsigned d[NB];
 };
 
+// Neighbourhood at an arbitrary byte address: NB+1 ALIGNED dword reads + byte funnel shifts.  (Unaligned
+// wide ds_read is legal on gfx950 but measured several times slower than this in k_morph_binary.)
 template <int CH>
-__device__ __forceinline__ Nb<CH> lds_nb(const unsigned char* p)
+__device__ __forceinline__ Nb<CH> lds_nb(const unsigned* base, unsigned sh)
 {
     Nb<CH> v;
-    __builtin_memcpy(v.d, p, sizeof(unsigned) * Nb<CH>::NB);  // unaligned ds_read_b64 / b128
+    unsigned w[Nb<CH>::NB + 1];
+#pragma unroll
+    for (int k = 0; k <= Nb<CH>::NB; ++k) w[k] = base[k];
+#pragma unroll
+    for (int k = 0; k < Nb<CH>::NB; ++k) v.d[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
     return v;
 }
 
@@ -76,7 +82,7 @@ template <int CH>
 __global__ void __launch_bounds__(256) k_nlm(PageSet src, PageSetOut dst, NlmParams np)
 {
     constexpr int NB = Nb<CH>::NB;
-    constexpr int PITCH = (EXT_W * CH + 16 + 3) / 4 * 4;  // bytes per staged row (+16: wide reads may overrun)
+    constexpr int PITCH = (EXT_W * CH + 16 + 3) / 4 * 4;  // bytes per staged row (+16: the dword reads overrun the row)
     __shared__ __attribute__((aligned(16))) unsigned char tile[EXT_H * PITCH + 32];
     __shared__ int sb[SB_H * SB_W];
     __shared__ int lut_s[kLutMax + 1];
@@ -121,6 +127,8 @@ __global__ void __launch_bounds__(256) k_nlm(PageSet src, PageSetOut dst, NlmPar
     // starts at staged column lane + 10.
     const unsigned char* abase = tile + (oy0 + kSH) * PITCH + (lane + kSH) * CH;  // template row 0 of output row 0
     const int* sa_base = sb + (oy0 + kSH) * SB_W + (lane + kSH);
+    const unsigned ash = (unsigned)(abase - tile) & 3u;
+    const unsigned* aword = reinterpret_cast<const unsigned*>(abase - ash);
 
     // own-pixel template energies
     int SA[ROWS];
@@ -143,14 +151,16 @@ __global__ void __launch_bounds__(256) k_nlm(PageSet src, PageSetOut dst, NlmPar
     for (int o = 0; o < kS * kS; ++o) {
         const int dy = o / kS - kSH, dx = o - (o / kS) * kS - kSH;
         const unsigned char* bbase = abase + dy * PITCH + dx * CH;
+        const unsigned bsh = (unsigned)(bbase - tile) & 3u;
+        const unsigned* bword = reinterpret_cast<const unsigned*>(bbase - bsh);
         const int* sb_o = sa_base + dy * SB_W + dx;
         unsigned ring[kT];
         unsigned qring[4][CH];
         unsigned AB = 0;
 #pragma unroll
         for (int r = 0; r < ROWS + kT - 1; ++r) {
-            Nb<CH> a = lds_nb<CH>(abase + r * PITCH);
-            const Nb<CH> b = lds_nb<CH>(bbase + r * PITCH);
+            Nb<CH> a = lds_nb<CH>(aword + r * (PITCH / 4), ash);
+            const Nb<CH> b = lds_nb<CH>(bword + r * (PITCH / 4), bsh);
             a.d[NB - 1] &= kLastMask;
             const unsigned hd = dot_nb<CH>(a, b, 0u);
             AB += hd;

@@ -343,7 +343,7 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         msrc.base = thr_dst.base;
         msrc.page_stride = thr_dst.page_stride;
         msrc.step = thr_dst.step;
-        st = morph_run(morph, msrc, n_pages, g.out_w, g.out_h, dst, stream);
+        st = morph_binary_run(morph, msrc, n_pages, g.out_w, g.out_h, dst, stream);
         if (st != PRL_OK) return st;
     }
     PRL_HIP_CHECK(hipEventRecord(ctx->last_use, stream));

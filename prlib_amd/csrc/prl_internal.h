@@ -94,7 +94,7 @@ struct PageGlobals {
     unsigned int n_refined;         // pixels decided by the float64 interval test
     unsigned int n_exact;           // pixels sent to the absolute-integral fix-up
     unsigned int worklist_overflow; // fix-up list overflowed -> page must rerun literally
-    unsigned int reserved;
+    unsigned int v32max_bits;       // Wolf fused sweep A: float32 bits of the page's largest variance estimate
 };
 
 // ---- literal pipeline (binarize_literal.hip) ---------------------------------------------------
@@ -113,9 +113,12 @@ bool fused_supports(const ThrParams& tp);
 // ---- morphology (morph.hip) ------------------------------------------------------------------
 int morph_run(int iterations, const PageSet& src, int n_pages, int width, int height,
               const PageSetOut& dst, hipStream_t stream);
+int morph_binary_run(int iterations, const PageSet& src, int n_pages, int width, int height,
+                     const PageSetOut& dst, hipStream_t stream);
 
 // ---- page reductions (binarize_literal.hip) ---------------------------------------------------
 int page_min_run(const ThrParams& tp, const PageSet& src, int n_pages, PageGlobals* d_globals,
                  hipStream_t stream);
+int wolf_coeff_run(const ThrParams& tp, PageGlobals* d_globals, int first_page, int n_pages, hipStream_t stream);
 
 }  // namespace prl_hip

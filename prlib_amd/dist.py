@@ -1,0 +1,72 @@
+"""Page-level sharding across the GPUs of one node.
+
+Pages are independent calls in the reference (src/binarizations/binarizeSauvola.cpp:32-134 touches only its
+two Mats), so the multi-GPU path is a contiguous block split of the page list: one process per GPU, no
+data-path collective.  torch.distributed (RCCL on GPUs, gloo in the CPU tests) is used only for the
+barrier around the timed region and for the max-over-ranks of the elapsed time.
+"""
+from __future__ import annotations
+
+import os
+
+
+def page_range(n_pages: int, world: int, rank: int) -> range:
+    """Contiguous block of the page list owned by `rank` (sizes differ by at most one page)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    base, extra = divmod(n_pages, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend: str | None = None):
+    """Join the process group described by torchrun's environment (no-op for a single process)."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank, local_rank = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+    return world, rank, local_rank
+
+
+def barrier():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def finish():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()

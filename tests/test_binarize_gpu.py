@@ -217,3 +217,56 @@ def test_auto_mode_uses_the_fused_kernel(prl, oracle, cuda_device):
     pages = _pages((300, 600), ["doc", "doc"], seed=31)
     st = _check(prl, oracle, cuda_device, pages, SAUVOLA, 31, 0.34, 0)
     assert st.literal_pages == 0 and st.exact_pixels < 50
+
+
+def test_golden_fixtures_on_device(prl, cuda_device):
+    """The committed fixtures (inputs = the reference's own test images) through the HIP path."""
+    import glob
+    import os
+
+    import torch
+
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    n = 0
+    for path in sorted(glob.glob(os.path.join(gdir, "0*.npz"))):
+        z = np.load(path)
+        gray = torch.from_numpy(z["gray"]).to(cuda_device)
+        for key in z.files:
+            if not key.startswith("mask_"):
+                continue
+            _, m, w, k, mo = key.split("_")
+            shape = tuple(z["shape_" + key[5:]])
+            want = np.unpackbits(z[key], axis=1)[:, :shape[1]].astype(np.uint8) * 255
+            got = prl.binarize(gray, prl.make_params(int(m), int(w), float(k), int(mo))).cpu().numpy()
+            assert np.array_equal(got, want), (os.path.basename(path), key)
+            n += 1
+    assert n >= 60
+
+
+def test_wolf_runs_fused(prl, oracle, cuda_device):
+    pages = _pages((400, 700), ["doc", "doc", "noise"], seed=37)
+    st = _check(prl, oracle, cuda_device, pages, WOLFJOLION, 31, 0.3, 0)
+    assert st.literal_pages == 0
+    st = _check(prl, oracle, cuda_device, pages, WOLFJOLION, 101, 0.01, 2)   # header defaults
+    assert st.literal_pages == 0
+    # degenerate page (no deviation anywhere): every pixel is a maximum candidate -> literal pipeline
+    st = _check(prl, oracle, cuda_device, [np.zeros((700, 600), np.uint8)], WOLFJOLION, 15, 0.3, 0)
+    assert st.literal_pages == 1
+
+
+@pytest.mark.parametrize("n", [1, 2, -2, 5, 8, -8])
+def test_public_morph_entry_on_gray_and_binary(prl, oracle, cuda_device, n):
+    import torch
+
+    rng = np.random.default_rng(abs(n))
+    gray = rng.integers(0, 256, (77, 203), dtype=np.uint8)          # cv::dilate/erode semantics on any u8 image
+    got = prl.morph(torch.from_numpy(gray).to(cuda_device), n).cpu().numpy()
+    assert np.array_equal(got, oracle.morph(gray, n))
+
+
+@pytest.mark.parametrize("shape", [(33, 130), (64, 128), (200, 517), (31, 40)])
+@pytest.mark.parametrize("morph", [1, -1, 2, 4, -3, 8])
+def test_binary_morphology_tiles(prl, oracle, cuda_device, shape, morph):
+    # page sizes around the 128x32 tile of the binary kernel; window clamps when the page is small
+    pages = _pages(shape, ["binary", "doc"], seed=41)
+    _check(prl, oracle, cuda_device, pages, NIBLACK, 15, 0.3, morph)

@@ -81,3 +81,17 @@ def test_denoise_rejects_other_channel_counts(prl, cuda_device):
     with pytest.raises(_capi.PrlError) as e:
         prl.denoise(np.zeros((10, 10, 1), np.uint8))
     assert e.value.status == _capi.PRL_ERR_BAD_CHANNELS
+
+
+def test_golden_nlm_fixture_on_device(prl, cuda_device):
+    import os
+
+    import torch
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nlm_0050_crop.npz"))
+    lab = z["lab"]
+    dev_l = torch.from_numpy(np.ascontiguousarray(lab[:, :, 0])).to(cuda_device)
+    dev_ab = torch.from_numpy(np.ascontiguousarray(lab[:, :, 1:])).to(cuda_device)
+    assert np.array_equal(prl.nlm_planes(dev_l, 10.0).cpu().numpy(), z["l_h10"])
+    assert np.array_equal(prl.nlm_planes(dev_ab, 3.0).cpu().numpy(), z["ab_h3"])
+    assert np.array_equal(prl.denoise(torch.from_numpy(z["noisy"]).to(cuda_device), 10.0).cpu().numpy(), z["denoised_s10"])

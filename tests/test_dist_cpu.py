@@ -1,0 +1,77 @@
+"""The N>1 path on CPU: two gloo ranks shard a page list, each processes its block (the CPU oracle stands
+in for the device here — it is the checker, and this test is about the sharding/collective plumbing),
+and the union equals the single-process result byte for byte."""
+import hashlib
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def test_page_range_partitions_exactly():
+    from prlib_amd.dist import page_range
+
+    for n in (0, 1, 7, 256, 1024, 1000):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                seen += list(page_range(n, world, r))
+            assert seen == list(range(n))
+            sizes = [len(page_range(n, world, r)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        page_range(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_pages, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    from oracle import capi as oc
+    from prlib_amd import dist as pd, synth
+
+    w, r, _ = pd.init("gloo")
+    assert (w, r) == (world, rank)
+    p = oc.make_params(oc.SAUVOLA, 15, 0.34, 0)
+    mine = pd.page_range(n_pages, world, rank)
+    digest = hashlib.sha256()
+    for i in mine:
+        digest.update(oc.binarize(synth.page_numpy(40, 56, index=i), p).tobytes())
+    pd.barrier()
+    t = pd.max_over_ranks(float(rank + 1))
+    total = pd.sum_over_ranks(float(len(mine)))
+    assert t == float(world) and total == float(n_pages)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(f"{mine.start} {mine.stop} {digest.hexdigest()}")
+    pd.finish()
+    assert not dist.is_initialized()
+
+
+def test_two_gloo_ranks_equal_one_process(tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle import capi as oc
+    from prlib_amd import synth
+    from prlib_amd.dist import page_range
+
+    n_pages, world = 7, 2
+    mp.spawn(_worker, args=(world, _free_port(), n_pages, str(tmp_path)), nprocs=world, join=True)
+    p = oc.make_params(oc.SAUVOLA, 15, 0.34, 0)
+    for r in range(world):
+        start, stop, got = open(tmp_path / f"rank{r}.txt").read().split()
+        rng = page_range(n_pages, world, r)
+        assert (int(start), int(stop)) == (rng.start, rng.stop)
+        d = hashlib.sha256()
+        for i in rng:
+            d.update(oc.binarize(synth.page_numpy(40, 56, index=i), p).tobytes())
+        assert d.hexdigest() == got
