@@ -298,7 +298,13 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             vnew_n = load_win(y + 1 + w);  // next iteration's entering row (row index clamps at the page end)
             vold = *reinterpret_cast<const uint2*>(ring + (size_t)slot_old * SW + CPL * lane);
             // compared pixels: strip columns 8*lane + h-1 .. +7 of padded row y+h (unaligned LDS read)
-            __builtin_memcpy(&pv, ring + (size_t)slot_p * SW + CPL * lane + (h - 1), 8);
+            {   // aligned dwords + byte funnel (unaligned wide ds_read is several times slower)
+                const unsigned off = (unsigned)(CPL * lane + (h - 1));
+                const unsigned* q = reinterpret_cast<const unsigned*>(ring + (size_t)slot_p * SW + (off & ~3u));
+                const unsigned w0 = q[0], w1 = q[1], w2 = q[2];
+                pv.x = __builtin_amdgcn_alignbyte(w1, w0, off & 3u);
+                pv.y = __builtin_amdgcn_alignbyte(w2, w1, off & 3u);
+            }
         } else {
             if (!SWEEP) pv = gload8(img + (size_t)y * istep + ep.colc);
             vnew_n = load_win(y + 1 + w);
