@@ -1,0 +1,93 @@
+"""Host logic: the float32 decision margin E1 the fused kernel relies on (fused_bounds() in
+prlib_amd/csrc/binarize_fused.hip) really bounds the float32 evaluation error.
+
+The kernel's float32 sequence is emulated with numpy float32 (fma through float64, which is exact for
+24-bit operands up to one final rounding) on window sums of random real windows, and compared with the
+exact-arithmetic threshold computed in float64 from the same integers (error ~1e-13, negligible here)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+SAUVOLA, NIBLACK, WOLFJOLION, NICK, FENG = range(5)
+
+
+def _bounds(prl, method, w, k, size=4096):
+    from prlib_amd import _capi
+
+    L = _capi.lib()
+    L.prl_hip_internal_fused_bounds.argtypes = [C.POINTER(_capi.BinarizeParams), C.c_int, C.c_int, C.POINTER(C.c_double)]
+    out = (C.c_double * 8)()
+    p = prl.make_params(method, w, k, 0)
+    assert L.prl_hip_internal_fused_bounds(C.byref(p), size, size, out) == 0
+    return dict(Em=out[0], Eq=out[1], vthr=out[2], E1=out[3], Elit=out[4], eps1=out[5], kappa=out[6])
+
+
+def _window_sums(rng, w, n):
+    npx = (w - 1) ** 2
+    kinds = rng.integers(0, 4, n)
+    S = np.empty(n, np.int64)
+    Q = np.empty(n, np.int64)
+    for i, kind in enumerate(kinds):
+        if kind == 0:
+            px = rng.integers(0, 256, npx)
+        elif kind == 1:
+            px = np.clip(rng.normal(rng.integers(20, 240), rng.integers(1, 40), npx), 0, 255).round().astype(np.int64)
+        elif kind == 2:
+            px = np.where(rng.random(npx) < rng.random(), 255, 0)
+        else:
+            px = np.full(npx, rng.integers(1, 256))
+        S[i], Q[i] = px.sum(), (px * px).sum()
+    return S, Q
+
+
+def _f32_fma(a, b, c):
+    return (np.float64(a) * np.float64(b) + np.float64(c)).astype(np.float32)
+
+
+@pytest.mark.parametrize("method,w,k", [(SAUVOLA, 31, 0.34), (SAUVOLA, 15, 0.34), (SAUVOLA, 101, 0.01), (SAUVOLA, 31, -0.5),
+                                       (NIBLACK, 31, 0.01), (NIBLACK, 15, -0.2), (NICK, 21, -0.01), (NICK, 31, -0.1)])
+def test_float32_margin_bounds_the_evaluation_error(prl, method, w, k):
+    b = _bounds(prl, method, w, k)
+    rng = np.random.default_rng(w * 7 + method)
+    S, Q = _window_sums(rng, w, 4000)
+    f = 1.0 / float(w * w)
+    # exact-arithmetic reference (float64 on exact integers)
+    m, q = S * f, Q * f
+    v = q - m * m
+    keep = v > b["vthr"] * 1.05
+    s = np.sqrt(np.where(keep, v, 1.0))
+    if method == SAUVOLA:
+        T = m * (s * (k / 128.0) + (1.0 - k))
+    elif method == NIBLACK:
+        T = s * k + m
+    else:
+        T = m + k * np.sqrt(q)
+    # the kernel's float32 sequence (eval32)
+    ff = np.float32(f)
+    m32 = S.astype(np.float32) * ff
+    q32 = Q.astype(np.float32) * ff
+    v32 = _f32_fma(-m32, m32, q32)
+    with np.errstate(invalid="ignore"):
+        s32 = np.sqrt(v32) * np.float32(1 + 2 ** -23)      # v_sqrt_f32 is 1 ulp, not correctly rounded
+        if method == SAUVOLA:
+            T32 = m32 * _f32_fma(s32, np.float32(k / 128.0), np.float32(1.0 - k))
+        elif method == NIBLACK:
+            T32 = _f32_fma(s32, np.float32(k), m32)
+        else:
+            T32 = _f32_fma(np.sqrt(q32) * np.float32(1 + 2 ** -23), np.float32(k), m32)
+    err = np.abs(T32.astype(np.float64) - T)[keep]
+    assert keep.sum() > 3000
+    assert err.max() <= b["E1"], (err.max(), b["E1"])
+    # the relative variance error is inside rho = 2 kappa-ish bound used by the Wolf sweeps
+    rel = np.abs(v32.astype(np.float64) - v)[keep] / v[keep]
+    R = (w - 1) ** 2 / (2.0 * w - 1.0)
+    assert rel.max() <= 1.1 * (4 + 7 * R) * 2.0 ** -24
+
+
+def test_margins_scale_with_page_and_stay_small(prl):
+    b4k = _bounds(prl, SAUVOLA, 31, 0.34, 4096)
+    b1k = _bounds(prl, SAUVOLA, 31, 0.34, 1024)
+    assert b1k["Em"] < b4k["Em"] and b1k["Eq"] < b4k["Eq"]
+    assert 1e-6 <= b4k["eps1"] < 5e-3          # the mask packing needs eps1 >= 1e-6; the band must stay narrow
+    assert b4k["vthr"] >= 64 * (b4k["Eq"] + 510 * b4k["Em"]) or b4k["vthr"] == 1e-2
