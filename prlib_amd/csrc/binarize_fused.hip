@@ -22,6 +22,7 @@
 // Memory: 1 B/px read + 1 B/px written to HBM (the algorithmic 2 B/px); window halos and the
 // "leaving" row of the sliding window are re-read from L2.  Bound: HBM; in practice VALU issue
 // (~30 lane-ops/px) is the co-limiter, see DESIGN.md.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -51,10 +52,13 @@ struct WorkItem {  // undecided after the float64 interval test
 constexpr int kWolfMax = 100;      // sweep A: float32 variance maximum per page and per wavefront
 constexpr int kWolfCollect = 101;  // sweep B: queue every pixel whose variance could be the literal maximum
 
+constexpr float kZ = 1073741824.0f;  // 2^30: every float32 threshold quantity is carried times Z (exact scaling)
+
 struct PageK {  // per-page constants of the float32 test
-    float c1;    // Feng: k2*Imin - Imin ; Wolf: k / devianceMax ; Wolf sweep B: candidate threshold on v~
-    float imin;  // Wolf: cv::minMaxLoc(imageInput) minimum
-    float eps1;  // decision margin (Wolf: page dependent through k / devianceMax)
+    float c1;    // Wolf: f * k / devianceMax ; Wolf sweep B: candidate threshold on K~
+    float imin;  // Wolf: Z * cv::minMaxLoc(imageInput) minimum
+    float p0;    // P2 = fma(p, Z, p0) = Z (p - 0.5) [Feng: minus Z (k2*Imin - Imin)]
+    float eps1;  // Z * decision margin (Wolf: page dependent through k / devianceMax)
 };
 
 struct FusedParams {
@@ -63,10 +67,10 @@ struct FusedParams {
     int n_strips, n_segs, rows_per_seg;
     int lane_off;      // (w-1) / 8
     unsigned total_waves;
-    float ff;          // (float)f
-    float c0, c1, c2;  // method constants in float32 (see decide32)
-    float eps1;        // float32 decision margin (covers float32 evaluation + literal rounding noise)
-    float vthr32;      // variance floor below which the float32 test is not trusted
+    float w2f;         // (float)(w*w), exact
+    float c0, c1, c2;  // method constants in float32, pre-multiplied by f and Z (see eval32)
+    float eps1;        // Z * float32 decision margin (covers float32 evaluation + literal rounding noise)
+    float vthr32;      // floor on K~ = w^2 Q - S^2 (= variance floor / f^2) below which the float32 test is not trusted
     double vthr;       // same floor for the float64 interval test
     double Em, Eq;     // |m_literal - f*S| <= Em, |q_literal - f*Q| <= Eq
     unsigned ref_cap, wl_cap;
@@ -100,39 +104,36 @@ __device__ __forceinline__ unsigned byte_of(uint2 v, int c)
     return (w >> (8 * (c & 3))) & 0xffu;
 }
 
-// ---- float32 evaluation: returns t = (p - 0.5) - T~ and the float32 variance v~ -----------------
-//   SAUVOLA  c0 = k/128, c1 = 1-k          T = m*(s*c0 + c1)
-//   NIBLACK  c0 = k                        T = s*c0 + m
-//   NICK     c0 = k                        T = m + c0*sqrt(q)            (m*m + s*s == q)
-//   FENG     c0 = 1 + (1-alpha1), c1 = k2*Imin - Imin (per page)   T = c0*m + c1   (s > 0)
+// ---- float32 evaluation: returns t2 = Z ((p - 0.5) - T~) and K~ = w^2 Q - S^2 (variance / f^2) ----------
+// With m = f S, v = f^2 K, s = f sqrt(K) every threshold is a polynomial in S and sqrt(K) (or sqrt(Q)); the
+// constants carry the powers of f and the scale Z = 2^30, so no multiply is spent on them (P2 = Z (p - 0.5)):
+//   SAUVOLA  c0 = Z a f^2, c1 = Z b f            T = S (c0 sqrtK + c1)            a = k/128, b = 1-k
+//   NIBLACK  c0 = Z k f,   c1 = Z f              T = c0 sqrtK + c1 S
+//   NICK     c0 = Z k sqrt(f), c1 = Z f          T = c0 sqrtQ + c1 S              (m*m + s*s == q)
+//   FENG     c0 = Z (1 + (1-alpha1)) f           T = c0 S + Z c3 (c3 folded into P2 per page)   (s > 0)
+//   WOLF     c0 = k, c1 = Z f, pk.c1 = f k/max(s), pk.imin = Z Imin
+//                                                T = c1 S + (pk.c1 sqrtK - c0)(c1 S - pk.imin)
 template <int METHOD>
-__device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsigned Q, float P, const PageK& pk,
-                                        float* v_out)
+__device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsigned Q, float P2, const PageK& pk,
+                                        float* k_out)
 {
-    const float Sf = (float)S, Qf = (float)Q;
-    const float m = Sf * fp.ff;
-    const float q = Qf * fp.ff;
-    const float v = fmaf(-m, m, q);
-    *v_out = v;
+    const float Sf = (float)S, Qf = (float)Q;      // S < 2^24: exact
+    const float K = fmaf(fp.w2f, Qf, -(Sf * Sf));
+    *k_out = K;
     if (METHOD == PRL_SAUVOLA) {
-        const float s = __builtin_amdgcn_sqrtf(v);
-        const float d = fmaf(s, fp.c0, fp.c1);
-        return fmaf(-m, d, P);
+        const float d = fmaf(__builtin_amdgcn_sqrtf(K), fp.c0, fp.c1);
+        return fmaf(-Sf, d, P2);
     } else if (METHOD == PRL_NIBLACK) {
-        const float s = __builtin_amdgcn_sqrtf(v);
-        return P - fmaf(s, fp.c0, m);
+        return fmaf(-Sf, fp.c1, fmaf(-__builtin_amdgcn_sqrtf(K), fp.c0, P2));
     } else if (METHOD == PRL_NICK) {
-        const float c = __builtin_amdgcn_sqrtf(q);
-        return P - fmaf(c, fp.c0, m);
+        return fmaf(-Sf, fp.c1, fmaf(-__builtin_amdgcn_sqrtf(Qf), fp.c0, P2));
     } else if (METHOD == PRL_WOLFJOLION) {
-        //   WOLF     c0 = k, pk.c1 = k/max(s), pk.imin         T = m + (s*c1 - k)*(m - Imin)
-        const float s = __builtin_amdgcn_sqrtf(v);
-        const float d = fmaf(s, pk.c1, -fp.c0);
-        const float e = m - pk.imin;
-        return P - fmaf(d, e, m);
+        const float d = fmaf(__builtin_amdgcn_sqrtf(K), pk.c1, -fp.c0);
+        const float e = fmaf(Sf, fp.c1, -pk.imin);
+        return P2 - fmaf(d, e, Sf * fp.c1);
     } else if (METHOD == PRL_FENG) {
-        return P - fmaf(m, fp.c0, pk.c1);
-    } else {  // Wolf sweeps: only v~ is used
+        return fmaf(-Sf, fp.c0, P2);
+    } else {  // Wolf sweeps: only K~ is used
         return 0.0f;
     }
 }
@@ -377,19 +378,18 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             }
         } else {
             // float32 decision; tmin/vmin track the smallest margin / variance of the lane's 8 pixels.
-            // Mask bytes: every settled pixel has |t| > eps1 >= 1e-6, so t * 2^30 saturates the float->u8
+            // Mask bytes: every settled pixel has |t| > eps1 >= 1e-6, so t2 = Z t saturates the float->u8
             // conversion to 255 (white, t > 0) or 0; unsettled pixels are overwritten by k_refine/k_fixup.
             unsigned lo = 0, hi = 0;
             float tmin = 3.0e38f, vmin = 3.0e38f;
     #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const unsigned p = byte_of(pv, c);
-                const float P = (float)p - 0.5f;
+                const float P2 = fmaf((float)p, kZ, pk.p0);
                 float v32;
-                const float t = eval32<METHOD>(fp, Ssum[c], Qsum[c], P, pk, &v32);
-                tmin = fminf(tmin, fabsf(t));
+                const float ts = eval32<METHOD>(fp, Ssum[c], Qsum[c], P2, pk, &v32);
+                tmin = fminf(tmin, fabsf(ts));
                 vmin = fminf(vmin, v32);
-                const float ts = t * 1073741824.0f;
                 if (c < 4) lo = __builtin_amdgcn_cvt_pk_u8_f32(ts, c, lo);
                 else hi = __builtin_amdgcn_cvt_pk_u8_f32(ts, c - 4, hi);
             }
@@ -415,7 +415,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                         const unsigned Q = c == 0 ? Qsum[0] : c == 1 ? Qsum[1] : c == 2 ? Qsum[2] : c == 3 ? Qsum[3]
                                          : c == 4 ? Qsum[4] : c == 5 ? Qsum[5] : c == 6 ? Qsum[6] : Qsum[7];
                         float v32;
-                        const float t = eval32<METHOD>(fp, S, Q, (float)p - 0.5f, pk, &v32);
+                        const float t = eval32<METHOD>(fp, S, Q, fmaf((float)p, kZ, pk.p0), pk, &v32);
                         if ((fabsf(t) > pk.eps1) && (v32 > fp.vthr32)) continue;
                         const unsigned idx = atomicAdd(&counters[0], 1u);
                         if (idx < fp.ref_cap) {
@@ -502,20 +502,21 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     PageK pk;
     pk.c1 = fp.c1;
     pk.imin = 0.0f;
+    pk.p0 = -0.5f * kZ;
     pk.eps1 = fp.eps1;
     if (METHOD == PRL_FENG) {
         const double imin = (double)g[page].imin;
         const double c3 = (tp.k2 * imin + (-imin)) + 0.0;  // binarizeFeng.cpp:137 with r2 = c2 = 1
-        pk.c1 = (float)c3;
+        pk.p0 = (float)((-0.5 - c3) * (double)kZ);
     } else if (METHOD == PRL_WOLFJOLION) {
         const double coeff = g[page].coeff;                // k / devianceMax, binarizeWolfJolion.cpp:121
-        pk.c1 = (float)coeff;
-        pk.imin = (float)g[page].imin;
+        pk.c1 = (float)(coeff * tp.f);
+        pk.imin = (float)g[page].imin * kZ;
         // |T_literal - T*| grows with |coeff| through the sqrt noise; not finite -> nothing is settled here
-        const float ac = fabsf(pk.c1);
-        pk.eps1 = (ac < 3.0e38f) ? fp.eps1 + 2.02f * 255.0f * ac * fp.es_max : __builtin_inff();
+        const float ac = fabsf((float)coeff);
+        pk.eps1 = (ac < 3.0e38f) ? fp.eps1 + kZ * 2.02f * 255.0f * ac * fp.es_max : __builtin_inff();
     } else if (METHOD == kWolfCollect) {
-        // a pixel can only carry the literal maximum if v~ >= (1-rho) (Vmax/(1+rho) - 2 Ev)
+        // a pixel can only carry the literal maximum if K~ >= (1-rho) (Kmax/(1+rho) - 2 Ev / f^2)
         const float vmax = __uint_as_float(g[page].v32max_bits);
         pk.c1 = (1.0f - fp.rho) * (vmax / (1.0f + fp.rho) - fp.ev2) * 0.999999f;
         if (!(fp.segmax[wid] >= pk.c1)) return;            // nothing in this wavefront's segment qualifies
@@ -791,37 +792,39 @@ static FusedBounds fused_bounds(const ThrParams& tp)
     const double Ev = b.Eq + 2.0 * M * b.Em + b.Em * b.Em;
     b.vthr = std::fmax(1e-2, 64.0 * Ev);
     const double Es = 1.01 * Ev / std::sqrt(b.vthr - Ev);
-    b.kappa = (4.0 + 3.5 * R) * u * 1.1;
+    // K~ = fma(w^2, Q~, -S^2~): |K~ - K| <= u (w^2 Q + S^2) + u K, i.e. relative to v* = f^2 K at most
+    // rho = (2 + 2R) u; sqrt halves it and adds 2u (v_sqrt_f32 is 1 ulp): kappa = (3 + R) u.
+    b.kappa = (3.0 + R) * u * 1.1;
     b.Ev = Ev;
     b.Es = Es;
-    b.rho = (4.0 + 7.0 * R) * u * 1.1;  // |v~ - v*| <= (4 u v* + 7 u m*^2) <= rho v*
+    b.rho = (2.0 + 2.0 * R) * u * 1.1;
     const double k = std::fabs(tp.k);
     switch (tp.method) {
     case PRL_SAUVOLA: {
         const double a = std::fabs(tp.a), bb = std::fabs(tp.b), Dmax = a * SM + bb;
-        b.E1 = M * (a * SM * (b.kappa + 2 * u) + bb * u + u * Dmax) + 3 * u * M * Dmax + u * (256 + M * Dmax);
+        b.E1 = M * (a * SM * (b.kappa + u) + bb * u + u * Dmax) + u * (256 + M * Dmax);
         b.Elit = M * a * Es + Dmax * b.Em;
         break;
     }
     case PRL_NIBLACK:
-        b.E1 = k * SM * (b.kappa + 2 * u) + 2 * u * M + u * (256 + M + k * SM);
+        b.E1 = k * SM * (b.kappa + u) + M * u + 2 * u * (256 + M + k * SM);
         b.Elit = k * Es + b.Em;
         break;
     case PRL_NICK: {
         const double Ec = 1.01 * (b.Eq + 1e-10) / std::sqrt(b.vthr - b.Eq - 1e-10);
-        b.E1 = k * SM * 4.5 * u + 2 * u * M + u * (256 + M + k * SM);
+        b.E1 = k * SM * 3.5 * u + M * u + 2 * u * (256 + M + k * SM);
         b.Elit = b.Em + k * Ec;
         break;
     }
     case PRL_WOLFJOLION:
         // T = m + (s c - k)(m - Imin), |c| s <= |k| (1 + tiny) because s <= max(s); the part of Elit that
         // scales with |c| = |k / devianceMax| is added per page in the kernel (FusedParams::es_max).
-        b.E1 = M * k * (b.kappa + 8 * u) + 3 * u * M + u * (512 + M * k);
+        b.E1 = M * k * (b.kappa + 14 * u) + 1276 * u;
         b.Elit = (2.0 + 2.0 * k) * b.Em;
         break;
     case PRL_FENG: {
         const double gcoef = std::fabs(1.0 + tp.c1), c3 = 255.0 * (std::fabs(tp.k2) + 1.0);
-        b.E1 = gcoef * M * 3 * u + c3 * u + u * (256 + gcoef * M + c3);
+        b.E1 = gcoef * M * u + 2 * u * (256 + gcoef * M + c3) + c3 * u;
         b.Elit = gcoef * b.Em + 1e-10;
         break;
     }
@@ -884,11 +887,12 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.uo = ((SW - (tp.w - 1)) / 8) * 8;
     fp.n_strips = (tp.ow + fp.uo - 1) / fp.uo;
     // rows per segment: long segments amortise the (w-1)-row warm-up, short ones fill the chip
-    int rps = 256;
+    int rps = 128;  // measured on MI355X (256 x 4K): 128 rows/segment 4.34 ms, 256: 4.46, 512: 4.95, 64: 4.41
     const long long waves_at = (long long)n_pages * fp.n_strips * ((tp.oh + rps - 1) / rps);
     if (waves_at < 8192) rps = 128;
     if ((long long)n_pages * fp.n_strips * ((tp.oh + rps - 1) / rps) < 8192) rps = 64;
     if (rps < tp.w) rps = ((tp.w + 63) / 64) * 64;
+    if (const char* e = std::getenv("PRL_HIP_ROWS_PER_SEG")) rps = std::max(16, std::atoi(e));  // tuning knob
     fp.rows_per_seg = rps;
     fp.n_segs = (tp.oh + rps - 1) / rps;
     fp.lane_off = (tp.w - 1) / 8;
@@ -896,25 +900,30 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     if (tw > 0xfffffff0ull) return PRL_ERR_BAD_ARG;
     fp.total_waves = (unsigned)tw;
     const FusedBounds b = fused_bounds(tp);
-    fp.ff = (float)tp.f;
+    const double Z = (double)kZ, f = tp.f;
+    fp.w2f = (float)(tp.w * tp.w);
     fp.Em = b.Em;
     fp.Eq = b.Eq;
     fp.vthr = b.vthr;
-    fp.vthr32 = (float)(b.vthr * 1.01);
-    fp.eps1 = (float)(b.eps1 * 1.01);
+    fp.vthr32 = (float)(b.vthr / (f * f) * (1.0 + 2.0 * b.rho + 1e-5));
+    fp.eps1 = (float)(b.eps1 * 1.01 * Z);
     fp.ref_cap = kRefineCap;
     fp.wl_cap = kWorkCap;
     switch (tp.method) {  // need_p0 = 0 only where T >= 0 for every window, so p == 0 can never come out white
-    case PRL_SAUVOLA: fp.c0 = (float)tp.a; fp.c1 = (float)tp.b; fp.need_p0 = !(tp.a >= 0.0 && tp.b >= 0.0); break;
-    case PRL_NIBLACK: fp.c0 = (float)tp.k; fp.need_p0 = !(tp.k >= 0.0); break;
-    case PRL_NICK: fp.c0 = (float)tp.k; fp.need_p0 = !(tp.k >= 0.0); break;
-    case PRL_FENG: fp.c0 = (float)(1.0 + tp.c1); fp.need_p0 = 1; break;
-    case PRL_WOLFJOLION: fp.c0 = (float)tp.k; fp.need_p0 = 1; break;
+    case PRL_SAUVOLA:
+        fp.c0 = (float)(Z * tp.a * f * f);
+        fp.c1 = (float)(Z * tp.b * f);
+        fp.need_p0 = !(tp.a >= 0.0 && tp.b >= 0.0);
+        break;
+    case PRL_NIBLACK: fp.c0 = (float)(Z * tp.k * f); fp.c1 = (float)(Z * f); fp.need_p0 = !(tp.k >= 0.0); break;
+    case PRL_NICK: fp.c0 = (float)(Z * tp.k * std::sqrt(f)); fp.c1 = (float)(Z * f); fp.need_p0 = !(tp.k >= 0.0); break;
+    case PRL_FENG: fp.c0 = (float)(Z * (1.0 + tp.c1) * f); fp.need_p0 = 1; break;
+    case PRL_WOLFJOLION: fp.c0 = (float)tp.k; fp.c1 = (float)(Z * f); fp.need_p0 = 1; break;
     default: return PRL_ERR_BAD_ARG;
     }
     fp.es_max = (float)(b.Es * 1.01);
     fp.rho = (float)(b.rho * 1.01);
-    fp.ev2 = (float)(2.0 * b.Ev * 1.01);
+    fp.ev2 = (float)(2.0 * b.Ev * 1.01 / (f * f));  // in K units
 
     // [0] refine-list length, [1] fix-up-list length, [2] Wolf candidate-list length
     auto* cnt = static_cast<unsigned*>(small);

@@ -63,26 +63,29 @@ def test_float32_margin_bounds_the_evaluation_error(prl, method, w, k):
         T = s * k + m
     else:
         T = m + k * np.sqrt(q)
-    # the kernel's float32 sequence (eval32)
-    ff = np.float32(f)
-    m32 = S.astype(np.float32) * ff
-    q32 = Q.astype(np.float32) * ff
-    v32 = _f32_fma(-m32, m32, q32)
+    # the kernel's float32 sequence (eval32): K~ = fma(w^2, Q~, -S^2~), constants carry f and Z = 2^30
+    Z = 2.0 ** 30
+    Sf, Qf = S.astype(np.float32), Q.astype(np.float32)
+    K32 = _f32_fma(np.float32(w * w), Qf, -(Sf * Sf))
+    P2 = np.float32(0.0)  # T only: compare Z*T~ with Z*T*
+    one_ulp = np.float32(1 + 2 ** -23)                      # v_sqrt_f32 is 1 ulp, not correctly rounded
     with np.errstate(invalid="ignore"):
-        s32 = np.sqrt(v32) * np.float32(1 + 2 ** -23)      # v_sqrt_f32 is 1 ulp, not correctly rounded
+        sK = np.sqrt(K32) * one_ulp
         if method == SAUVOLA:
-            T32 = m32 * _f32_fma(s32, np.float32(k / 128.0), np.float32(1.0 - k))
+            d = _f32_fma(sK, np.float32(Z * (k / 128.0) * f * f), np.float32(Z * (1.0 - k) * f))
+            t2 = _f32_fma(-Sf, d, P2)
         elif method == NIBLACK:
-            T32 = _f32_fma(s32, np.float32(k), m32)
+            t2 = _f32_fma(-Sf, np.float32(Z * f), _f32_fma(-sK, np.float32(Z * k * f), P2))
         else:
-            T32 = _f32_fma(np.sqrt(q32) * np.float32(1 + 2 ** -23), np.float32(k), m32)
-    err = np.abs(T32.astype(np.float64) - T)[keep]
+            t2 = _f32_fma(-Sf, np.float32(Z * f), _f32_fma(-(np.sqrt(Qf) * one_ulp), np.float32(Z * k * f ** 0.5), P2))
+    T32 = -t2.astype(np.float64) / Z
+    err = np.abs(T32 - T)[keep]
     assert keep.sum() > 3000
     assert err.max() <= b["E1"], (err.max(), b["E1"])
-    # the relative variance error is inside rho = 2 kappa-ish bound used by the Wolf sweeps
-    rel = np.abs(v32.astype(np.float64) - v)[keep] / v[keep]
+    # relative error of the float32 variance surrogate K~ f^2 (bound rho used by the Wolf sweeps and the K floor)
+    rel = np.abs(K32.astype(np.float64) * f * f - v)[keep] / v[keep]
     R = (w - 1) ** 2 / (2.0 * w - 1.0)
-    assert rel.max() <= 1.1 * (4 + 7 * R) * 2.0 ** -24
+    assert rel.max() <= 1.1 * (2 + 2 * R) * 2.0 ** -24
 
 
 def test_margins_scale_with_page_and_stay_small(prl):
