@@ -241,6 +241,122 @@ __global__ void __launch_bounds__(256) k_morph_binary(PageSet src, PageSetOut ds
     }
 }
 
+
+// ---- binary masks, streaming form (the default path) ---------------------------------------------------
+// One wavefront walks down a strip of 64 dwords (256 pixels); no workgroup tiles, no barriers.  Per row:
+//   horizontal rectangle from the lane's dword and its neighbours' (DPP wave shifts + funnel shifts),
+//   vertical rectangle = OR/AND over the last 2n+1 horizontally filtered rows kept in a per-wavefront LDS ring;
+// the second operator runs on the first one's rows n rows later, the output appears 2n rows behind the
+// fetch.  Each page row is fetched once per strip (halo: 2 or 4 dwords per side).
+extern __shared__ unsigned morph_ring_lds[];
+
+template <bool IS_OR>
+__device__ __forceinline__ unsigned hop(unsigned c0, int n)
+{
+    // neighbours' dwords: lane-1 (wave_shr:1) and lane+1 (wave_shl:1); a second hop for n > 4
+    const unsigned p1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c0, 0x138, 0xf, 0xf, true);
+    const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c0, 0x130, 0xf, 0xf, true);
+    unsigned p2 = 0, n2 = 0;
+    if (n > 4) {
+        p2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p1, 0x138, 0xf, 0xf, true);
+        n2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)n1, 0x130, 0xf, 0xf, true);
+    }
+    // shifted views: v_alignbyte_b32 (one 4-cycle op each) instead of 64-bit shifts
+    unsigned v = c0;
+    const int m = n < 4 ? n : 4;
+    for (int k = 1; k <= m; ++k) {
+        const unsigned right = k == 4 ? n1 : __builtin_amdgcn_alignbyte(n1, c0, (unsigned)k);
+        const unsigned left = k == 4 ? p1 : __builtin_amdgcn_alignbyte(c0, p1, (unsigned)(4 - k));
+        v = comb<IS_OR>(v, comb<IS_OR>(left, right));
+    }
+    for (int k = 5; k <= n; ++k) {
+        const unsigned right = k == 8 ? n2 : __builtin_amdgcn_alignbyte(n2, n1, (unsigned)(k - 4));
+        const unsigned left = k == 8 ? p2 : __builtin_amdgcn_alignbyte(p1, p2, (unsigned)(8 - k));
+        v = comb<IS_OR>(v, comb<IS_OR>(left, right));
+    }
+    return v;
+}
+
+template <bool FIRST_OR>
+__global__ void __launch_bounds__(256) k_morph_stream(PageSet src, PageSetOut dst, int width, int height, int n,
+                                                     int n_strips, int n_segs, int rows_per_seg, unsigned total_waves)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
+    if (wid >= total_waves) return;
+    const int per_page = n_strips * n_segs;
+    const int page = (int)(wid / (unsigned)per_page);
+    const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
+    const int seg = rem / n_strips, strip = rem - seg * n_strips;
+
+    const int K = 2 * n + 1;                       // rows of each vertical rectangle
+    const int hd = 2 * ((n + 3) / 4);              // halo dwords per side consumed by the two horizontal passes
+    const int useful = 64 - 2 * hd;                // output dwords per strip
+    unsigned* ring1 = morph_ring_lds + (size_t)wv * 2 * K * 64;
+    unsigned* ring2 = ring1 + K * 64;
+
+    const uint8_t* in = src.page(page);
+    uint8_t* out = dst.page(page);
+    const int gx = (strip * useful - hd + lane) * 4;            // first pixel of this lane's dword
+    const int ys = seg * rows_per_seg, ye = min(ys + rows_per_seg, height);
+    const unsigned neutral1 = FIRST_OR ? 0u : 0xffffffffu, neutral2 = ~neutral1;
+    // bytes of this dword that lie inside the page row
+    unsigned inside = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        if (gx + b >= 0 && gx + b < width) inside |= 0xffu << (8 * b);
+    const bool whole = inside == 0xffffffffu;
+    const bool lane_out = lane >= hd && lane < 64 - hd && gx < width;
+    const bool aligned_dst = (((size_t)out | dst.step) & 3) == 0;
+
+    // fetch of page row r (source pointer and step are 4-byte aligned: checked by the host)
+    auto fetch = [&](int r) -> unsigned {
+        unsigned v = neutral1;
+        if (r >= 0 && r < height && inside) {
+            const uint8_t* row = in + (size_t)r * src.step;
+            if (whole) {
+                v = *reinterpret_cast<const unsigned*>(row + gx);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if ((inside >> (8 * b)) & 1u) v = (v & ~(0xffu << (8 * b))) | ((unsigned)row[gx + b] << (8 * b));
+            }
+        }
+        return v;
+    };
+
+    int s1 = 0, s2 = 0;  // ring slots written next
+    unsigned va = fetch(ys - 2 * n), vb = fetch(ys - 2 * n + 1);  // two rows in flight ahead of the consumer
+    for (int r = ys - 2 * n; r < ye + 2 * n; ++r) {
+        const unsigned v = va;
+        va = vb;
+        vb = fetch(r + 2);
+        ring1[s1 * 64 + lane] = hop<FIRST_OR>(v, n);
+        s1 = (s1 + 1 == K) ? 0 : s1 + 1;
+        const int rc = r - n;                      // centre row of the first operator's vertical window
+        if (rc < ys - n) continue;                 // ring 1 not full yet
+        unsigned v1 = ring1[lane];
+        for (int k = 1; k < K; ++k) v1 = comb<FIRST_OR>(v1, ring1[k * 64 + lane]);
+        // pixels outside the page do not exist for the second operator
+        if (rc < 0 || rc >= height) v1 = neutral2;
+        else v1 = (v1 & inside) | (neutral2 & ~inside);
+        ring2[s2 * 64 + lane] = hop<!FIRST_OR>(v1, n);
+        s2 = (s2 + 1 == K) ? 0 : s2 + 1;
+        const int ro = r - 2 * n;                  // output row
+        if (ro < ys) continue;                     // ring 2 not full yet
+        unsigned o = ring2[lane];
+        for (int k = 1; k < K; ++k) o = comb<!FIRST_OR>(o, ring2[k * 64 + lane]);
+        if (lane_out) {
+            uint8_t* op = out + (size_t)ro * dst.step + gx;
+            if (aligned_dst && whole) {
+                *reinterpret_cast<unsigned*>(op) = o;
+            } else {
+                for (int b = 0; b < 4 && gx + b < width; ++b) op[b] = (uint8_t)(o >> (8 * b));
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // The rectangle of n iterations equals n applications of the 3x3 one, and a closing/opening with
@@ -254,6 +370,27 @@ int morph_binary_run(int iterations, const PageSet& src, int n_pages, int width,
     if (n == 0 || n > kMaxN) {
         set_error_detail("morph_iterations out of range (1.." + std::to_string(kMaxN) + ")");
         return PRL_ERR_BAD_ARG;
+    }
+    if ((((size_t)src.base | src.page_stride | src.step) & 3) == 0 && !src.table) {
+        // streaming kernel: needs 4-byte aligned source rows (the pipeline's own mask buffer always is)
+        const int hd = 2 * ((n + 3) / 4), useful = (64 - 2 * hd) * 4;
+        const int n_strips = (width + useful - 1) / useful;
+        int rps = 128;  // short segments: many wavefronts, each with two row fetches in flight
+        while (rps > 32 && (long long)n_pages * n_strips * ((height + rps - 1) / rps) < 32768) rps /= 2;
+        const int n_segs = (height + rps - 1) / rps;
+        const unsigned long long tw = (unsigned long long)n_pages * n_strips * n_segs;
+        if (tw < 0xfffffff0ull) {
+            const unsigned blocks = (unsigned)((tw + 3) / 4);
+            const size_t lds = (size_t)4 * 2 * (2 * n + 1) * 64 * sizeof(unsigned);
+            if (iterations > 0)
+                hipLaunchKernelGGL(k_morph_stream<true>, dim3(blocks), dim3(256), lds, stream, src, dst, width, height, n,
+                                   n_strips, n_segs, rps, (unsigned)tw);
+            else
+                hipLaunchKernelGGL(k_morph_stream<false>, dim3(blocks), dim3(256), lds, stream, src, dst, width, height, n,
+                                   n_strips, n_segs, rps, (unsigned)tw);
+            PRL_HIP_CHECK(hipGetLastError());
+            return PRL_OK;
+        }
     }
     const int h4 = ((2 * n + 3) / 4) * 4 + 8;  // halo: the window (2n) rounded to dwords + 2 guard dwords
     const int btw = BND * 4 - 2 * h4;          // output pixels per tile row (232 for n <= 2)
