@@ -109,6 +109,40 @@ __global__ void __launch_bounds__(256) k_morph(PageSet src, PageSetOut dst, int 
 }
 
 
+// One rectangle operator (max or min) of radius n <= kMaxN on any 8-bit image; out-of-image pixels ignored.
+// Rectangles compose (radius a then radius b = radius a+b, also with the ignore-outside rule), which is how
+// radii above kMaxN are built: cv::dilate/erode with iterations > 8.
+template <bool TAKE_MAX>
+__global__ void __launch_bounds__(256) k_rect(PageSet src, PageSetOut dst, int width, int height, int n)
+{
+    constexpr int PITCH = TW + 2 * kMaxN + 4;
+    __shared__ unsigned char bufA[(TH + 2 * kMaxN) * PITCH];
+    __shared__ unsigned char bufB[(TH + 2 * kMaxN) * PITCH];
+    const int page = blockIdx.z;
+    const uint8_t* in = src.page(page);
+    uint8_t* out = dst.page(page);
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const unsigned char neutral = TAKE_MAX ? 0 : 255;
+    const int sw = TW + 2 * n, sh = TH + 2 * n;
+    for (int i = threadIdx.x; i < sw * sh; i += blockDim.x) {
+        const int r = i / sw, c = i - r * sw;
+        const int gy = y0 - n + r, gx = x0 - n + c;
+        unsigned char v = neutral;
+        if (gy >= 0 && gy < height && gx >= 0 && gx < width) v = in[(size_t)gy * src.step + gx];
+        bufA[r * PITCH + c] = v;
+    }
+    __syncthreads();
+    row_pass<TAKE_MAX>(bufA, PITCH, bufB, PITCH, sh, TW, n);
+    __syncthreads();
+    col_pass<TAKE_MAX>(bufB, PITCH, bufA, PITCH, TH, TW, n);
+    __syncthreads();
+    for (int i = threadIdx.x; i < TW * TH; i += blockDim.x) {
+        const int r = i / TW, c = i - r * TW;
+        const int gy = y0 + r, gx = x0 + c;
+        if (gy < height && gx < width) out[(size_t)gy * dst.step + gx] = bufA[r * PITCH + c];
+    }
+}
+
 // ---- binary masks: 4 pixels per operation ------------------------------------------------------------
 // The binarizers only ever emit 0 / 255, and for such bytes max == bitwise OR and min == bitwise AND, so a
 // dword carries 4 pixels through every step.  The horizontal pass ORs/ANDs 2n+1 dwords read from LDS at
@@ -362,13 +396,44 @@ __global__ void __launch_bounds__(256) k_morph_stream(PageSet src, PageSetOut ds
 // The rectangle of n iterations equals n applications of the 3x3 one, and a closing/opening with
 // radius n cannot be split into smaller closings — so radii above kMaxN are rejected here and
 // handled by the caller (PRL_ERR_BAD_ARG); the reference's defaults are n in {0, 2}.
+// Radius above kMaxN: chain single-operator passes of radius <= kMaxN, ping-ponging between `tmp` and `dst`
+// so that the last pass lands in dst.  `tmp` must hold n_pages pages of height x tmp_step bytes.
+int morph_large_run(int iterations, const PageSet& src, int n_pages, int width, int height, const PageSetOut& dst,
+                    uint8_t* tmp, size_t tmp_step, hipStream_t stream)
+{
+    const int n = iterations > 0 ? iterations : -iterations;
+    const int per_op = (n + kMaxN - 1) / kMaxN, passes = 2 * per_op;
+    const dim3 grid((width + TW - 1) / TW, (height + TH - 1) / TH, n_pages);
+    PageSetOut t{};
+    t.base = tmp;
+    t.page_stride = tmp_step * (size_t)height;
+    t.step = tmp_step;
+    PageSet cur = src;
+    for (int i = 0; i < passes; ++i) {
+        const bool first_op = i < per_op;
+        const int idx = first_op ? i : i - per_op;
+        const int r = (idx == per_op - 1) ? n - kMaxN * (per_op - 1) : kMaxN;
+        const bool take_max = (iterations > 0) == first_op;          // closing: max then min; opening: min then max
+        const PageSetOut& o = ((passes - 1 - i) % 2 == 0) ? dst : t;  // last pass -> dst
+        if (take_max) hipLaunchKernelGGL(k_rect<true>, grid, dim3(256), 0, stream, cur, o, width, height, r);
+        else hipLaunchKernelGGL(k_rect<false>, grid, dim3(256), 0, stream, cur, o, width, height, r);
+        PRL_HIP_CHECK(hipGetLastError());
+        cur = PageSet{};
+        cur.base = o.base;
+        cur.page_stride = o.page_stride;
+        cur.table = o.table;
+        cur.step = o.step;
+    }
+    return PRL_OK;
+}
+
 // binary (0/255) masks: the pipeline's own threshold output
 int morph_binary_run(int iterations, const PageSet& src, int n_pages, int width, int height,
                      const PageSetOut& dst, hipStream_t stream)
 {
     const int n = iterations > 0 ? iterations : -iterations;
     if (n == 0 || n > kMaxN) {
-        set_error_detail("morph_iterations out of range (1.." + std::to_string(kMaxN) + ")");
+        set_error_detail("radius above " + std::to_string(kMaxN) + " goes through morph_large_run");
         return PRL_ERR_BAD_ARG;
     }
     if ((((size_t)src.base | src.page_stride | src.step) & 3) == 0 && !src.table) {
@@ -409,7 +474,7 @@ int morph_run(int iterations, const PageSet& src, int n_pages, int width, int he
 {
     const int n = iterations > 0 ? iterations : -iterations;
     if (n == 0 || n > kMaxN) {
-        set_error_detail("morph_iterations out of range (1.." + std::to_string(kMaxN) + ")");
+        set_error_detail("radius above " + std::to_string(kMaxN) + " goes through morph_large_run");
         return PRL_ERR_BAD_ARG;
     }
     const dim3 grid((width + TW - 1) / TW, (height + TH - 1) / TH, n_pages);

@@ -343,7 +343,15 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         msrc.base = thr_dst.base;
         msrc.page_stride = thr_dst.page_stride;
         msrc.step = thr_dst.step;
-        st = morph_binary_run(morph, msrc, n_pages, g.out_w, g.out_h, dst, stream);
+        if (std::abs(morph) <= kMorphMaxFusedRadius) {
+            st = morph_binary_run(morph, msrc, n_pages, g.out_w, g.out_h, dst, stream);
+        } else {
+            // large radii: chained single-operator passes through one more page-sized buffer
+            st = ensure_scratch(ctx, mask_page * (size_t)n_pages);
+            if (st != PRL_OK) return st;
+            st = morph_large_run(morph, msrc, n_pages, g.out_w, g.out_h, dst, static_cast<uint8_t*>(ctx->scratch),
+                                 mask_step, stream);
+        }
         if (st != PRL_OK) return st;
     }
     PRL_HIP_CHECK(hipEventRecord(ctx->last_use, stream));
@@ -624,7 +632,20 @@ int prl_hip_morph_batch_device(int morph_iterations, int n_pages, const uint8_t*
     d.base = d_dst;
     d.page_stride = dst_page_stride;
     d.step = dst_step;
-    return morph_run(morph_iterations, s, n_pages, width, height, d, static_cast<hipStream_t>(stream));
+    if (std::abs(morph_iterations) <= kMorphMaxFusedRadius)
+        return morph_run(morph_iterations, s, n_pages, width, height, d, static_cast<hipStream_t>(stream));
+    DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const size_t tstep = ((size_t)width + 63) / 64 * 64;
+    st = ensure_scratch(ctx, tstep * (size_t)height * (size_t)n_pages);
+    if (st != PRL_OK) return st;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(hs, ctx->last_use, 0));
+    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+    st = morph_large_run(morph_iterations, s, n_pages, width, height, d, static_cast<uint8_t*>(ctx->scratch), tstep, hs);
+    if (st != PRL_OK) return st;
+    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, hs));
+    return PRL_OK;
 }
 
 }  // extern "C"

@@ -115,6 +115,9 @@ int morph_run(int iterations, const PageSet& src, int n_pages, int width, int he
               const PageSetOut& dst, hipStream_t stream);
 int morph_binary_run(int iterations, const PageSet& src, int n_pages, int width, int height,
                      const PageSetOut& dst, hipStream_t stream);
+int morph_large_run(int iterations, const PageSet& src, int n_pages, int width, int height, const PageSetOut& dst,
+                    uint8_t* tmp, size_t tmp_step, hipStream_t stream);
+constexpr int kMorphMaxFusedRadius = 8;  // morph_run / morph_binary_run handle |iterations| up to this
 
 // ---- page reductions (binarize_literal.hip) ---------------------------------------------------
 int page_min_run(const ThrParams& tp, const PageSet& src, int n_pages, PageGlobals* d_globals,

@@ -270,3 +270,15 @@ def test_binary_morphology_tiles(prl, oracle, cuda_device, shape, morph):
     # page sizes around the 128x32 tile of the binary kernel; window clamps when the page is small
     pages = _pages(shape, ["binary", "doc"], seed=41)
     _check(prl, oracle, cuda_device, pages, NIBLACK, 15, 0.3, morph)
+
+
+@pytest.mark.parametrize("n", [9, 12, -17])
+def test_morph_radius_above_eight(prl, oracle, cuda_device, n):
+    """cv::dilate/erode accept any iteration count; radii above 8 are chained rectangle passes."""
+    import torch
+
+    rng = np.random.default_rng(abs(n))
+    gray = rng.integers(0, 256, (90, 140), dtype=np.uint8)
+    got = prl.morph(torch.from_numpy(gray).to(cuda_device), n).cpu().numpy()
+    assert np.array_equal(got, oracle.morph(gray, n))
+    _check(prl, oracle, cuda_device, _pages((120, 150), ["doc", "binary"], seed=43), SAUVOLA, 15, 0.3, n)
