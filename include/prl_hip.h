@@ -195,6 +195,25 @@ int prl_hip_denoise_host(int channels, float strength,
                          const uint8_t* src, size_t src_step, int width, int height,
                          uint8_t* dst, size_t dst_step);
 
+/* ---- thinning (prl::thinZhangSuen / prl::thinGuoHall) --------------------------- */
+
+typedef enum prl_thin_method {
+    PRL_THIN_ZHANGSUEN = 0,  /* src/thinning/thinZhangSuen.cpp:15-108 */
+    PRL_THIN_GUOHALL = 1     /* src/thinning/thinGuoHall.cpp:15-107   */
+} prl_thin_method;
+
+/*
+ * Iterative thinning of 1-channel 8-bit pages: foreground = pixels with bit 0 set (the reference's `&= 1`),
+ * output 0 / 255.  Replaces the body of prl::thinZhangSuen / prl::thinGuoHall after cvtColor.  d_src == d_dst is
+ * allowed.  Synchronises the stream every few passes to read the convergence flags.
+ */
+int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                              int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                              void* stream);
+
+int prl_hip_thin_host(int method, const uint8_t* src, size_t src_step, int width, int height,
+                      uint8_t* dst, size_t dst_step);
+
 #ifdef __cplusplus
 }
 #endif

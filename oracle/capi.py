@@ -106,6 +106,7 @@ def lib() -> C.CDLL:
             L.prl_oracle_lab2lbgr.restype = None
             L.prl_oracle_denoise.argtypes = [C.c_int, C.c_float, u8p, C.c_size_t, C.c_int, C.c_int,
                                              u8p, C.c_size_t, C.c_int]
+        L.prl_oracle_thin.argtypes = [C.c_int, u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -257,3 +258,20 @@ def denoise(img: np.ndarray, strength: float, threads: int = 1) -> np.ndarray:
     if st != PRL_OK:
         raise OracleError(st)
     return out
+
+
+# ---- thinning -----------------------------------------------------------------------------------
+
+ZHANGSUEN, GUOHALL = 0, 1
+
+
+def thin(img: np.ndarray, method: int = ZHANGSUEN, return_passes: bool = False):
+    """prl::thinZhangSuen / prl::thinGuoHall on a 1-channel u8 image (after cvtColor)."""
+    assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+    h, w = img.shape
+    out = np.empty((h, w), dtype=np.uint8)
+    passes = C.c_int(0)
+    st = lib().prl_oracle_thin(method, _ptr(img), img.strides[0], w, h, _ptr(out), out.strides[0], C.byref(passes))
+    if st != PRL_OK:
+        raise OracleError(st)
+    return (out, passes.value) if return_passes else out

@@ -93,6 +93,12 @@ void prl_oracle_lab2lbgr(const uint8_t* lab, size_t src_step, int width, int hei
 int prl_oracle_denoise(int channels, float strength, const uint8_t* src, size_t src_step,
                        int width, int height, uint8_t* dst, size_t dst_step, int threads);
 
+/* ---- thinning (src/thinning/thinZhangSuen.cpp:57-108, thinGuoHall.cpp:56-107) ---- */
+/* method 0 = Zhang-Suen, 1 = Guo-Hall; src is the 1-channel image after cvtColor; passes_out (optional) gets the
+ * number of do-while passes the reference loop makes. */
+int prl_oracle_thin(int method, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst,
+                    size_t dst_step, int* passes_out);
+
 #ifdef __cplusplus
 }
 #endif

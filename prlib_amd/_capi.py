@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "prl_hip_release_workspace", "prl_hip_set_profiling", "prl_hip_last_kernel_ms", "prl_hip_default_params", "prl_hip_binarize_geometry",
     "prl_hip_binarize_batch_device", "prl_hip_binarize_pages_device", "prl_hip_binarize_host",
     "prl_hip_morph_batch_device", "prl_hip_nlm_planes_device", "prl_hip_denoise_batch_device",
-    "prl_hip_denoise_host",
+    "prl_hip_denoise_host", "prl_hip_thin_batch_device", "prl_hip_thin_host",
 ]
 
 
@@ -103,6 +103,8 @@ def lib() -> C.CDLL:
         L.prl_hip_nlm_planes_device.argtypes = [i, i, C.c_float, vp, sz, sz, i, i, vp, sz, sz, vp]
         L.prl_hip_denoise_batch_device.argtypes = [i, i, C.c_float, vp, sz, sz, i, i, vp, sz, sz, vp]
         L.prl_hip_denoise_host.argtypes = [i, C.c_float, vp, sz, i, i, vp, sz]
+        L.prl_hip_thin_batch_device.argtypes = [i, i, vp, sz, sz, i, i, vp, sz, sz, vp]
+        L.prl_hip_thin_host.argtypes = [i, vp, sz, i, i, vp, sz]
         _lib = L
     return _lib
 

@@ -47,6 +47,12 @@ void binarizeFeng(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 21
 
 void denoise(const cv::Mat& inputImage, cv::Mat& outputImage, double strength = 5.5);
 
+// SURVEY.md §8f rank 1 — src/thinning/thinZhangSuen.h, src/thinning/thinGuoHall.h.  8UC1 or 8UC3 (BGR is
+// converted to gray first, thinZhangSuen.cpp:78-81); foreground = pixels with bit 0 set; output 0/255.
+// std::invalid_argument for an empty image or another type (:59-68).
+void thinZhangSuen(cv::Mat& inputImage, cv::Mat& outputImage);
+void thinGuoHall(cv::Mat& inputImage, cv::Mat& outputImage);
+
 // BASELINE config 1 (plumbing, host only): global Otsu, the one global threshold the reference uses
 // (cv::threshold(..., THRESH_BINARY | THRESH_OTSU), src/deskew/deskew.cpp:224).  Not a GPU path.
 void binarize(cv::Mat& inputImage, cv::Mat& outputImage);

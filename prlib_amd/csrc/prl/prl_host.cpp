@@ -117,6 +117,27 @@ void prl::denoise(const cv::Mat& inputImage, cv::Mat& outputImage, double streng
     outputImage = result;
 }
 
+namespace {
+void thin_impl(int method, cv::Mat& inputImage, cv::Mat& outputImage)
+{
+    if (inputImage.empty()) throw std::invalid_argument("Input image for thinning is empty");
+    if (inputImage.type() != CV_8UC3 && inputImage.type() != CV_8UC1)
+        throw std::invalid_argument("Invalid type of image for thinning (required 8 or 24 bits per pixel)");
+    // the reference works on the caller's buffer when input and output share data, else on a clone (:71-80)
+    const bool in_place = inputImage.data == outputImage.data;
+    cv::Mat work = in_place ? inputImage : inputImage.clone();
+    if (work.channels() == 3) bgr2gray_inplace(work);
+    cv::Mat result(work.rows, work.cols, CV_8UC1);
+    const int st = prl_hip_thin_host(method, work.data, work.step, work.cols, work.rows, result.data, result.step);
+    if (st != PRL_OK) raise(st);
+    if (in_place) inputImage = result;
+    outputImage = result;
+}
+}  // namespace
+
+void prl::thinZhangSuen(cv::Mat& inputImage, cv::Mat& outputImage) { thin_impl(PRL_THIN_ZHANGSUEN, inputImage, outputImage); }
+void prl::thinGuoHall(cv::Mat& inputImage, cv::Mat& outputImage) { thin_impl(PRL_THIN_GUOHALL, inputImage, outputImage); }
+
 // Global Otsu on the host (BASELINE config 1: plumbing, no GPU).  [upstream getThreshVal_Otsu_8u]
 void prl::binarize(cv::Mat& inputImage, cv::Mat& outputImage)
 {

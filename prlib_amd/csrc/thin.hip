@@ -1,0 +1,256 @@
+// thin.hip — prl::thinZhangSuen (src/thinning/thinZhangSuen.cpp:15-108) and prl::thinGuoHall
+// (src/thinning/thinGuoHall.cpp:15-107): SURVEY.md §8f rank 1, the last step of the BASELINE config-5 chain.
+//
+// The reference works on a 0/1 byte image (`&= 1`, :83) and repeats two sub-iterations until a whole pass
+// changes nothing (:88-96).  Both sub-iterations are pure 3x3 boolean functions of the neighbourhood, so the
+// device keeps the image as ONE BIT per pixel (a 4K page is 2 MiB and stays in L2 across passes) and evaluates
+// 32 pixels per thread with bit-sliced logic:
+//   neighbours p2..p9 (thinZhangSuen.cpp:28-35) are the three row words shifted by -1/0/+1 bit;
+//   Zhang-Suen: A == 1 (exactly one 0->1 transition around the ring) via an "any / two-or-more" pair,
+//               2 <= B <= 6 via a bit-sliced population count, m1 == 0, m2 == 0      (:37-51)
+//   Guo-Hall:   C == 1, 2 <= min(N1, N2) <= 3, m == 0                                 (thinGuoHall.cpp:40-50)
+//   marker applied as `image &= ~marker` after the sub-iteration (:54) = ping-pong between two bit planes;
+//   border pixels (row/column 0 and last) are never marked (:22-24).
+// Integer/boolean throughout: bit-exact by construction.  Bound: latency/launch (each sub-iteration touches
+// 1/8 B per pixel out of L2); HBM traffic is one u8 read (pack) and one u8 write (unpack) per pixel.
+#include <algorithm>
+#include <vector>
+
+#include "prl_internal.h"
+
+namespace prl_hip {
+
+namespace {
+
+// pack: bit = pixel & 1  (imageUnderProcess &= 1, thinZhangSuen.cpp:83)
+__global__ void __launch_bounds__(256) k_thin_pack(PageSet src, int width, int height, int wpr, unsigned* __restrict__ bits,
+                                                  size_t plane_words)
+{
+    const int page = blockIdx.z, y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    unsigned b = 0;
+    if (x < width) b = src.page(page)[(size_t)y * src.step + x] & 1u;
+    const unsigned long long m = __ballot(b != 0);
+    const int lane = threadIdx.x & 63;
+    const int w0 = (blockIdx.x * 256 + (threadIdx.x & ~63)) / 32;
+    unsigned* row = bits + (size_t)page * plane_words + (size_t)y * wpr;
+    if (lane == 0 && w0 < wpr) row[w0] = (unsigned)m;
+    if (lane == 32 && w0 + 1 < wpr) row[w0 + 1] = (unsigned)(m >> 32);
+}
+
+// unpack: byte = bit * 255  (outputImage = imageUnderProcess * 255, :100-106)
+__global__ void __launch_bounds__(256) k_thin_unpack(const unsigned* __restrict__ bits, size_t plane_words, int wpr,
+                                                    PageSetOut dst, int width, int height)
+{
+    const int page = blockIdx.z, y = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= width) return;
+    const unsigned w = bits[(size_t)page * plane_words + (size_t)y * wpr + (x >> 5)];
+    dst.page(page)[(size_t)y * dst.step + x] = ((w >> (x & 31)) & 1u) ? 255 : 0;
+}
+
+// exactly one of the given bit-planes set, per bit
+struct OneOf {
+    unsigned any = 0, two = 0;
+    __device__ __forceinline__ void add(unsigned t)
+    {
+        two |= any & t;
+        any |= t;
+    }
+    __device__ __forceinline__ unsigned exactly_one() const { return any & ~two; }
+};
+
+// bit-sliced counter (values 0..8 in s3 s2 s1 s0) of up to 8 one-bit planes
+struct Count8 {
+    unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    __device__ __forceinline__ void add(unsigned t)
+    {
+        const unsigned c0 = s0 & t;
+        s0 ^= t;
+        const unsigned c1 = s1 & c0;
+        s1 ^= c0;
+        const unsigned c2 = s2 & c1;
+        s2 ^= c1;
+        s3 |= c2;
+    }
+};
+
+// One sub-iteration on the words of one row.  METHOD 0 = Zhang-Suen, 1 = Guo-Hall; `iteration` as in the reference.
+template <int METHOD>
+__global__ void __launch_bounds__(256) k_thin_iter(const unsigned* __restrict__ in, unsigned* __restrict__ out,
+                                                  size_t plane_words, int wpr, int width, int height, int iteration,
+                                                  unsigned* __restrict__ changed, const unsigned* __restrict__ done)
+{
+    const int page = blockIdx.z;
+    if (done[page]) return;  // converged: its bit plane is final and stays in buffer A
+    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (k >= wpr || y >= height) return;
+    const unsigned* base = in + (size_t)page * plane_words;
+    auto word = [&](int yy, int kk) -> unsigned {
+        return (yy < 0 || yy >= height || kk < 0 || kk >= wpr) ? 0u : base[(size_t)yy * wpr + kk];
+    };
+    const unsigned c = word(y, k);
+    unsigned res = c;
+    // rows/columns 0 and last are never marked (loops run 1 .. rows-2 / 1 .. cols-2)
+    if (c != 0 && y >= 1 && y <= height - 2) {
+        const unsigned up = word(y - 1, k), dn = word(y + 1, k);
+        const unsigned cl = word(y, k - 1), cr = word(y, k + 1);
+        const unsigned ul = word(y - 1, k - 1), ur = word(y - 1, k + 1);
+        const unsigned dl = word(y + 1, k - 1), dr = word(y + 1, k + 1);
+        // bit b of each plane = neighbour of pixel x = 32k + b      (thinZhangSuen.cpp:28-35)
+        const unsigned p2 = up;                                  // (i-1, j)
+        const unsigned p3 = (up >> 1) | (ur << 31);              // (i-1, j+1)
+        const unsigned p4 = (c >> 1) | (cr << 31);               // (i,   j+1)
+        const unsigned p5 = (dn >> 1) | (dr << 31);              // (i+1, j+1)
+        const unsigned p6 = dn;                                  // (i+1, j)
+        const unsigned p7 = (dn << 1) | (dl >> 31);              // (i+1, j-1)
+        const unsigned p8 = (c << 1) | (cl >> 31);               // (i,   j-1)
+        const unsigned p9 = (up << 1) | (ul >> 31);              // (i-1, j-1)
+        unsigned mark;
+        if (METHOD == 0) {
+            OneOf A;                                             // :37-40
+            A.add(~p2 & p3); A.add(~p3 & p4); A.add(~p4 & p5); A.add(~p5 & p6);
+            A.add(~p6 & p7); A.add(~p7 & p8); A.add(~p8 & p9); A.add(~p9 & p2);
+            Count8 B;                                            // :42
+            B.add(p2); B.add(p3); B.add(p4); B.add(p5); B.add(p6); B.add(p7); B.add(p8); B.add(p9);
+            const unsigned ge2 = B.s3 | B.s2 | B.s1;
+            const unsigned le6 = ~(B.s3 | (B.s2 & B.s1 & B.s0));
+            const unsigned m1 = iteration == 0 ? (p2 & p4 & p6) : (p2 & p4 & p8);   // :44
+            const unsigned m2 = iteration == 0 ? (p4 & p6 & p8) : (p2 & p6 & p8);   // :45
+            mark = A.exactly_one() & ge2 & le6 & ~m1 & ~m2;      // :47
+        } else {
+            OneOf Cn;                                            // thinGuoHall.cpp:40-41
+            Cn.add(~p2 & (p3 | p4)); Cn.add(~p4 & (p5 | p6)); Cn.add(~p6 & (p7 | p8)); Cn.add(~p8 & (p9 | p2));
+            Count8 N1, N2;                                       // :42-43
+            N1.add(p9 | p2); N1.add(p3 | p4); N1.add(p5 | p6); N1.add(p7 | p8);
+            N2.add(p2 | p3); N2.add(p4 | p5); N2.add(p6 | p7); N2.add(p8 | p9);
+            const unsigned n1_ge2 = N1.s2 | N1.s1, n2_ge2 = N2.s2 | N2.s1;
+            const unsigned n1_le3 = ~N1.s2, n2_le3 = ~N2.s2;
+            const unsigned n_ok = n1_ge2 & n2_ge2 & (n1_le3 | n2_le3);              // 2 <= min(N1,N2) <= 3   :44,47
+            const unsigned m = iteration == 0 ? ((p6 | p7 | ~p9) & p8) : ((p2 | p3 | ~p5) & p4);   // :45
+            mark = Cn.exactly_one() & n_ok & ~m;
+        }
+        // columns 0 and width-1 never marked; bits beyond the row are zero anyway
+        unsigned col_ok = 0xffffffffu;
+        if (k == 0) col_ok &= ~1u;
+        const int last = width - 1;
+        if ((last >> 5) == k) col_ok &= ~(1u << (last & 31));
+        mark &= col_ok;
+        res = c & ~mark;                                         // imageUnderProcessing &= ~marker   :54
+        if (res != c) atomicOr(&changed[page], 1u);
+    }
+    out[(size_t)page * plane_words + (size_t)y * wpr + k] = res;
+}
+
+// after both sub-iterations of a pass: a page whose pass changed nothing is final (do-while test, :93-96)
+__global__ void k_thin_endpass(unsigned* changed, unsigned* done, int n_pages)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pages) {
+        if (changed[i] == 0) done[i] = 1;
+        changed[i] = 0;
+    }
+}
+
+}  // namespace
+}  // namespace prl_hip
+
+using namespace prl_hip;
+
+extern "C" {
+
+int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                              int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream)
+{
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;  // "Input image for thinning is empty" (thinZhangSuen.cpp:59-62)
+    if (method != PRL_THIN_ZHANGSUEN && method != PRL_THIN_GUOHALL) return PRL_ERR_BAD_ARG;
+    if (n_pages < 0 || !d_src || !d_dst || src_step < (size_t)width || dst_step < (size_t)width) return PRL_ERR_BAD_ARG;
+    if (n_pages == 0) return PRL_OK;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    const int wpr = (width + 31) / 32;
+    const size_t plane_words = (size_t)wpr * height;
+    const size_t bits_bytes = plane_words * sizeof(unsigned) * (size_t)n_pages;
+    const size_t flags_bytes = ((size_t)n_pages * sizeof(unsigned) + 255) / 256 * 256;
+    st = ensure_scratch(ctx, 2 * bits_bytes + 2 * flags_bytes);
+    if (st != PRL_OK) return st;
+    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(s, ctx->last_use, 0));
+    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+    auto* A = static_cast<unsigned*>(ctx->scratch);
+    auto* B = A + plane_words * (size_t)n_pages;
+    auto* changed = reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(B) + bits_bytes);
+    auto* done = reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(changed) + flags_bytes);
+    PRL_HIP_CHECK(hipMemsetAsync(changed, 0, 2 * flags_bytes, s));
+
+    PageSet ps{};
+    ps.base = d_src;
+    ps.page_stride = src_page_stride;
+    ps.step = src_step;
+    PageSetOut pd{};
+    pd.base = d_dst;
+    pd.page_stride = dst_page_stride;
+    pd.step = dst_step;
+    const dim3 gpx((width + 255) / 256, height, n_pages);
+    hipLaunchKernelGGL(k_thin_pack, gpx, dim3(256), 0, s, ps, width, height, wpr, A, plane_words);
+    PRL_HIP_CHECK(hipGetLastError());
+
+    const dim3 git((wpr + 63) / 64, (height + 3) / 4, n_pages);
+    std::vector<unsigned> h_done((size_t)n_pages);
+    const int max_passes = std::max(width, height) + 2;  // every effective pass removes at least one pixel layer
+    const int group = 4;                                 // passes per host check; extra passes change nothing
+    for (int pass = 0; pass < max_passes;) {
+        for (int gidx = 0; gidx < group && pass < max_passes; ++gidx, ++pass) {
+            for (int it = 0; it < 2; ++it) {
+                const unsigned* in = it == 0 ? A : B;
+                unsigned* out = it == 0 ? B : A;
+                if (method == PRL_THIN_ZHANGSUEN)
+                    hipLaunchKernelGGL(k_thin_iter<0>, git, dim3(256), 0, s, in, out, plane_words, wpr, width, height, it,
+                                       changed, done);
+                else
+                    hipLaunchKernelGGL(k_thin_iter<1>, git, dim3(256), 0, s, in, out, plane_words, wpr, width, height, it,
+                                       changed, done);
+                PRL_HIP_CHECK(hipGetLastError());
+            }
+            hipLaunchKernelGGL(k_thin_endpass, dim3((n_pages + 255) / 256), dim3(256), 0, s, changed, done, n_pages);
+            PRL_HIP_CHECK(hipGetLastError());
+        }
+        PRL_HIP_CHECK(hipMemcpyAsync(h_done.data(), done, sizeof(unsigned) * (size_t)n_pages, hipMemcpyDeviceToHost, s));
+        PRL_HIP_CHECK(hipStreamSynchronize(s));
+        if (std::all_of(h_done.begin(), h_done.end(), [](unsigned v) { return v != 0; })) break;
+    }
+    hipLaunchKernelGGL(k_thin_unpack, gpx, dim3(256), 0, s, A, plane_words, wpr, pd, width, height);
+    PRL_HIP_CHECK(hipGetLastError());
+    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, s));
+    return PRL_OK;
+}
+
+int prl_hip_thin_host(int method, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst, size_t dst_step)
+{
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    if (!src || !dst || src_step < (size_t)width || dst_step < (size_t)width) return PRL_ERR_BAD_ARG;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    const size_t pitch = ((size_t)width + 255) / 256 * 256;
+    uint8_t* d = nullptr;
+    PRL_HIP_CHECK(hipMalloc(&d, pitch * (size_t)height));
+    if (hipMemcpy2D(d, pitch, src, src_step, (size_t)width, (size_t)height, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return PRL_ERR_HIP;
+    }
+    st = prl_hip_thin_batch_device(method, 1, d, pitch * (size_t)height, pitch, width, height, d, pitch * (size_t)height,
+                                   pitch, nullptr);
+    if (st == PRL_OK &&
+        hipMemcpy2D(dst, dst_step, d, pitch, (size_t)width, (size_t)height, hipMemcpyDeviceToHost) != hipSuccess)
+        st = PRL_ERR_HIP;
+    (void)hipFree(d);
+    return st;
+}
+
+}  // extern "C"

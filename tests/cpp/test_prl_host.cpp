@@ -58,6 +58,9 @@ static void test_validation()
     CHECK(throws_invalid_argument([&] { prl::binarizeNiblack(page, out, 1); }));    // window <= 1
     CHECK(throws_invalid_argument([&] { prl::binarizeNICK(page, out, -3); }));
     CHECK(page.rows == 40 && page.cols == 50);  // a rejected call leaves the input alone
+    CHECK(throws_invalid_argument([&] { prl::thinZhangSuen(empty, out); }));
+    cv::Mat two(8, 8, CV_8UC2);
+    CHECK(throws_invalid_argument([&] { prl::thinGuoHall(two, out); }));
     // global Otsu plumbing (host only): bimodal page splits between the modes
     cv::Mat bi(64, 64, CV_8UC1), bo;
     for (int y = 0; y < 64; ++y)
@@ -166,6 +169,20 @@ static void test_gpu()
     cv::Mat gray1 = synth_page(30, 30, 5);
     try { prl::denoise(gray1, den); } catch (const cv::Exception&) { threw = true; } catch (...) {}
     CHECK(threw);  // 8UC1 is rejected by fastNlMeansDenoisingColored
+    // thinning: binarize, invert (white = foreground for prl::thin*), thin
+    cv::Mat pg = synth_page(140, 180, 13), mk, sk;
+    prl::binarizeSauvola(pg, mk, 15, 0.34, 0);
+    for (int y = 0; y < mk.rows; ++y)
+        for (int x = 0; x < mk.cols; ++x) mk.at<unsigned char>(y, x) = 255 - mk.at<unsigned char>(y, x);
+    std::vector<unsigned char> tw((size_t)mk.rows * mk.cols);
+    for (int method = 0; method < 2; ++method) {
+        CHECK(prl_oracle_thin(method, mk.data, mk.step, mk.cols, mk.rows, tw.data(), (size_t)mk.cols, nullptr) == PRL_OK);
+        if (method == 0) prl::thinZhangSuen(mk, sk); else prl::thinGuoHall(mk, sk);
+        CHECK(sk.rows == mk.rows && sk.cols == mk.cols);
+        bad = 0;
+        for (int y = 0; y < sk.rows; ++y) bad += std::memcmp(sk.ptr(y), &tw[(size_t)y * mk.cols], (size_t)mk.cols) != 0;
+        CHECK(bad == 0);
+    }
 }
 
 int main(int argc, char** argv)

@@ -182,3 +182,22 @@ def test_golden_nlm_fixture(oracle):
     assert np.array_equal(oracle.nlm_planes(np.ascontiguousarray(lab[:, :, 0]), 10.0), z["l_h10"])
     assert np.array_equal(oracle.nlm_planes(np.ascontiguousarray(lab[:, :, 1:]), 3.0), z["ab_h3"])
     assert np.array_equal(oracle.denoise(z["noisy"], 10.0), z["denoised_s10"])
+
+
+def test_thinning_known_shapes(oracle):
+    # a 1-pixel-wide line is already thin; a filled rectangle collapses to a thin set; borders never change
+    line = np.zeros((20, 30), np.uint8)
+    line[10, 3:27] = 255
+    for m in (0, 1):
+        assert np.array_equal(oracle.thin(line, m), line)
+    rect = np.zeros((40, 60), np.uint8)
+    rect[10:30, 15:45] = 255
+    for m in (0, 1):
+        out, passes = oracle.thin(rect, m, return_passes=True)
+        assert 0 < (out > 0).sum() < 60 and passes > 5
+        assert set(np.unique(out).tolist()) <= {0, 255}
+    border = np.full((12, 12), 255, np.uint8)
+    out = oracle.thin(border, 0)
+    assert out[0].min() == 255 and out[-1].min() == 255 and out[:, 0].min() == 255 and out[:, -1].min() == 255
+    odd = np.array([[0, 1, 2, 3], [254, 255, 7, 8]], np.uint8)       # `&= 1`: only bit 0 is foreground
+    assert np.array_equal(oracle.thin(odd, 0), (odd & 1) * 255)

@@ -1,0 +1,72 @@
+"""GPU parity of the thinning step against the CPU oracle: boolean logic => bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mask(shape, seed, kind):
+    from prlib_amd import synth
+
+    rng = np.random.default_rng(seed)
+    h, w = shape
+    if kind == "doc":   # thinning treats white as foreground: invert a binarized page so strokes are white
+        page = synth.page_numpy(h, w, index=seed)
+        return np.where(page < 150, 255, 0).astype(np.uint8)
+    if kind == "noise":
+        return (rng.random((h, w)) < 0.55).astype(np.uint8) * 255
+    if kind == "blobs":
+        a = np.zeros((h, w), np.uint8)
+        for _ in range(12):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            a[max(0, y - 9):y + 9, max(0, x - 14):x + 14] = 255
+        return a
+    if kind == "full":
+        return np.full((h, w), 255, np.uint8)
+    if kind == "odd_values":  # `&= 1`: only bit 0 counts
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("method", [0, 1], ids=["zhangsuen", "guohall"])
+@pytest.mark.parametrize("shape", [(40, 60), (64, 64), (33, 97), (100, 31), (129, 257), (3, 50), (50, 2), (1, 1)])
+def test_thinning_matches_oracle(prl, oracle, cuda_device, method, shape):
+    import torch
+
+    fn = prl.thinZhangSuen if method == 0 else prl.thinGuoHall
+    kinds = ["doc", "noise", "blobs", "full", "odd_values"]
+    imgs = [_mask(shape, seed=i + 1, kind=k) for i, k in enumerate(kinds)]
+    got = fn(torch.from_numpy(np.stack(imgs)).to(cuda_device)).cpu().numpy()
+    for i, img in enumerate(imgs):
+        want = oracle.thin(img, method)
+        assert np.array_equal(got[i], want), f"{kinds[i]}: {int((got[i] != want).sum())} mismatching pixels"
+
+
+def test_thinning_in_place_host_entry_and_chain(prl, oracle, cuda_device):
+    import torch
+
+    img = _mask((120, 200), seed=9, kind="blobs")
+    t = torch.from_numpy(img).to(cuda_device)
+    prl.thinZhangSuen(t, out=t)                         # inputImage.data == outputImage.data branch (:73-76)
+    assert np.array_equal(t.cpu().numpy(), oracle.thin(img, 0))
+    assert np.array_equal(prl.thinGuoHall(img), oracle.thin(img, 1))   # host entry point
+    # config-5 style hand-off on the device: Sauvola mask -> invert -> thinning, no host round trip
+    from prlib_amd import synth
+
+    page = synth.page_numpy(300, 400, index=3)
+    mask = prl.binarizeSauvola(torch.from_numpy(page).to(cuda_device), 31, 0.34, 0)
+    skel = prl.thinZhangSuen((255 - mask).contiguous())
+    want = oracle.thin(255 - oracle.binarize(page, oracle.make_params(oracle.SAUVOLA, 31, 0.34, 0)), 0)
+    assert np.array_equal(skel.cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        prl.thinZhangSuen(np.zeros((0, 0), np.uint8))
+
+
+def test_thinning_full_page(prl, oracle, cuda_device):
+    import torch
+    from prlib_amd import synth
+
+    page = synth.page_numpy(1500, 2000, index=5)
+    img = np.where(page < 150, 255, 0).astype(np.uint8)
+    got = prl.thinGuoHall(torch.from_numpy(img).to(cuda_device)).cpu().numpy()
+    assert np.array_equal(got, oracle.thin(img, 1))
