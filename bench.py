@@ -83,6 +83,17 @@ def main():
     from prlib_amd import dist as pdist
 
     world, rank, local_rank = pdist.init()
+    if os.environ.get("PRL_BENCH_DRYRUN") == "1":
+        # launcher/collective plumbing only (CPU test of the N>1 path): no kernels, no number
+        mine = pdist.page_range(world * args.pages, world, rank)
+        pdist.barrier()
+        slowest = pdist.max_over_ranks(float(rank + 1))
+        total = pdist.sum_over_ranks(float(len(mine)))
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "pages_total": int(total), "max_rank_plus_1": slowest,
+                              "first_block": [mine.start, mine.stop]}), flush=True)
+        pdist.finish()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path in prlib_amd)")
     dev = torch.device("cuda", local_rank)

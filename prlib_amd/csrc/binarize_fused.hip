@@ -14,14 +14,16 @@
 //      decides every pixel whose margin |T - (p - 0.5)| exceeds it;
 //   3. re-evaluates the few remaining pixels in float64 with a per-pixel interval that also covers
 //      the literal sequence's rounding noise;
-//   4. queues what is still undecided (|T - (p-0.5)| ~< 1e-6) for k_fixup, which rebuilds the
-//      absolute integral corners from the page and runs the literal float64 sequence.
+//   4. queues what is still undecided (|T - (p-0.5)| ~< 1e-6) for k_corner_partial / k_fixup_final, which
+//      rebuild the absolute integral corners from the page and run the literal float64 sequence.
 // Steps 2-4 make the output bit-identical to the literal pipeline (binarize_literal.hip) while
 // >99.9999 % of pixels only pay for step 2.
 //
-// Memory: 1 B/px read + 1 B/px written to HBM (the algorithmic 2 B/px); window halos and the
-// "leaving" row of the sliding window are re-read from L2.  Bound: HBM; in practice VALU issue
-// (~30 lane-ops/px) is the co-limiter, see DESIGN.md.
+// Memory: 1 B/px read + 1 B/px written to HBM (the algorithmic 2 B/px); window halos, the "leaving" row of
+// the sliding window and the compared-pixel row are re-read through L2 / Infinity Cache (measured 20 GB of
+// fabric traffic per 8.6 GB algorithmic).  Roofline by the metric: HBM; the measured limiter is VALU issue
+// (~630-680 SIMD cycles per 512-column wavefront-row, instruction costs in profiles/r01/valu_issue_costs.txt),
+// see DESIGN.md 4.1.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -68,7 +70,7 @@ struct FusedParams {
     int lane_off;      // (w-1) / 8
     unsigned total_waves;
     float w2f;         // (float)(w*w), exact
-    float c0, c1, c2;  // method constants in float32, pre-multiplied by f and Z (see eval32)
+    float c0, c1;      // method constants in float32, pre-multiplied by f and Z (see eval32)
     float eps1;        // Z * float32 decision margin (covers float32 evaluation + literal rounding noise)
     float vthr32;      // floor on K~ = w^2 Q - S^2 (= variance floor / f^2) below which the float32 test is not trusted
     double vthr;       // same floor for the float64 interval test

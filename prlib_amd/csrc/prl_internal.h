@@ -103,7 +103,6 @@ int literal_run(const ThrParams& tp, const PageSet& src, int first_page, int n_p
                 const PageSetOut& dst, void* scratch, PageGlobals* d_globals, hipStream_t stream);
 
 // ---- fused pipeline (binarize_fused.hip) -------------------------------------------------------
-struct FusedWork;  // opaque
 size_t fused_small_bytes(int n_pages);
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst,
               void* small, PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start,

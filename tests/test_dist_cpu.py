@@ -75,3 +75,23 @@ def test_two_gloo_ranks_equal_one_process(tmp_path):
         for i in rng:
             d.update(oc.binarize(synth.page_numpy(40, 56, index=i), p).tobytes())
         assert d.hexdigest() == got
+
+
+def test_bench_launcher_path_two_ranks_dryrun():
+    """bench.py under `python -m torch.distributed.run --nproc-per-node 2` (gloo on CPU): rendezvous on 127.0.0.1,
+    page sharding, barrier, max/sum reductions and the single JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PRL_BENCH_DRYRUN="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--pages", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d == {"dryrun": True, "n_gpus": 2, "pages_total": 10, "max_rank_plus_1": 2.0, "first_block": [0, 5]}
