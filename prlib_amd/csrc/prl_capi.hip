@@ -117,6 +117,20 @@ int ensure_small(DeviceCtx* ctx, size_t bytes)
     return PRL_OK;
 }
 
+int ensure_stage(DeviceCtx* ctx, size_t bytes)
+{
+    if (ctx->stage_bytes >= bytes) return PRL_OK;
+    if (ctx->stage) {
+        PRL_HIP_CHECK(hipDeviceSynchronize());
+        PRL_HIP_CHECK(hipFree(ctx->stage));
+        ctx->stage = nullptr;
+        ctx->stage_bytes = 0;
+    }
+    PRL_HIP_CHECK(hipMalloc(&ctx->stage, bytes));
+    ctx->stage_bytes = bytes;
+    return PRL_OK;
+}
+
 int ensure_pinned(DeviceCtx* ctx, size_t bytes)
 {
     if (ctx->pinned_bytes >= bytes) return PRL_OK;
@@ -446,6 +460,7 @@ int prl_hip_release_workspace(void)
     int st = current_device(&dev);
     if (st != PRL_OK) return st;
     DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> slk(ctx->stage_mu);  // lock order everywhere: stage_mu, then mu
     std::lock_guard<std::mutex> lk(ctx->mu);
     PRL_HIP_CHECK(hipDeviceSynchronize());
     if (ctx->scratch) PRL_HIP_CHECK(hipFree(ctx->scratch));
@@ -460,6 +475,9 @@ int prl_hip_release_workspace(void)
     if (ctx->pinned) PRL_HIP_CHECK(hipHostFree(ctx->pinned));
     ctx->pinned = nullptr;
     ctx->pinned_bytes = 0;
+    if (ctx->stage) PRL_HIP_CHECK(hipFree(ctx->stage));
+    ctx->stage = nullptr;
+    ctx->stage_bytes = 0;
     return PRL_OK;
 }
 
@@ -559,33 +577,22 @@ int prl_hip_binarize_host(const prl_binarize_params* p, const uint8_t* src, size
 
     const size_t in_pitch = ((size_t)width + 255) / 256 * 256;
     const size_t out_pitch = ((size_t)g.out_w + 255) / 256 * 256;
-    uint8_t* d_in = nullptr;
-    uint8_t* d_out = nullptr;
+    const size_t in_bytes = in_pitch * (size_t)height, out_bytes = out_pitch * (size_t)g.out_h;
+    DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> slk(ctx->stage_mu);  // cached device staging: no hipMalloc/hipFree per page
+    st = ensure_stage(ctx, in_bytes + out_bytes);
+    if (st != PRL_OK) return st;
+    uint8_t* d_in = static_cast<uint8_t*>(ctx->stage);
+    uint8_t* d_out = d_in + in_bytes;
     hipStream_t stream = nullptr;
-    PRL_HIP_CHECK(hipMalloc(&d_in, in_pitch * (size_t)height));
-    hipError_t e = hipMalloc(&d_out, out_pitch * (size_t)g.out_h);
-    if (e != hipSuccess) {
-        (void)hipFree(d_in);
-        return PRL_ERR_NOMEM;
-    }
-    auto cleanup = [&]() {
-        (void)hipFree(d_in);
-        (void)hipFree(d_out);
-    };
-    e = hipMemcpy2D(d_in, in_pitch, src, src_step, (size_t)width, (size_t)height, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy2D(d_in, in_pitch, src, src_step, (size_t)width, (size_t)height, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         set_error_detail(std::string("hipMemcpy2D H2D: ") + hipGetErrorString(e));
-        cleanup();
         return PRL_ERR_HIP;
     }
-    st = prl_hip_binarize_batch_device(p, 1, d_in, in_pitch * (size_t)height, in_pitch, width, height,
-                                       d_out, out_pitch * (size_t)g.out_h, out_pitch, stream);
-    if (st != PRL_OK) {
-        cleanup();
-        return st;
-    }
+    st = prl_hip_binarize_batch_device(p, 1, d_in, in_bytes, in_pitch, width, height, d_out, out_bytes, out_pitch, stream);
+    if (st != PRL_OK) return st;
     e = hipMemcpy2D(dst, dst_step, d_out, out_pitch, (size_t)g.out_w, (size_t)g.out_h, hipMemcpyDeviceToHost);
-    cleanup();
     if (e != hipSuccess) {
         set_error_detail(std::string("hipMemcpy2D D2H: ") + hipGetErrorString(e));
         return PRL_ERR_HIP;

@@ -34,6 +34,9 @@ struct DeviceCtx {
     size_t mask_bytes = 0;
     void* small = nullptr;  // counters / work lists / per-page globals
     size_t small_bytes = 0;
+    std::mutex stage_mu;    // one *_host call at a time per device (taken before `mu`)
+    void* stage = nullptr;  // device staging of the *_host entry points (page in + page out)
+    size_t stage_bytes = 0;
     void* pinned = nullptr; // pinned host staging for tiny transfers
     size_t pinned_bytes = 0;
     int cu_count = 0;
@@ -48,6 +51,7 @@ int ensure_scratch(DeviceCtx* ctx, size_t bytes);
 int ensure_mask(DeviceCtx* ctx, size_t bytes);
 int ensure_small(DeviceCtx* ctx, size_t bytes);
 int ensure_pinned(DeviceCtx* ctx, size_t bytes);
+int ensure_stage(DeviceCtx* ctx, size_t bytes);  // caller holds stage_mu
 
 // ---- page addressing: contiguous batch or table of page pointers ---------------------------------
 struct PageSet {
