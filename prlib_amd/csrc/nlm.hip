@@ -31,7 +31,7 @@ namespace prl_hip {
 namespace {
 
 constexpr int kT = 7, kS = 21, kTH = 3, kSH = 10, kBorder = kTH + kSH;  // 13
-constexpr int TILE_W = 64, ROWS = 16, WAVES = 4, TILE_H = ROWS * WAVES;   // 64 x 64 outputs per workgroup
+constexpr int TILE_W = 64, ROWS = 8, WAVES = 4, TILE_H = ROWS * WAVES;  // 8 rows: 94 VGPRs, 5 waves/SIMD (16 rows: 178 VGPRs, 1.3x slower)   // 64 x 32 outputs per workgroup
 constexpr int EXT_W = TILE_W + 2 * kBorder, EXT_H = TILE_H + 2 * kBorder; // 90 x 90 staged pixels
 constexpr int SB_W = TILE_W + 2 * kSH, SB_H = TILE_H + 2 * kSH;           // 84 x 84 template energies
 constexpr int kLutMax = 1024;  // non-zero LUT entries kept in LDS (h <= ~13 for 1 channel); else global
