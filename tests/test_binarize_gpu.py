@@ -282,3 +282,24 @@ def test_morph_radius_above_eight(prl, oracle, cuda_device, n):
     got = prl.morph(torch.from_numpy(gray).to(cuda_device), n).cpu().numpy()
     assert np.array_equal(got, oracle.morph(gray, n))
     _check(prl, oracle, cuda_device, _pages((120, 150), ["doc", "binary"], seed=43), SAUVOLA, 15, 0.3, n)
+
+
+@pytest.mark.parametrize("method,morph", [(SAUVOLA, 0), (SAUVOLA, 2), (WOLFJOLION, 0), (NICK, -1)])
+def test_unaligned_output_pitch(prl, oracle, cuda_device, method, morph):
+    """cv::Mat outputs are continuous: the row pitch equals out_w (odd for Sauvola/Niblack) — byte-granular stores."""
+    import torch
+
+    pages = _pages((131, 1042), ["doc", "noise"], seed=47)
+    dev_pages = torch.from_numpy(np.stack(pages)).to(cuda_device)
+    p = prl.make_params(method, 31, 0.3, morph)
+    g = prl.geometry(p, 1042, 131)
+    out = torch.zeros((2, g.out_h, g.out_w), dtype=torch.uint8, device=cuda_device)   # pitch == out_w
+    got = prl.binarize(dev_pages, p, out=out).cpu().numpy()
+    po = oracle.make_params(method, 31, 0.3, morph)
+    for i, pg in enumerate(pages):
+        assert np.array_equal(got[i], oracle.binarize(pg, po))
+    # and an input view with a base pointer that is not 8-byte aligned
+    big = torch.zeros((2, 131, 1100), dtype=torch.uint8, device=cuda_device)
+    big[:, :, 3:1045] = dev_pages
+    got2 = prl.binarize(big[:, :, 3:1045], p).cpu().numpy()
+    assert np.array_equal(got2, got)
