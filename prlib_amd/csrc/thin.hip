@@ -22,31 +22,69 @@ namespace prl_hip {
 
 namespace {
 
-// pack: bit = pixel & 1  (imageUnderProcess &= 1, thinZhangSuen.cpp:83)
+// pack: bit = pixel & 1  (imageUnderProcess &= 1, thinZhangSuen.cpp:83).  One thread per 32-pixel word.  Rows of a
+// (W-1)-wide binarizer output are rarely 8-byte aligned, so the thread reads the (up to five) ALIGNED u64 that cover
+// its 32 bytes and funnel-shifts them; an aligned u64 that holds at least one byte of the row never leaves the
+// row's memory page, so the over-read is safe, and bytes past the row end are masked off.
 __global__ void __launch_bounds__(256) k_thin_pack(PageSet src, int width, int height, int wpr, unsigned* __restrict__ bits,
                                                   size_t plane_words)
 {
-    const int page = blockIdx.z, y = blockIdx.y;
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    unsigned b = 0;
-    if (x < width) b = src.page(page)[(size_t)y * src.step + x] & 1u;
-    const unsigned long long m = __ballot(b != 0);
-    const int lane = threadIdx.x & 63;
-    const int w0 = (blockIdx.x * 256 + (threadIdx.x & ~63)) / 32;
-    unsigned* row = bits + (size_t)page * plane_words + (size_t)y * wpr;
-    if (lane == 0 && w0 < wpr) row[w0] = (unsigned)m;
-    if (lane == 32 && w0 + 1 < wpr) row[w0 + 1] = (unsigned)(m >> 32);
+    const int page = blockIdx.y;
+    const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid >= plane_words) return;
+    const int y = (int)(gid / (unsigned)wpr), k = (int)(gid - (unsigned)y * (unsigned)wpr);
+    const uint8_t* p0 = src.page(page) + (size_t)y * src.step + (size_t)k * 32;
+    const int nb = min(32, width - k * 32);           // valid bytes of this word (>= 1)
+    const int a = (int)((size_t)p0 & 7);
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p0 - a);
+    unsigned long long v[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] = (8 * i - a < nb) ? q[i] : 0ull;   // loaded only if it holds a valid byte
+    const int sh = 8 * a;
+    unsigned w = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned long long u = sh ? ((v[i] >> sh) | (v[i + 1] << (64 - sh))) : v[i];
+        // bit 0 of each of the 8 bytes -> 8 adjacent bits (byte j lands on bit j)
+        w |= (unsigned)(((u & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * i);
+    }
+    if (nb < 32) w &= (1u << nb) - 1u;
+    bits[(size_t)page * plane_words + gid] = w;
 }
 
-// unpack: byte = bit * 255  (outputImage = imageUnderProcess * 255, :100-106)
+// unpack: byte = bit * 255  (outputImage = imageUnderProcess * 255, :100-106).  One thread per ALIGNED 32-byte block
+// of the destination row (wpr + 1 blocks per row: the first one may start up to 7 pixels left of the row); its 32
+// bits straddle two plane words.  Whole u64 stores inside the row, byte stores on the two ragged ends.
 __global__ void __launch_bounds__(256) k_thin_unpack(const unsigned* __restrict__ bits, size_t plane_words, int wpr,
                                                     PageSetOut dst, int width, int height)
 {
-    const int page = blockIdx.z, y = blockIdx.y;
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= width) return;
-    const unsigned w = bits[(size_t)page * plane_words + (size_t)y * wpr + (x >> 5)];
-    dst.page(page)[(size_t)y * dst.step + x] = ((w >> (x & 31)) & 1u) ? 255 : 0;
+    const int page = blockIdx.y;
+    const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+    const unsigned bpr = (unsigned)wpr + 1u;
+    if (gid >= bpr * (unsigned)height) return;
+    const int y = (int)(gid / bpr), t = (int)(gid - (unsigned)y * bpr);
+    uint8_t* row = dst.page(page) + (size_t)y * dst.step;
+    const int a = (int)((size_t)row & 7);
+    const int xs = 32 * t - a;                        // first pixel of this block
+    const unsigned* wrow = bits + (size_t)page * plane_words + (size_t)y * wpr;
+    const unsigned lo = (t >= 1) ? wrow[t - 1] : 0u, hi = (t < wpr) ? wrow[t] : 0u;
+    const unsigned w = a ? ((lo >> (32 - a)) | (hi << a)) : hi;   // a == 0: block t is word t
+    if (xs >= width) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // 8 bits -> 8 bytes of 0x00 / 0xFF (bit j to byte j)
+        const unsigned long long b8 = (w >> (8 * i)) & 0xffull;
+        const unsigned long long sel = (b8 * 0x0101010101010101ull) & 0x8040201008040201ull;  // byte j keeps bit j
+        const unsigned long long nz = (sel + 0x7f7f7f7f7f7f7f7full) & 0x8080808080808080ull;  // byte non-zero -> bit 7
+        const unsigned long long o = (nz >> 7) * 255ull;
+        const int x = xs + 8 * i;
+        if (x >= 0 && x + 8 <= width) {
+            *reinterpret_cast<unsigned long long*>(row + x) = o;
+        } else {
+            for (int j = 0; j < 8; ++j)
+                if (x + j >= 0 && x + j < width) row[x + j] = (uint8_t)(o >> (8 * j));
+        }
+    }
 }
 
 // exactly one of the given bit-planes set, per bit
@@ -81,14 +119,17 @@ __global__ void __launch_bounds__(256) k_thin_iter(const unsigned* __restrict__ 
                                                   size_t plane_words, int wpr, int width, int height, int iteration,
                                                   unsigned* __restrict__ changed, const unsigned* __restrict__ done)
 {
-    const int page = blockIdx.z;
+    const int page = blockIdx.y;
     if (done[page]) return;  // converged: its bit plane is final and stays in buffer A
-    const int k = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (k >= wpr || y >= height) return;
+    const unsigned gid = blockIdx.x * 256u + threadIdx.x;  // 32-bit index math (64-bit division is ~10x slower)
+    if (gid >= plane_words) return;
+    const int y = (int)(gid / (unsigned)wpr), k = (int)(gid - (unsigned)y * (unsigned)wpr);
     const unsigned* base = in + (size_t)page * plane_words;
+    // clamped (always valid) addresses, out-of-image words forced to zero afterwards: no divergent branches
     auto word = [&](int yy, int kk) -> unsigned {
-        return (yy < 0 || yy >= height || kk < 0 || kk >= wpr) ? 0u : base[(size_t)yy * wpr + kk];
+        const int yc = min(max(yy, 0), height - 1), kc = min(max(kk, 0), wpr - 1);
+        const unsigned v = base[(size_t)yc * wpr + kc];
+        return (yy == yc && kk == kc) ? v : 0u;
     };
     const unsigned c = word(y, k);
     unsigned res = c;
@@ -138,9 +179,10 @@ __global__ void __launch_bounds__(256) k_thin_iter(const unsigned* __restrict__ 
         if ((last >> 5) == k) col_ok &= ~(1u << (last & 31));
         mark &= col_ok;
         res = c & ~mark;                                         // imageUnderProcessing &= ~marker   :54
-        if (res != c) atomicOr(&changed[page], 1u);
     }
-    out[(size_t)page * plane_words + (size_t)y * wpr + k] = res;
+    out[(size_t)page * plane_words + gid] = res;
+    // one plain store per wave that changed something (every writer stores the same 1: no atomic needed)
+    if (__ballot(res != c) != 0ull && (threadIdx.x & 63) == 0) changed[page] = 1u;
 }
 
 // after both sub-iterations of a pass: a page whose pass changed nothing is final (do-while test, :93-96)
@@ -176,6 +218,7 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
 
     const int wpr = (width + 31) / 32;
     const size_t plane_words = (size_t)wpr * height;
+    if (plane_words >= 0x7fffff00ull) return PRL_ERR_BAD_ARG;  // kernels index a page's words with 32 bits
     const size_t bits_bytes = plane_words * sizeof(unsigned) * (size_t)n_pages;
     const size_t flags_bytes = ((size_t)n_pages * sizeof(unsigned) + 255) / 256 * 256;
     st = ensure_scratch(ctx, 2 * bits_bytes + 2 * flags_bytes);
@@ -196,11 +239,10 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
     pd.base = d_dst;
     pd.page_stride = dst_page_stride;
     pd.step = dst_step;
-    const dim3 gpx((width + 255) / 256, height, n_pages);
-    hipLaunchKernelGGL(k_thin_pack, gpx, dim3(256), 0, s, ps, width, height, wpr, A, plane_words);
+    const dim3 gw((unsigned)((plane_words + 255) / 256), n_pages);  // one thread per 32-pixel word
+    hipLaunchKernelGGL(k_thin_pack, gw, dim3(256), 0, s, ps, width, height, wpr, A, plane_words);
     PRL_HIP_CHECK(hipGetLastError());
 
-    const dim3 git((wpr + 63) / 64, (height + 3) / 4, n_pages);
     std::vector<unsigned> h_done((size_t)n_pages);
     const int max_passes = std::max(width, height) + 2;  // every effective pass removes at least one pixel layer
     const int group = 4;                                 // passes per host check; extra passes change nothing
@@ -210,10 +252,10 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
                 const unsigned* in = it == 0 ? A : B;
                 unsigned* out = it == 0 ? B : A;
                 if (method == PRL_THIN_ZHANGSUEN)
-                    hipLaunchKernelGGL(k_thin_iter<0>, git, dim3(256), 0, s, in, out, plane_words, wpr, width, height, it,
+                    hipLaunchKernelGGL(k_thin_iter<0>, gw, dim3(256), 0, s, in, out, plane_words, wpr, width, height, it,
                                        changed, done);
                 else
-                    hipLaunchKernelGGL(k_thin_iter<1>, git, dim3(256), 0, s, in, out, plane_words, wpr, width, height, it,
+                    hipLaunchKernelGGL(k_thin_iter<1>, gw, dim3(256), 0, s, in, out, plane_words, wpr, width, height, it,
                                        changed, done);
                 PRL_HIP_CHECK(hipGetLastError());
             }
@@ -224,7 +266,8 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
         PRL_HIP_CHECK(hipStreamSynchronize(s));
         if (std::all_of(h_done.begin(), h_done.end(), [](unsigned v) { return v != 0; })) break;
     }
-    hipLaunchKernelGGL(k_thin_unpack, gpx, dim3(256), 0, s, A, plane_words, wpr, pd, width, height);
+    const dim3 gu((unsigned)(((size_t)(wpr + 1) * height + 255) / 256), n_pages);  // one thread per aligned 32-byte block
+    hipLaunchKernelGGL(k_thin_unpack, gu, dim3(256), 0, s, A, plane_words, wpr, pd, width, height);
     PRL_HIP_CHECK(hipGetLastError());
     PRL_HIP_CHECK(hipEventRecord(ctx->last_use, s));
     return PRL_OK;

@@ -70,3 +70,23 @@ def test_thinning_full_page(prl, oracle, cuda_device):
     img = np.where(page < 150, 255, 0).astype(np.uint8)
     got = prl.thinGuoHall(torch.from_numpy(img).to(cuda_device)).cpu().numpy()
     assert np.array_equal(got, oracle.thin(img, 1))
+
+
+@pytest.mark.parametrize("off", [1, 3, 5, 8])
+def test_thinning_strided_views_keep_their_surroundings(prl, oracle, cuda_device, off):
+    """ROI-style views (unaligned rows, step > width): aligned over-reads must not leak in, nothing may be written outside."""
+    import torch
+
+    h, w = 70, 123
+    img = _mask((h, w), seed=4, kind="blobs") | _mask((h, w), seed=5, kind="doc")
+    src = torch.full((2, h + 2, w + 16), 255, dtype=torch.uint8, device=cuda_device)   # odd surroundings = foreground
+    dst = torch.full((2, h + 2, w + 16), 7, dtype=torch.uint8, device=cuda_device)
+    src[:, 1:h + 1, off:off + w] = torch.from_numpy(img).to(cuda_device)
+    prl.thinGuoHall(src[:, 1:h + 1, off:off + w], out=dst[:, 1:h + 1, off:off + w])
+    got = dst.cpu().numpy()
+    want = oracle.thin(img, 1)
+    for i in range(2):
+        assert np.array_equal(got[i, 1:h + 1, off:off + w], want)
+        guard = got[i].copy()
+        guard[1:h + 1, off:off + w] = 7
+        assert (guard == 7).all()
