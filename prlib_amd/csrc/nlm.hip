@@ -7,21 +7,24 @@
 //   offsets, `>> 6` binning, host-built weight LUT, int32 accumulation, rounding division), so the
 //   device result is bit-identical to the CPU restatement given the same LUT.
 //
-// Kernel shape (k_nlm).  NL-means is ALU-bound by construction (441 offsets x 49 taps per pixel and
-// channel against 2 B/px of traffic), so the design minimises instructions per (pixel, offset):
-//   - a workgroup stages a 64x64 tile plus its 13-pixel reflect-101 halo in LDS as raw bytes, plus
-//     SB(pos) = sum over the 7x7 template around pos of E^2 (int32) and the non-zero part of the LUT;
-//   - SSD = SA + SB - 2*AB with AB = sum over the template of E(p+t)*E(q+t).  A thread owns one column
-//     and walks down 16 output rows per offset; the 7 horizontally adjacent template taps are 7
-//     consecutive bytes of one LDS row, so one (unaligned) wide LDS read per side and V_DOT4_U32_U8
-//     gives a whole template row of AB in 2 instructions per channel-dword; the vertical 7-row sum is a
-//     sliding sum in registers (ring of 7).  No cross-lane traffic, ~13 VALU instructions per
-//     (pixel, offset) for one channel.
-// Roofline: bound by integer VALU issue, not HBM; bench reports the HBM fraction because the metric
-// asks for it (algorithmic 2 B/px per plane byte) and states the ALU bound next to it.
+// Kernel shape (k_nlm_y for 1 and 2 channels, k_nlm for 3).  NL-means is ALU-bound by construction (441 offsets x
+// 49 taps per pixel and channel against 2 B/px of traffic), so the design minimises instructions and LDS cycles
+// per (pixel, offset):
+//   - a workgroup owns a 64x32 output tile (4 wavefronts x 8 rows); it stages the tile plus its 13-pixel
+//     reflect-101 halo in LDS EXPANDED to one 8-byte element per pixel position (the 8 bytes that start there),
+//     plus SB(pos) = sum over the 7x7 template around pos of E^2 (int32) and the non-zero part of the LUT;
+//   - SSD = SA + SB - 2*AB with AB = sum over the template of E(p+t)*E(q+t).  A thread owns one column and walks
+//     down 8 output rows per offset; the 7 horizontally adjacent template taps of the other patch are ONE
+//     conflict-free ds_read_b64, the own side stays in registers, V_DOT4_U32_U8 accumulates a template row in 2
+//     instructions per channel, the 14 row dots are chained through the dot accumulator (prefix sums) so the
+//     vertical 7-row window is one subtraction per output, and 2-3 offsets are processed together so that
+//     independent chains interleave.  ~37 VALU instructions per (wavefront row, offset) for one channel.
+// Roofline: bound by integer VALU issue (and, before the expanded layout, by LDS cycles), not HBM; bench reports
+// the HBM fraction because the metric asks for it (algorithmic 2 B/px per plane byte) and states the ALU bound.
 #include <algorithm>
 #include <cmath>
 #include <climits>
+#include <type_traits>
 #include <vector>
 
 #include "prl_internal.h"
@@ -55,8 +58,7 @@ struct Nb {  // the 7-pixel horizontal neighbourhood of one position: 7*CH bytes
     unsigned d[NB];
 };
 
-// Neighbourhood at an arbitrary byte address: NB+1 ALIGNED dword reads + byte funnel shifts.  (Unaligned
-// wide ds_read is legal on gfx950 but measured several times slower than this in k_morph_binary.)
+// Neighbourhood at an arbitrary byte address of ONE copy: NB+1 aligned dword reads + byte funnel shifts.
 template <int CH>
 __device__ __forceinline__ Nb<CH> lds_nb(const unsigned* base, unsigned sh)
 {
@@ -78,14 +80,77 @@ __device__ __forceinline__ unsigned dot_nb(const Nb<CH>& a, const Nb<CH>& b, uns
     return acc;
 }
 
+// ---- k_nlm_y (1 and 2 channels: the two planes prl::denoise filters) ------------------------------------------
+// The kernel is LDS-bound (SQ_LDS_IDX_ACTIVE ~ 93 % of the CU cycles in the first version), so the staged tile is
+// kept EXPANDED: element P of a row is the 8 bytes starting at pixel P (u64).  A lane's neighbourhood is then one
+// 8-byte-aligned ds_read_b64 (two for the 14-byte ab neighbourhood: elements P and P+4), consecutive lanes read
+// consecutive elements = all 64 banks exactly once for every offset, and no funnel shifts are needed.  (Byte-
+// shifted copies read with ds_read2_b32 gave a 2-way bank conflict for 3 of 4 alignments.)
+// LUT_LDS: the non-zero part of the weight table fits the LDS copy (always, for prl::denoise's h range); the
+// other instantiation reads it from memory.  A run-time choice inside the loop made the compiler issue both loads.
 template <int CH>
-__global__ void __launch_bounds__(256) k_nlm(PageSet src, PageSetOut dst, NlmParams np)
+struct YGeo {
+    static constexpr int NE = CH;                              // u64 elements per neighbourhood (8 / 16 bytes >= 7 / 14)
+    static constexpr int YP = EXT_W + (CH == 2 ? 4 : 0);       // elements per staged row
+    static constexpr int RAWP = (EXT_W * CH + 24) / 4 * 4;     // raw bytes per row, zero padded (elements overrun the row)
+    static constexpr int SB_BYTES = SB_H * SB_W * 4, RAW_BYTES = EXT_H * RAWP;
+    static constexpr int SBRAW_WORDS = (SB_BYTES > RAW_BYTES ? SB_BYTES : RAW_BYTES) / 4 + 4;
+    // last dword of a neighbourhood: keep the bytes below 7*CH
+    static constexpr unsigned kLastMask = CH == 1 ? 0x00ffffffu : 0x0000ffffu;
+};
+
+template <int CH>
+struct NbY {
+    uint2 e[YGeo<CH>::NE];
+};
+
+template <int CH>
+__device__ __forceinline__ NbY<CH> y_nb(const uint2* p)
 {
-    constexpr int NB = Nb<CH>::NB;
-    constexpr int PITCH = (EXT_W * CH + 16 + 3) / 4 * 4;  // bytes per staged row (+16: the dword reads overrun the row)
-    __shared__ __attribute__((aligned(16))) unsigned char tile[EXT_H * PITCH + 32];
-    __shared__ int sb[SB_H * SB_W];
-    __shared__ int lut_s[kLutMax + 1];
+    NbY<CH> v;
+    v.e[0] = p[0];
+    if (CH == 2) v.e[1] = p[4];
+    return v;
+}
+
+template <int CH>
+__device__ __forceinline__ NbY<CH> y_mask(NbY<CH> v)
+{
+    v.e[CH - 1].y &= YGeo<CH>::kLastMask;
+    return v;
+}
+
+template <int CH>
+__device__ __forceinline__ unsigned y_dot(const NbY<CH>& a, const NbY<CH>& b, unsigned acc)
+{
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        acc = __builtin_amdgcn_udot4(a.e[k].x, b.e[k].x, acc, false);
+        acc = __builtin_amdgcn_udot4(a.e[k].y, b.e[k].y, acc, false);
+    }
+    return acc;
+}
+
+// a - b kept as its own v_sub_u32: the empty asm hides the value, so the compiler cannot re-form a - 2b as
+// shift-left + add3.  (A hand-written "v_sub_u32" in the asm is NOT safe here: gfx950 needs wait states between a
+// v_dot4 write and a different VALU read of that register, and the hazard pass does not look inside inline asm.)
+__device__ __forceinline__ unsigned sub_keep(unsigned a, unsigned b)
+{
+    unsigned d = a - b;
+    asm("" : "+v"(d));
+    return d;
+}
+
+template <int CH, bool LUT_LDS>
+__global__ void __launch_bounds__(256) k_nlm_y(PageSet src, PageSetOut dst, NlmParams np)
+{
+    using G = YGeo<CH>;
+    constexpr int YP = G::YP, RAWP = G::RAWP;
+    __shared__ __attribute__((aligned(16))) uint2 ytile[EXT_H * YP];
+    __shared__ __attribute__((aligned(16))) unsigned sbraw[G::SBRAW_WORDS];   // raw bytes while staging, then SB
+    __shared__ int lut_s[LUT_LDS ? kLutMax + 1 : 1];
+    unsigned char* raw = reinterpret_cast<unsigned char*>(sbraw);
+    int* sb = reinterpret_cast<int*>(sbraw);
 
     const int page = blockIdx.z;
     const uint8_t* __restrict__ img = src.page(page);
@@ -93,7 +158,172 @@ __global__ void __launch_bounds__(256) k_nlm(PageSet src, PageSetOut dst, NlmPar
     const int W = np.width, H = np.height;
     const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
 
-    // stage the tile with its reflect-101 halo (copyMakeBorder(BORDER_DEFAULT) by 13)
+    // raw tile with its reflect-101 halo (copyMakeBorder(BORDER_DEFAULT) by 13), zero padded rows
+    for (int i = threadIdx.x; i < EXT_H * EXT_W; i += blockDim.x) {
+        const int r = i / EXT_W, c = i - r * EXT_W;
+        const int sy = reflect101(y0 - kBorder + r, H), sx = reflect101(x0 - kBorder + c, W);
+        const uint8_t* s = img + (size_t)sy * src.step + (size_t)sx * CH;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) raw[r * RAWP + c * CH + k] = s[k];
+    }
+    for (int i = threadIdx.x; i < EXT_H * (RAWP - EXT_W * CH); i += blockDim.x) {
+        const int r = i / (RAWP - EXT_W * CH), c = i - r * (RAWP - EXT_W * CH);
+        raw[r * RAWP + EXT_W * CH + c] = 0;
+    }
+    if (LUT_LDS)
+        for (int i = threadIdx.x; i <= kLutMax; i += blockDim.x) lut_s[i] = (i < np.n_lut) ? np.lut[i] : 0;
+    __syncthreads();
+
+    // expand: element (r, k) = raw bytes [k*CH, k*CH + 8) of row r
+    for (int i = threadIdx.x; i < EXT_H * YP; i += blockDim.x) {
+        const int r = i / YP, k = i - r * YP;
+        const unsigned P = (unsigned)(k * CH);
+        const unsigned* q = reinterpret_cast<const unsigned*>(raw + r * RAWP + (P & ~3u));
+        const unsigned w0 = q[0], w1 = q[1], w2 = q[2];
+        ytile[i] = make_uint2(__builtin_amdgcn_alignbyte(w1, w0, P & 3u), __builtin_amdgcn_alignbyte(w2, w1, P & 3u));
+    }
+    __syncthreads();
+
+    // SB(r, c) = sum over the 7x7 template centred at staged position (r + 3, c + 3) of E^2: one thread per
+    // column and third of the rows, a horizontal dot per row and a sliding vertical sum of seven of them
+    {
+        constexpr int CHR = (SB_H + 2) / 3;  // rows per thread
+        if (threadIdx.x < 3 * SB_W) {
+            const int c = threadIdx.x % SB_W, rb = (threadIdx.x / SB_W) * CHR;
+            unsigned ring[kT];
+            unsigned acc = 0;
+#pragma unroll
+            for (int i = 0; i < CHR + kT - 1; ++i) {
+                const int rr = min(rb + i, EXT_H - 1);  // rows past the tile are never stored
+                const NbY<CH> a = y_nb<CH>(ytile + rr * YP + c);
+                const unsigned hd = y_dot<CH>(y_mask<CH>(a), a, 0u);
+                acc += hd;
+                if (i >= kT) acc -= ring[i % kT];
+                ring[i % kT] = hd;
+                if (i >= kT - 1 && rb + i - (kT - 1) < SB_H) sb[(rb + i - (kT - 1)) * SB_W + c] = (int)acc;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int oy0 = wv * ROWS;  // first output row of this wavefront inside the tile
+    // staged coordinates: output (oy, lane) sits at staged (oy + 13, lane + 13); its template row ty starts at
+    // staged column lane + 10 = element index lane + 10.
+    const uint2* abase = ytile + (oy0 + kSH) * YP + (lane + kSH);
+    const int* sa_base = sb + (oy0 + kSH) * SB_W + (lane + kSH);
+
+    // own side, once: template energies and the 14 neighbourhood rows (padding bytes zeroed) stay in registers
+    int SA[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) SA[i] = sa_base[i * SB_W];
+    NbY<CH> A[ROWS + kT - 1];
+#pragma unroll
+    for (int r = 0; r < ROWS + kT - 1; ++r) A[r] = y_mask<CH>(y_nb<CH>(abase + r * YP));
+
+    unsigned est[ROWS][CH], wsum[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        wsum[i] = 0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) est[i][k] = 0;
+    }
+
+    // NO offsets at a time: their dot chains are independent, which keeps the vector ALU fed at the 2-3
+    // wavefronts per SIMD the LDS footprint allows
+    const unsigned dmax = (unsigned)np.n_lut * 64u;
+    auto offsets = [&](int o, auto no_tag) {
+        constexpr int NO = decltype(no_tag)::value;
+        const uint2* bbase[NO];
+        const int* sb_o[NO];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            const int dy = (o + j) / kS - kSH, dx = (o + j) - ((o + j) / kS) * kS - kSH;
+            bbase[j] = abase + dy * YP + dx;
+            sb_o[j] = sa_base + dy * SB_W + dx;
+        }
+        // P[r] = sum of the row dots 0..r, chained through the dot accumulator; AB(i) = P[i+6] - P[i-1]
+        unsigned P[NO][ROWS + kT - 1];
+        unsigned cen[NO][ROWS + kT - 1];
+        unsigned acc[NO];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) acc[j] = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS + kT - 1; ++r) {
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                const NbY<CH> b = y_nb<CH>(bbase[j] + r * YP);
+                acc[j] = y_dot<CH>(A[r], b, acc[j]);
+                P[j][r] = acc[j];
+                // centre pixel of the other patch's row r: bytes 3*CH .. 4*CH-1 of its neighbourhood
+                cen[j][r] = CH == 1 ? b.e[0].x : b.e[0].y;
+            }
+            if (r >= kT - 1) {
+                const int i = r - (kT - 1);  // output row; its centre row was fetched at step i + 3 = r - 3
+#pragma unroll
+                for (int j = 0; j < NO; ++j) {
+                    const unsigned AB = i == 0 ? P[j][r] : P[j][r] - P[j][i - 1];
+                    // D = SA + SB - 2 AB >= 0.  Two subtractions and shift-right + mask instead of shift-left forms:
+                    // on gfx950 v_lshlrev / v_add3 / v_lshl_add issue in 4 cycles, v_sub / v_lshrrev / v_and in 2
+                    // (profiles/r01/valu_issue_costs.txt)
+                    unsigned D = (unsigned)(SA[i] + sb_o[j][i * SB_W]);
+                    D = sub_keep(D, AB);
+                    D = sub_keep(D, AB);
+                    D = min(D, dmax);            // entries from n_lut on are zero
+                    // byte offset of entry D >> 6 (almost_template_window_size_sq_bin_shift_)
+                    const unsigned boff = (D >> 4) & ~3u;
+                    const unsigned wgt = LUT_LDS ? *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(lut_s) + boff)
+                                                 : *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(np.lut) + boff);
+                    wsum[i] += wgt;
+                    const unsigned cw = cen[j][r - 3];
+                    if (CH == 1) {
+                        est[i][0] += __umul24(wgt, cw >> 24);           // wgt <= 19096, byte: 24-bit mad
+                    } else {
+                        est[i][0] += __umul24(wgt, (cw >> 16) & 0xffu);
+                        est[i][CH - 1] += __umul24(wgt, cw >> 24);
+                    }
+                }
+            }
+        }
+    };
+    constexpr int kPair = CH == 1 ? 3 : 2;  // measured: 1 -> 28.4 / 40.5 ms, 2 -> 18.2 / 27.2, 3 -> 17.8 / 27.6 (L / ab, 8 x 4K pages)
+#pragma unroll 1
+    for (int o = 0; o + kPair <= kS * kS; o += kPair) offsets(o, std::integral_constant<int, kPair>{});
+#pragma unroll 1
+    for (int o = (kS * kS) / kPair * kPair; o < kS * kS; ++o) offsets(o, std::integral_constant<int, 1>{});
+
+    // divByWeightsSum + saturate_cast<uchar>
+    const int gx = x0 + lane;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int gy = y0 + oy0 + i;
+        if (gx < W && gy < H) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const unsigned v = (est[i][k] + wsum[i] / 2u) / wsum[i];
+                out[(size_t)gy * dst.step + (size_t)gx * CH + k] = (uint8_t)(v > 255u ? 255u : v);
+            }
+        }
+    }
+}
+
+// ---- generic kernel (3 interleaved channels; fastNlMeansDenoising on a colour image, not on the prl::denoise
+// path): one byte tile, neighbourhoods by aligned dword reads + funnel shifts --------------------------------
+template <int CH, bool LUT_LDS>
+__global__ void __launch_bounds__(256) k_nlm(PageSet src, PageSetOut dst, NlmParams np)
+{
+    constexpr int NB = Nb<CH>::NB;
+    constexpr int PITCH = (EXT_W * CH + 16 + 3) / 4 * 4;  // bytes per staged row (+16: the dword reads overrun the row)
+    __shared__ __attribute__((aligned(16))) unsigned char tile[EXT_H * PITCH + 32];
+    __shared__ int sb[SB_H * SB_W];
+    __shared__ int lut_s[LUT_LDS ? kLutMax + 1 : 1];
+
+    const int page = blockIdx.z;
+    const uint8_t* __restrict__ img = src.page(page);
+    uint8_t* __restrict__ out = dst.page(page);
+    const int W = np.width, H = np.height;
+    const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+
     for (int i = threadIdx.x; i < EXT_H * EXT_W; i += blockDim.x) {
         const int r = i / EXT_W, c = i - r * EXT_W;
         const int sy = reflect101(y0 - kBorder + r, H), sx = reflect101(x0 - kBorder + c, W);
@@ -105,36 +335,48 @@ __global__ void __launch_bounds__(256) k_nlm(PageSet src, PageSetOut dst, NlmPar
         const int r = i / (PITCH - EXT_W * CH), c = i - r * (PITCH - EXT_W * CH);
         tile[r * PITCH + EXT_W * CH + c] = 0;
     }
-    const int n_lut_s = min(np.n_lut, kLutMax);
-    for (int i = threadIdx.x; i <= n_lut_s; i += blockDim.x) lut_s[i] = (i < np.n_lut) ? np.lut[i] : 0;
+    for (int i = threadIdx.x; i < 32; i += blockDim.x) tile[EXT_H * PITCH + i] = 0;
+    if (LUT_LDS)
+        for (int i = threadIdx.x; i <= kLutMax; i += blockDim.x) lut_s[i] = (i < np.n_lut) ? np.lut[i] : 0;
     __syncthreads();
 
-    // SB(r, c) = sum over the 7x7 template centred at staged position (r + 3, c + 3) of E^2
-    for (int i = threadIdx.x; i < SB_H * SB_W; i += blockDim.x) {
-        const int r = i / SB_W, c = i - r * SB_W;
-        unsigned s = 0;
-        for (int ty = 0; ty < kT; ++ty) {
-            const unsigned char* p = tile + (r + ty) * PITCH + c * CH;
-            for (int k = 0; k < kT * CH; ++k) s += (unsigned)p[k] * p[k];
+    constexpr unsigned kPadBytes = NB * 4 - 7 * CH;
+    constexpr unsigned kLastMask = kPadBytes == 0 ? 0xffffffffu : (0xffffffffu >> (8 * kPadBytes));
+    {
+        constexpr int CHR = (SB_H + 2) / 3;
+        if (threadIdx.x < 3 * SB_W) {
+            const int c = threadIdx.x % SB_W, rb = (threadIdx.x / SB_W) * CHR;
+            const unsigned char* p = tile + c * CH;
+            const unsigned sh = (unsigned)(p - tile) & 3u;
+            const unsigned* pw = reinterpret_cast<const unsigned*>(p - sh);
+            unsigned ring[kT];
+            unsigned acc = 0;
+#pragma unroll
+            for (int i = 0; i < CHR + kT - 1; ++i) {
+                const int rr = min(rb + i, EXT_H - 1);
+                const Nb<CH> a = lds_nb<CH>(pw + rr * (PITCH / 4), sh);
+                Nb<CH> m = a;
+                m.d[NB - 1] &= kLastMask;
+                const unsigned hd = dot_nb<CH>(m, a, 0u);
+                acc += hd;
+                if (i >= kT) acc -= ring[i % kT];
+                ring[i % kT] = hd;
+                if (i >= kT - 1 && rb + i - (kT - 1) < SB_H) sb[(rb + i - (kT - 1)) * SB_W + c] = (int)acc;
+            }
         }
-        sb[i] = (int)s;
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int oy0 = wv * ROWS;  // first output row of this wavefront inside the tile
-    // staged coordinates: output (oy, lane) sits at staged (oy + 13, lane + 13); its template row ty
-    // starts at staged column lane + 10.
-    const unsigned char* abase = tile + (oy0 + kSH) * PITCH + (lane + kSH) * CH;  // template row 0 of output row 0
+    const int oy0 = wv * ROWS;
+    const int aoff = (oy0 + kSH) * PITCH + (lane + kSH) * CH;  // byte offset of template row 0 of output row 0
     const int* sa_base = sb + (oy0 + kSH) * SB_W + (lane + kSH);
-    const unsigned ash = (unsigned)(abase - tile) & 3u;
-    const unsigned* aword = reinterpret_cast<const unsigned*>(abase - ash);
+    const unsigned ash = (unsigned)aoff & 3u;
+    const unsigned* aword = reinterpret_cast<const unsigned*>(tile + (aoff - (int)ash));
 
-    // own-pixel template energies
     int SA[ROWS];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) SA[i] = sa_base[i * SB_W];
-
     unsigned est[ROWS][CH], wsum[ROWS];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
@@ -142,17 +384,13 @@ __global__ void __launch_bounds__(256) k_nlm(PageSet src, PageSetOut dst, NlmPar
 #pragma unroll
         for (int k = 0; k < CH; ++k) est[i][k] = 0;
     }
-    // mask that zeroes the padding bytes of the last neighbourhood dword on the own side
-    constexpr unsigned kPadBytes = NB * 4 - 7 * CH;
-    constexpr unsigned kLastMask = kPadBytes == 0 ? 0xffffffffu : (0xffffffffu >> (8 * kPadBytes));
-    const bool lut_in_lds = np.n_lut <= kLutMax;
 
 #pragma unroll 1
     for (int o = 0; o < kS * kS; ++o) {
         const int dy = o / kS - kSH, dx = o - (o / kS) * kS - kSH;
-        const unsigned char* bbase = abase + dy * PITCH + dx * CH;
-        const unsigned bsh = (unsigned)(bbase - tile) & 3u;
-        const unsigned* bword = reinterpret_cast<const unsigned*>(bbase - bsh);
+        const int boff = aoff + dy * PITCH + dx * CH;
+        const unsigned bsh = (unsigned)boff & 3u;
+        const unsigned* bword = reinterpret_cast<const unsigned*>(tile + (boff - (int)bsh));
         const int* sb_o = sa_base + dy * SB_W + dx;
         unsigned ring[kT];
         unsigned qring[4][CH];
@@ -160,32 +398,30 @@ __global__ void __launch_bounds__(256) k_nlm(PageSet src, PageSetOut dst, NlmPar
 #pragma unroll
         for (int r = 0; r < ROWS + kT - 1; ++r) {
             Nb<CH> a = lds_nb<CH>(aword + r * (PITCH / 4), ash);
-            const Nb<CH> b = lds_nb<CH>(bword + r * (PITCH / 4), bsh);
             a.d[NB - 1] &= kLastMask;
+            const Nb<CH> b = lds_nb<CH>(bword + r * (PITCH / 4), bsh);
             const unsigned hd = dot_nb<CH>(a, b, 0u);
             AB += hd;
             if (r >= kT) AB -= ring[r % kT];
             ring[r % kT] = hd;
-            // centre pixel of the other patch's row r: bytes 3*CH .. 4*CH-1 of its neighbourhood
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 const int byte = 3 * CH + k;
                 qring[r % 4][k] = (b.d[byte / 4] >> (8 * (byte % 4))) & 0xffu;
             }
             if (r >= kT - 1) {
-                const int i = r - (kT - 1);  // output row; its centre row was fetched at step i + 3 = r - 3
+                const int i = r - (kT - 1);
                 const int D = SA[i] + sb_o[i * SB_W] - 2 * (int)AB;
-                int idx = D >> 6;            // almost_template_window_size_sq_bin_shift_
+                int idx = D >> 6;
                 idx = min(idx, np.n_lut);
-                const unsigned wgt = (unsigned)(lut_in_lds ? lut_s[idx] : np.lut[idx]);
+                const unsigned wgt = (unsigned)(LUT_LDS ? lut_s[idx] : np.lut[idx]);
                 wsum[i] += wgt;
 #pragma unroll
-                for (int k = 0; k < CH; ++k) est[i][k] += wgt * qring[(r - 3) % 4][k];
+                for (int k = 0; k < CH; ++k) est[i][k] += __umul24(wgt, qring[(r - 3) % 4][k]);
             }
         }
     }
 
-    // divByWeightsSum + saturate_cast<uchar>
     const int gx = x0 + lane;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
@@ -366,7 +602,16 @@ template <int CH>
 int launch_nlm(const PageSet& src, const PageSetOut& dst, int n_pages, const NlmParams& np, hipStream_t stream)
 {
     const dim3 grid((np.width + TILE_W - 1) / TILE_W, (np.height + TILE_H - 1) / TILE_H, n_pages);
-    hipLaunchKernelGGL((k_nlm<CH>), grid, dim3(256), 0, stream, src, dst, np);
+    const bool lds_lut = np.n_lut <= kLutMax;
+    if (CH <= 2) {
+        constexpr int C = CH <= 2 ? CH : 1;
+        if (lds_lut) hipLaunchKernelGGL((k_nlm_y<C, true>), grid, dim3(256), 0, stream, src, dst, np);
+        else hipLaunchKernelGGL((k_nlm_y<C, false>), grid, dim3(256), 0, stream, src, dst, np);
+    } else {
+        constexpr int C = CH > 2 ? CH : 3;
+        if (lds_lut) hipLaunchKernelGGL((k_nlm<C, true>), grid, dim3(256), 0, stream, src, dst, np);
+        else hipLaunchKernelGGL((k_nlm<C, false>), grid, dim3(256), 0, stream, src, dst, np);
+    }
     PRL_HIP_CHECK(hipGetLastError());
     return PRL_OK;
 }
