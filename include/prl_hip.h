@@ -214,6 +214,49 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
 int prl_hip_thin_host(int method, const uint8_t* src, size_t src_step, int width, int height,
                       uint8_t* dst, size_t dst_step);
 
+/* ---- channel adapters and the device-resident chain ---------------------- */
+
+/*
+ * cv::cvtColor(src, dst, cv::COLOR_BGR2GRAY) on 8-bit BGR (channels = 3) / BGRA (4) pages already in device
+ * memory: the first call of every binarizer for a colour input (src/binarizations/binarizeSauvola.cpp:51, same
+ * line in the other four; src/thinning/thinZhangSuen.cpp:78).  14-bit fixed point, bit-exact.
+ */
+int prl_hip_bgr2gray_batch_device(int n_pages, int channels, const uint8_t* d_src, size_t src_page_stride,
+                                  size_t src_step, int width, int height, uint8_t* d_dst, size_t dst_page_stride,
+                                  size_t dst_step, void* stream);
+
+/* cv::cvtColor(COLOR_GRAY2BGR / GRAY2BGRA): what a caller needs in front of prl::denoise, which only accepts
+ * 3/4-channel input (src/denoise/denoiseNLM.cpp:31 -> fastNlMeansDenoisingColored). */
+int prl_hip_gray2bgr_batch_device(int n_pages, int channels, const uint8_t* d_src, size_t src_page_stride,
+                                  size_t src_step, int width, int height, uint8_t* d_dst, size_t dst_page_stride,
+                                  size_t dst_step, void* stream);
+
+/* cv::bitwise_not on 1-channel pages (d_src == d_dst allowed): the binarizers emit white = background while
+ * prl::thinZhangSuen thins white (src/thinning/thinZhangSuen.cpp:85). */
+int prl_hip_invert_batch_device(int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                                int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                                void* stream);
+
+#define PRL_CHAIN_NO_THINNING (-1)
+
+/* One page through prl::denoise -> cvtColor -> prl::binarize* -> bitwise_not -> prl::thin* (BASELINE config 5 without
+ * deskew and background normalisation).  Not a function of the reference: a caller writes these calls one after the
+ * other; here the intermediates stay in device memory. */
+typedef struct prl_chain_params {
+    int denoise;                   /* != 0: prl::denoise(denoise_strength) first; needs a 3/4-channel input */
+    float denoise_strength;        /* src/denoise/denoiseNLM.h:32 default 5.5 */
+    prl_binarize_params binarize;  /* which binarizer and its arguments */
+    int thin;                      /* PRL_CHAIN_NO_THINNING, PRL_THIN_ZHANGSUEN or PRL_THIN_GUOHALL */
+} prl_chain_params;
+
+void prl_hip_default_chain_params(prl_chain_params* out);
+
+/* d_dst: out_w x out_h bytes per page (prl_hip_binarize_geometry): the binarizer's mask, or, with thinning, the
+ * skeleton of the dark strokes (white on black).  Synchronises `stream` where the stages do. */
+int prl_hip_chain_batch_device(const prl_chain_params* params, int n_pages, int channels, const uint8_t* d_src,
+                               size_t src_page_stride, size_t src_step, int width, int height, uint8_t* d_dst,
+                               size_t dst_page_stride, size_t dst_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

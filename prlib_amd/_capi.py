@@ -33,6 +33,8 @@ EXPORTED_SYMBOLS = [
     "prl_hip_binarize_batch_device", "prl_hip_binarize_pages_device", "prl_hip_binarize_host",
     "prl_hip_morph_batch_device", "prl_hip_nlm_planes_device", "prl_hip_denoise_batch_device",
     "prl_hip_denoise_host", "prl_hip_thin_batch_device", "prl_hip_thin_host",
+    "prl_hip_bgr2gray_batch_device", "prl_hip_gray2bgr_batch_device", "prl_hip_invert_batch_device",
+    "prl_hip_default_chain_params", "prl_hip_chain_batch_device",
 ]
 
 
@@ -50,6 +52,12 @@ class BinarizeParams(C.Structure):
         ("feng_k2", C.c_double),
         ("feng_gamma", C.c_double),
     ]
+
+
+class ChainParams(C.Structure):
+    """struct prl_chain_params."""
+
+    _fields_ = [("denoise", C.c_int32), ("denoise_strength", C.c_float), ("binarize", BinarizeParams), ("thin", C.c_int32)]
 
 
 class BinarizeGeometry(C.Structure):
@@ -105,6 +113,12 @@ def lib() -> C.CDLL:
         L.prl_hip_denoise_host.argtypes = [i, C.c_float, vp, sz, i, i, vp, sz]
         L.prl_hip_thin_batch_device.argtypes = [i, i, vp, sz, sz, i, i, vp, sz, sz, vp]
         L.prl_hip_thin_host.argtypes = [i, vp, sz, i, i, vp, sz]
+        L.prl_hip_bgr2gray_batch_device.argtypes = [i, i, vp, sz, sz, i, i, vp, sz, sz, vp]
+        L.prl_hip_gray2bgr_batch_device.argtypes = [i, i, vp, sz, sz, i, i, vp, sz, sz, vp]
+        L.prl_hip_invert_batch_device.argtypes = [i, vp, sz, sz, i, i, vp, sz, sz, vp]
+        L.prl_hip_default_chain_params.argtypes = [P(ChainParams)]
+        L.prl_hip_default_chain_params.restype = None
+        L.prl_hip_chain_batch_device.argtypes = [P(ChainParams), i, i, vp, sz, sz, i, i, vp, sz, sz, vp]
         _lib = L
     return _lib
 

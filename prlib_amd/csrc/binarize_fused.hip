@@ -100,6 +100,12 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v)
     return (unsigned)x;
 }
 
+// value held by lane + 1 (0 beyond the wavefront): DPP wave_shl:1
+__device__ __forceinline__ unsigned lane_up1(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+}
+
 __device__ __forceinline__ unsigned byte_of(uint2 v, int c)
 {
     const unsigned w = c < 4 ? v.x : v.y;
@@ -315,8 +321,12 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             if (EDGE && !SWEEP) pv = apply_edge(pv, ep.sh);
         }
 
-        // horizontal window sums: E = exclusive prefix over the strip, S(j0) = E(j0+w-1) - E(j0)
+        // horizontal window sums: S(j0) = E(j0+w-1) - E(j0) with E the exclusive prefix of the column sums.
+        // No wavefront-wide scan is needed: with RAW in-lane prefixes the difference between this lane and the lane
+        // that holds the far edge is E_far[sub] - E_own[c] + W, W = totals of the lanes in between (`lane_off` of
+        // them, one more for the columns whose far edge lies a lane further), gathered by DPP wave_shl:1 steps.
         unsigned ES[CPL], EQ[CPL];
+        unsigned tot_s, tot_q;
         {
             unsigned accs = 0, accq = 0;
 #pragma unroll
@@ -326,21 +336,35 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                 accs += VS[c];
                 accq += VQ[c];
             }
-            const unsigned bs = wave_scan_incl(accs) - accs;
-            const unsigned bq = wave_scan_incl(accq) - accq;
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                ES[c] += bs;
-                EQ[c] += bq;
-            }
+            tot_s = accs;
+            tot_q = accq;
         }
+        unsigned w0s = 0, w0q = 0, w1s = tot_s, w1q = tot_q;  // sums over lanes [lane, lane+j) and [lane, lane+j]
+#define PRL_W_STEP()                      \
+    do {                                  \
+        w0s = w1s;                        \
+        w0q = w1q;                        \
+        w1s = tot_s + lane_up1(w1s);      \
+        w1q = tot_q + lane_up1(w1q);      \
+    } while (0)
+        switch (fp.lane_off) {  // wave-uniform; straight-line code for the common window sizes (w <= 41)
+        case 0: break;
+        case 1: PRL_W_STEP(); break;
+        case 2: PRL_W_STEP(); PRL_W_STEP(); break;
+        case 3: PRL_W_STEP(); PRL_W_STEP(); PRL_W_STEP(); break;
+        case 4: PRL_W_STEP(); PRL_W_STEP(); PRL_W_STEP(); PRL_W_STEP(); break;
+        default:
+            for (int j = 0; j < fp.lane_off; ++j) PRL_W_STEP();
+        }
+#undef PRL_W_STEP
         unsigned Ssum[CPL], Qsum[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const int sub = (c + SH) & 7;  // compile-time
-            const int addr = (c + SH) >= 8 ? far_addr1 : far_addr0;
-            Ssum[c] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)ES[sub]) - ES[c];
-            Qsum[c] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)EQ[sub]) - EQ[c];
+            const bool far1 = (c + SH) >= 8;
+            const int addr = far1 ? far_addr1 : far_addr0;
+            Ssum[c] = ((unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)ES[sub]) - ES[c]) + (far1 ? w1s : w0s);
+            Qsum[c] = ((unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)EQ[sub]) - EQ[c]) + (far1 ? w1q : w0q);
         }
 
         if (METHOD == kWolfMax) {

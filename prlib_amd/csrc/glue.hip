@@ -1,0 +1,291 @@
+// glue.hip — SURVEY.md §8f rank 2: the channel adapters and the device-resident hand-off between the hot-path
+// stages, so a page goes denoise -> gray -> binarize -> (invert) -> thinning without a host round trip.
+//
+//   k_bgr2gray : cv::cvtColor(COLOR_BGR2GRAY / BGRA2GRAY) on 8-bit data, the call every binarizer makes first for a
+//                colour input (src/binarizations/binarizeSauvola.cpp:51; same line in Niblack/Wolf/NICK/Feng and in
+//                src/thinning/thinZhangSuen.cpp:78): 14-bit fixed point (1868 B + 9617 G + 4899 R + 8192) >> 14
+//                [upstream, SURVEY.md Appendix B], integer => bit-exact.
+//   k_gray2bgr : cv::cvtColor(COLOR_GRAY2BGR): the replicate a user needs in front of prl::denoise, which only
+//                accepts 3/4-channel input.
+//   k_invert   : cv::bitwise_not: the binarizers emit white = background, thinning thins white (§3.4).
+// All three are pure byte streams (HBM-bound: 4, 4 and 2 B per pixel); a thread handles 4 pixels with dword
+// accesses when the rows are 4-byte aligned, byte accesses otherwise.
+//
+// prl_hip_chain_batch_device strings the public entry points together on one stream with its intermediates in the
+// device staging workspace.  There is no such function in the reference (a user writes the calls one after the
+// other, each through host memory); BASELINE config 5 is this chain.
+#include <algorithm>
+
+#include "prl_internal.h"
+
+namespace prl_hip {
+namespace {
+
+__device__ __forceinline__ unsigned gray14(unsigned b, unsigned g, unsigned r)
+{
+    return (b * 1868u + g * 9617u + r * 4899u + (1u << 13)) >> 14;
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256) k_bgr2gray(PageSet src, PageSetOut dst, int width, int height)
+{
+    const int page = blockIdx.z, y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= width) return;
+    const uint8_t* s = src.page(page) + (size_t)y * src.step + (size_t)x0 * CH;
+    uint8_t* d = dst.page(page) + (size_t)y * dst.step + x0;
+    const int n = min(4, width - x0);
+    unsigned g[4] = {0, 0, 0, 0};
+    if (n == 4 && (((size_t)s) & 3) == 0) {
+        const unsigned* q = reinterpret_cast<const unsigned*>(s);
+        if (CH == 3) {
+            const unsigned w0 = q[0], w1 = q[1], w2 = q[2];  // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+            g[0] = gray14(w0 & 0xff, (w0 >> 8) & 0xff, (w0 >> 16) & 0xff);
+            g[1] = gray14(w0 >> 24, w1 & 0xff, (w1 >> 8) & 0xff);
+            g[2] = gray14((w1 >> 16) & 0xff, w1 >> 24, w2 & 0xff);
+            g[3] = gray14((w2 >> 8) & 0xff, (w2 >> 16) & 0xff, w2 >> 24);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = gray14(q[i] & 0xff, (q[i] >> 8) & 0xff, (q[i] >> 16) & 0xff);
+        }
+    } else {
+        for (int i = 0; i < n; ++i) g[i] = gray14(s[i * CH], s[i * CH + 1], s[i * CH + 2]);
+    }
+    if (n == 4 && (((size_t)d) & 3) == 0) {
+        *reinterpret_cast<unsigned*>(d) = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+    } else {
+        for (int i = 0; i < n; ++i) d[i] = (uint8_t)g[i];
+    }
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256) k_gray2bgr(PageSet src, PageSetOut dst, int width, int height)
+{
+    const int page = blockIdx.z, y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= width) return;
+    const uint8_t* s = src.page(page) + (size_t)y * src.step + x0;
+    uint8_t* d = dst.page(page) + (size_t)y * dst.step + (size_t)x0 * CH;
+    const int n = min(4, width - x0);
+    unsigned g[4] = {0, 0, 0, 0};
+    if (n == 4 && (((size_t)s) & 3) == 0) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(s);
+        g[0] = w & 0xff; g[1] = (w >> 8) & 0xff; g[2] = (w >> 16) & 0xff; g[3] = w >> 24;
+    } else {
+        for (int i = 0; i < n; ++i) g[i] = s[i];
+    }
+    if (n == 4 && (((size_t)d) & 3) == 0) {
+        unsigned* q = reinterpret_cast<unsigned*>(d);
+        if (CH == 3) {
+            q[0] = g[0] * 0x00010101u | (g[1] << 24);
+            q[1] = g[1] * 0x00000101u | (g[2] * 0x01010000u);
+            q[2] = g[2] | (g[3] * 0x01010100u);
+        } else {  // alpha = 255 (cv::cvtColor GRAY2BGRA)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = g[i] * 0x00010101u | 0xff000000u;
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            d[i * CH] = d[i * CH + 1] = d[i * CH + 2] = (uint8_t)g[i];
+            if (CH == 4) d[i * CH + 3] = 255;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_invert(PageSet src, PageSetOut dst, int width, int height)
+{
+    const int page = blockIdx.z, y = blockIdx.y;
+    const uint8_t* s = src.page(page) + (size_t)y * src.step;
+    uint8_t* d = dst.page(page) + (size_t)y * dst.step;
+    // align on the destination: head bytes, then 16-byte stores (source fetched as dwords / bytes when it is not
+    // co-aligned), tail bytes
+    const int head = min(width, (int)((16 - ((size_t)d & 15)) & 15));
+    if (blockIdx.x == 0 && (int)threadIdx.x < head) d[threadIdx.x] = (uint8_t)~s[threadIdx.x];
+    const int x0 = head + (blockIdx.x * 256 + threadIdx.x) * 16;
+    if (x0 >= width) return;
+    if (x0 + 16 <= width) {
+        uint4 w;
+        const size_t sa = (size_t)(s + x0);
+        if ((sa & 15) == 0) {
+            w = *reinterpret_cast<const uint4*>(s + x0);
+        } else if ((sa & 3) == 0) {
+            const unsigned* q = reinterpret_cast<const unsigned*>(s + x0);
+            w = make_uint4(q[0], q[1], q[2], q[3]);
+        } else {  // aligned dwords + byte funnel
+            const unsigned sh = (unsigned)(sa & 3);
+            const unsigned* q = reinterpret_cast<const unsigned*>(s + x0 - sh);
+            const unsigned a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];  // q[4] holds bytes x0+16-sh.. : inside the row
+            w = make_uint4(__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh),
+                           __builtin_amdgcn_alignbyte(a3, a2, sh), __builtin_amdgcn_alignbyte(a4, a3, sh));
+        }
+        *reinterpret_cast<uint4*>(d + x0) = make_uint4(~w.x, ~w.y, ~w.z, ~w.w);
+    } else {
+        for (int i = x0; i < width; ++i) d[i] = (uint8_t)~s[i];
+    }
+}
+
+struct Args {
+    PageSet ps{};
+    PageSetOut pd{};
+    dim3 grid;
+};
+
+int common_args(int n_pages, const uint8_t* d_src, size_t sps, size_t sstep, size_t src_row_bytes, int width, int height,
+                uint8_t* d_dst, size_t dps, size_t dstep, size_t dst_row_bytes, Args* a)
+{
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    if (n_pages < 0 || !d_src || !d_dst || sstep < src_row_bytes || dstep < dst_row_bytes) return PRL_ERR_BAD_ARG;
+    if (n_pages > 65535 || height > 65535) return PRL_ERR_BAD_ARG;  // grid.y / grid.z limits
+    a->ps.base = d_src; a->ps.page_stride = sps; a->ps.step = sstep;
+    a->pd.base = d_dst; a->pd.page_stride = dps; a->pd.step = dstep;
+    a->grid = dim3((unsigned)((width + 1023) / 1024), (unsigned)height, (unsigned)n_pages);  // 4 px per thread
+    return PRL_OK;
+}
+
+}  // namespace
+}  // namespace prl_hip
+
+using namespace prl_hip;
+
+extern "C" {
+
+int prl_hip_bgr2gray_batch_device(int n_pages, int channels, const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                                  int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                                  void* stream)
+{
+    if (channels != 3 && channels != 4) return PRL_ERR_BAD_CHANNELS;
+    Args a;
+    int st = common_args(n_pages, d_src, src_page_stride, src_step, (size_t)(width > 0 ? width : 0) * channels, width, height,
+                         d_dst, dst_page_stride, dst_step, (size_t)(width > 0 ? width : 0), &a);
+    if (st != PRL_OK || n_pages == 0) return st;
+    int dev;
+    st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (channels == 3) hipLaunchKernelGGL(k_bgr2gray<3>, a.grid, dim3(256), 0, s, a.ps, a.pd, width, height);
+    else hipLaunchKernelGGL(k_bgr2gray<4>, a.grid, dim3(256), 0, s, a.ps, a.pd, width, height);
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
+int prl_hip_gray2bgr_batch_device(int n_pages, int channels, const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                                  int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                                  void* stream)
+{
+    if (channels != 3 && channels != 4) return PRL_ERR_BAD_CHANNELS;
+    Args a;
+    int st = common_args(n_pages, d_src, src_page_stride, src_step, (size_t)(width > 0 ? width : 0), width, height, d_dst,
+                         dst_page_stride, dst_step, (size_t)(width > 0 ? width : 0) * channels, &a);
+    if (st != PRL_OK || n_pages == 0) return st;
+    int dev;
+    st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (channels == 3) hipLaunchKernelGGL(k_gray2bgr<3>, a.grid, dim3(256), 0, s, a.ps, a.pd, width, height);
+    else hipLaunchKernelGGL(k_gray2bgr<4>, a.grid, dim3(256), 0, s, a.ps, a.pd, width, height);
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
+int prl_hip_invert_batch_device(int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step, int width,
+                                int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream)
+{
+    Args a;
+    int st = common_args(n_pages, d_src, src_page_stride, src_step, (size_t)(width > 0 ? width : 0), width, height, d_dst,
+                         dst_page_stride, dst_step, (size_t)(width > 0 ? width : 0), &a);
+    if (st != PRL_OK || n_pages == 0) return st;
+    int dev;
+    st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    a.grid.x = (unsigned)((width + 15 + 4095) / 4096);  // 16 px per thread after a head of up to 15
+    hipLaunchKernelGGL(k_invert, a.grid, dim3(256), 0, static_cast<hipStream_t>(stream), a.ps, a.pd, width, height);
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
+// denoise (optional, colour input only) -> gray -> binarize -> thinning of the inverted mask (optional).
+// d_dst receives out_w x out_h bytes per page (prl_hip_binarize_geometry): the mask, or the skeleton when thinning
+// is requested (white = skeleton of the dark strokes).
+int prl_hip_chain_batch_device(const prl_chain_params* cp, int n_pages, int channels, const uint8_t* d_src,
+                               size_t src_page_stride, size_t src_step, int width, int height, uint8_t* d_dst,
+                               size_t dst_page_stride, size_t dst_step, void* stream)
+{
+    if (!cp) return PRL_ERR_BAD_ARG;
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    if (channels != 1 && channels != 3 && channels != 4) return PRL_ERR_BAD_CHANNELS;
+    if (cp->denoise && channels == 1) return PRL_ERR_BAD_CHANNELS;  // fastNlMeansDenoisingColored asserts 8UC3 / 8UC4
+    if (cp->thin != PRL_CHAIN_NO_THINNING && cp->thin != PRL_THIN_ZHANGSUEN && cp->thin != PRL_THIN_GUOHALL)
+        return PRL_ERR_BAD_ARG;
+    if (n_pages < 0 || !d_src || !d_dst || src_step < (size_t)width * channels) return PRL_ERR_BAD_ARG;
+    prl_binarize_geometry g;
+    int st = prl_hip_binarize_geometry(&cp->binarize, width, height, &g);
+    if (st != PRL_OK) return st;
+    if (dst_step < (size_t)g.out_w) return PRL_ERR_BAD_ARG;
+    if (n_pages == 0) return PRL_OK;
+    int dev;
+    st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> slk(ctx->stage_mu);  // the staging workspace holds the intermediates
+
+    const size_t px = (size_t)width * height, cpx = px * (size_t)channels;
+    const size_t mpx = (size_t)g.out_w * g.out_h;
+    const bool thin = cp->thin != PRL_CHAIN_NO_THINNING;
+    // per page: [denoised colour][gray][mask], each rounded up to 256 B
+    auto r256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t per_page = (cp->denoise ? r256(cpx) : 0) + (channels != 1 ? r256(px) : 0) + (thin ? r256(mpx) : 0);
+    const size_t budget = (size_t)1 << 30;
+    const int chunk = per_page == 0 ? n_pages : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, budget / per_page));
+    if (per_page) {
+        st = ensure_stage(ctx, per_page * (size_t)chunk);
+        if (st != PRL_OK) return st;
+    }
+    for (int first = 0; first < n_pages; first += chunk) {
+        const int cnt = std::min(chunk, n_pages - first);
+        uint8_t* w = static_cast<uint8_t*>(ctx->stage);
+        const uint8_t* cur = d_src + (size_t)first * src_page_stride;
+        size_t cur_ps = src_page_stride, cur_step = src_step;
+        if (cp->denoise) {
+            st = prl_hip_denoise_batch_device(cnt, channels, cp->denoise_strength, cur, cur_ps, cur_step, width, height, w,
+                                              r256(cpx), (size_t)width * channels, stream);
+            if (st != PRL_OK) return st;
+            cur = w; cur_ps = r256(cpx); cur_step = (size_t)width * channels;
+            w += r256(cpx) * (size_t)cnt;
+        }
+        if (channels != 1) {
+            st = prl_hip_bgr2gray_batch_device(cnt, channels, cur, cur_ps, cur_step, width, height, w, r256(px), (size_t)width,
+                                               stream);
+            if (st != PRL_OK) return st;
+            cur = w; cur_ps = r256(px); cur_step = (size_t)width;
+            w += r256(px) * (size_t)cnt;
+        }
+        uint8_t* out = d_dst + (size_t)first * dst_page_stride;
+        if (!thin) {
+            st = prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, out, dst_page_stride,
+                                               dst_step, stream);
+            if (st != PRL_OK) return st;
+        } else {
+            st = prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, w, r256(mpx),
+                                               (size_t)g.out_w, stream);
+            if (st != PRL_OK) return st;
+            st = prl_hip_invert_batch_device(cnt, w, r256(mpx), (size_t)g.out_w, g.out_w, g.out_h, w, r256(mpx), (size_t)g.out_w,
+                                             stream);
+            if (st != PRL_OK) return st;
+            st = prl_hip_thin_batch_device(cp->thin, cnt, w, r256(mpx), (size_t)g.out_w, g.out_w, g.out_h, out, dst_page_stride,
+                                           dst_step, stream);
+            if (st != PRL_OK) return st;
+        }
+    }
+    return PRL_OK;
+}
+
+void prl_hip_default_chain_params(prl_chain_params* out)
+{
+    if (!out) return;
+    out->denoise = 0;
+    out->denoise_strength = 5.5f;  // src/denoise/denoiseNLM.h:32
+    prl_hip_default_params(PRL_SAUVOLA, &out->binarize);
+    out->thin = PRL_CHAIN_NO_THINNING;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+"""GPU parity of the channel adapters and the device-resident chain against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _colour(shape, c, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, shape + (c,), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("c", [3, 4])
+@pytest.mark.parametrize("shape", [(40, 64), (33, 97), (17, 5), (1, 1), (50, 1026)])
+def test_bgr2gray_matches_oracle(prl, oracle, cuda_device, shape, c):
+    import torch
+
+    imgs = np.stack([_colour(shape, c, s) for s in (1, 2)])
+    got = prl.cvtColorBGR2GRAY(torch.from_numpy(imgs).to(cuda_device)).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], oracle.bgr2gray(imgs[i]))
+
+
+def test_bgr2gray_extremes_and_views(prl, oracle, cuda_device):
+    import torch
+
+    # saturation corners of the fixed-point formula
+    px = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [1, 1, 1], [254, 255, 253], [128, 127, 129]]], np.uint8)
+    got = prl.cvtColorBGR2GRAY(torch.from_numpy(px).to(cuda_device)).cpu().numpy()
+    assert np.array_equal(got, oracle.bgr2gray(px)) and got[0, 0] == 255 and got[0, 1] == 0
+    # unaligned ROI view with a row step larger than the row, output into a guarded view
+    h, w = 21, 37
+    big = torch.from_numpy(_colour((h + 2, w + 9), 3, 7)).to(cuda_device)
+    view = big[1:h + 1, 5:5 + w]                      # rows start at byte offset 15 (mod 4 = 3)
+    out = torch.full((h + 2, w + 8), 9, dtype=torch.uint8, device=cuda_device)
+    prl.cvtColorBGR2GRAY(view, out=out[1:h + 1, 3:3 + w])
+    o = out.cpu().numpy()
+    assert np.array_equal(o[1:h + 1, 3:3 + w], oracle.bgr2gray(np.ascontiguousarray(view.cpu().numpy())))
+    o[1:h + 1, 3:3 + w] = 9
+    assert (o == 9).all()
+
+
+@pytest.mark.parametrize("shape", [(30, 64), (19, 45), (3, 2)])
+def test_gray2bgr_and_invert(prl, cuda_device, shape):
+    import torch
+
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 256, (2,) + shape, dtype=np.uint8)
+    t = torch.from_numpy(g).to(cuda_device)
+    for c in (3, 4):
+        got = prl.cvtColorGRAY2BGR(t, c).cpu().numpy()
+        want = np.repeat(g[..., None], c, axis=-1)
+        if c == 4:
+            want[..., 3] = 255
+        assert np.array_equal(got, want)
+    assert np.array_equal(prl.bitwise_not(t).cpu().numpy(), 255 - g)
+    # in place, on an unaligned view
+    big = torch.from_numpy(rng.integers(0, 256, (shape[0] + 2, shape[1] + 7), dtype=np.uint8)).to(cuda_device)
+    ref = big.cpu().numpy().copy()
+    v = big[1:shape[0] + 1, 3:3 + shape[1]]
+    prl.bitwise_not(v, out=v)
+    ref[1:shape[0] + 1, 3:3 + shape[1]] = 255 - ref[1:shape[0] + 1, 3:3 + shape[1]]
+    assert np.array_equal(big.cpu().numpy(), ref)
+
+
+def _oracle_chain(oracle, img, channels, method, w, k, morph, strength, thin):
+    cur = img
+    if strength is not None:
+        cur = oracle.denoise(cur, strength, threads=8)
+    if channels != 1:
+        cur = oracle.bgr2gray(cur)
+    mask = oracle.binarize(cur, oracle.make_params(method, w, k, morph))
+    if thin < 0:
+        return mask
+    return oracle.thin(255 - mask, thin)
+
+
+@pytest.mark.parametrize("thin", [-1, 0, 1])
+@pytest.mark.parametrize("strength", [None, 8.0])
+def test_chain_matches_the_composed_oracle(prl, oracle, cuda_device, strength, thin):
+    import torch
+    from prlib_amd import synth
+
+    h, w = 96, 128
+    pages = []
+    for i in range(2):
+        gray = synth.page_numpy(h, w, index=i + 11)
+        rng = np.random.default_rng(i)
+        pages.append(np.clip(gray[..., None].astype(np.int32) + rng.normal(0, 9, (h, w, 3)), 0, 255).round().astype(np.uint8))
+    pages = np.stack(pages)
+    got = prl.process_pages(torch.from_numpy(pages).to(cuda_device), 3, prl.SAUVOLA, 31, 0.34, 1,
+                            denoise_strength=strength, thin=thin).cpu().numpy()
+    for i in range(2):
+        want = _oracle_chain(oracle, pages[i], 3, oracle.SAUVOLA, 31, 0.34, 1, strength, thin)
+        assert got[i].shape == want.shape
+        assert np.array_equal(got[i], want), f"page {i}: {int((got[i] != want).sum())} mismatching pixels"
+
+
+def test_chain_gray_input_other_methods_and_errors(prl, oracle, cuda_device):
+    import torch
+    from prlib_amd import synth
+
+    page = synth.page_numpy(120, 150, index=4)
+    t = torch.from_numpy(page).to(cuda_device)
+    for method, w, k in ((prl.NICK, 21, -0.1), (prl.WOLFJOLION, 31, 0.3)):
+        got = prl.process_pages(t, 1, method, w, k, 0, thin=0).cpu().numpy()
+        want = _oracle_chain(oracle, page, 1, method, w, k, 0, None, 0)
+        assert np.array_equal(got, want)
+    with pytest.raises(Exception):          # fastNlMeansDenoisingColored asserts 3/4 channels
+        prl.process_pages(t, 1, prl.SAUVOLA, 31, 0.34, 0, denoise_strength=5.0)
+    with pytest.raises(Exception):
+        prl.process_pages(t, 1, prl.SAUVOLA, 31, 0.34, 0, thin=7)
+    with pytest.raises(ValueError):         # even window: std::invalid_argument in the reference
+        prl.process_pages(t, 1, prl.SAUVOLA, 30, 0.34, 0)

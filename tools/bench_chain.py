@@ -29,21 +29,22 @@ def timed(fn):
     return (time.perf_counter() - t0) / a.steps, r
 
 
-def gray_of(x):  # cv::cvtColor(BGR2GRAY) 14-bit fixed point, on the device as torch glue (not part of the hot path)
-    b, g, r = x[..., 0].int(), x[..., 1].int(), x[..., 2].int()
-    return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).to(torch.uint8).contiguous()
-
-
 px = a.pages * a.width * a.height
 t_den, den = timed(lambda: prlib_amd.denoise(bgr, 10.0))
-g8 = gray_of(den)
+t_gray, g8 = timed(lambda: prlib_amd.cvtColorBGR2GRAY(den))
 t_bin, mask = timed(lambda: prlib_amd.binarizeSauvola(g8, 31, 0.34, 0))
-inv = (255 - mask).contiguous()
+t_inv, inv = timed(lambda: prlib_amd.bitwise_not(mask))
 t_thin_zs, sk = timed(lambda: prlib_amd.thinZhangSuen(inv))
 t_thin_gh, _ = timed(lambda: prlib_amd.thinGuoHall(inv))
+t_chain, sk2 = timed(lambda: prlib_amd.process_pages(bgr, 3, prlib_amd.SAUVOLA, 31, 0.34, 0, denoise_strength=10.0, thin=0))
+t_chain_nd, _ = timed(lambda: prlib_amd.process_pages(bgr, 3, prlib_amd.SAUVOLA, 31, 0.34, 0, thin=0))
+assert torch.equal(sk, sk2)
 res = {"workload": f"{a.pages} x {a.width}x{a.height} pages, 1 GPU, device resident",
        "denoise_ms": round(t_den * 1e3, 2), "sauvola_w31_ms": round(t_bin * 1e3, 3),
        "thin_zhangsuen_ms": round(t_thin_zs * 1e3, 3), "thin_guohall_ms": round(t_thin_gh * 1e3, 3),
-       "thin_zhangsuen_Mpx_s": round(px / t_thin_zs / 1e6, 1), "chain_Mpx_s": round(px / (t_den + t_bin + t_thin_zs) / 1e6, 1),
+       "bgr2gray_ms": round(t_gray * 1e3, 3), "invert_ms": round(t_inv * 1e3, 3),
+       "thin_zhangsuen_Mpx_s": round(px / t_thin_zs / 1e6, 1),
+       "chain_one_call_ms": round(t_chain * 1e3, 2), "chain_Mpx_s": round(px / t_chain / 1e6, 1),
+       "chain_without_denoise_ms": round(t_chain_nd * 1e3, 3), "chain_without_denoise_Mpx_s": round(px / t_chain_nd / 1e6, 1),
        "skeleton_fraction": round(float((sk > 0).float().mean()), 5)}
 print(json.dumps(res))
