@@ -353,8 +353,13 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
         case 2: PRL_W_STEP(); PRL_W_STEP(); break;
         case 3: PRL_W_STEP(); PRL_W_STEP(); PRL_W_STEP(); break;
         case 4: PRL_W_STEP(); PRL_W_STEP(); PRL_W_STEP(); PRL_W_STEP(); break;
-        default:
-            for (int j = 0; j < fp.lane_off; ++j) PRL_W_STEP();
+        default: {  // wide windows: one wavefront scan of the lane totals, W = difference of its values at the two lanes
+            const unsigned ps = wave_scan_incl(tot_s) - tot_s, pq = wave_scan_incl(tot_q) - tot_q;
+            w0s = (unsigned)__builtin_amdgcn_ds_bpermute(far_addr0, (int)ps) - ps;
+            w1s = (unsigned)__builtin_amdgcn_ds_bpermute(far_addr1, (int)ps) - ps;
+            w0q = (unsigned)__builtin_amdgcn_ds_bpermute(far_addr0, (int)pq) - pq;
+            w1q = (unsigned)__builtin_amdgcn_ds_bpermute(far_addr1, (int)pq) - pq;
+        }
         }
 #undef PRL_W_STEP
         unsigned Ssum[CPL], Qsum[CPL];
