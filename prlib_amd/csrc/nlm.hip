@@ -753,24 +753,21 @@ int prl_hip_denoise_host(int channels, float strength, const uint8_t* src, size_
     int dev;
     int st = current_device(&dev);
     if (st != PRL_OK) return st;
-    const size_t row = (size_t)width * channels, pitch = (row + 255) / 256 * 256;
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    PRL_HIP_CHECK(hipMalloc(&d_in, pitch * (size_t)height));
-    if (hipMalloc(&d_out, pitch * (size_t)height) != hipSuccess) {
-        (void)hipFree(d_in);
-        return PRL_ERR_NOMEM;
-    }
-    auto cleanup = [&]() { (void)hipFree(d_in); (void)hipFree(d_out); };
-    if (hipMemcpy2D(d_in, pitch, src, src_step, row, (size_t)height, hipMemcpyHostToDevice) != hipSuccess) {
-        cleanup();
-        return PRL_ERR_HIP;
-    }
-    st = prl_hip_denoise_batch_device(1, channels, strength, d_in, pitch * (size_t)height, pitch, width, height, d_out,
-                                      pitch * (size_t)height, pitch, nullptr);
-    if (st == PRL_OK && hipMemcpy2D(dst, dst_step, d_out, pitch, row, (size_t)height, hipMemcpyDeviceToHost) != hipSuccess)
-        st = PRL_ERR_HIP;
-    cleanup();
-    return st;
+    const size_t row = (size_t)width * channels;
+    const size_t bytes = (row * (size_t)height + 255) / 256 * 256;
+    DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> slk(ctx->stage_mu);  // cached device + pinned staging (lock order: stage_mu, then mu)
+    st = ensure_stage(ctx, 2 * bytes);
+    if (st != PRL_OK) return st;
+    st = ensure_stage_pinned(ctx, 2 * bytes);
+    if (st != PRL_OK) return st;
+    uint8_t* d_in = static_cast<uint8_t*>(ctx->stage);
+    uint8_t* d_out = d_in + bytes;
+    st = stage_upload(ctx, 0, src, src_step, row, height, d_in, nullptr);
+    if (st != PRL_OK) return st;
+    st = prl_hip_denoise_batch_device(1, channels, strength, d_in, bytes, row, width, height, d_out, bytes, row, nullptr);
+    if (st != PRL_OK) return st;
+    return stage_download(ctx, bytes, d_out, row, height, dst, dst_step, nullptr);
 }
 
 }  // extern "C"

@@ -131,6 +131,47 @@ int ensure_stage(DeviceCtx* ctx, size_t bytes)
     return PRL_OK;
 }
 
+int ensure_stage_pinned(DeviceCtx* ctx, size_t bytes)
+{
+    if (ctx->stage_pinned_bytes >= bytes) return PRL_OK;
+    if (ctx->stage_pinned) {
+        PRL_HIP_CHECK(hipDeviceSynchronize());
+        PRL_HIP_CHECK(hipHostFree(ctx->stage_pinned));
+        ctx->stage_pinned = nullptr;
+        ctx->stage_pinned_bytes = 0;
+    }
+    PRL_HIP_CHECK(hipHostMalloc(&ctx->stage_pinned, bytes, hipHostMallocDefault));
+    ctx->stage_pinned_bytes = bytes;
+    return PRL_OK;
+}
+
+int stage_upload(DeviceCtx* ctx, size_t pin_off, const uint8_t* src, size_t src_step, size_t row_bytes, int rows,
+                 uint8_t* d_dst, hipStream_t stream)
+{
+    uint8_t* pin = static_cast<uint8_t*>(ctx->stage_pinned) + pin_off;
+    if (src_step == row_bytes) {
+        std::memcpy(pin, src, row_bytes * (size_t)rows);
+    } else {
+        for (int y = 0; y < rows; ++y) std::memcpy(pin + (size_t)y * row_bytes, src + (size_t)y * src_step, row_bytes);
+    }
+    PRL_HIP_CHECK(hipMemcpyAsync(d_dst, pin, row_bytes * (size_t)rows, hipMemcpyHostToDevice, stream));
+    return PRL_OK;
+}
+
+int stage_download(DeviceCtx* ctx, size_t pin_off, const uint8_t* d_src, size_t row_bytes, int rows, uint8_t* dst,
+                   size_t dst_step, hipStream_t stream)
+{
+    uint8_t* pin = static_cast<uint8_t*>(ctx->stage_pinned) + pin_off;
+    PRL_HIP_CHECK(hipMemcpyAsync(pin, d_src, row_bytes * (size_t)rows, hipMemcpyDeviceToHost, stream));
+    PRL_HIP_CHECK(hipStreamSynchronize(stream));
+    if (dst_step == row_bytes) {
+        std::memcpy(dst, pin, row_bytes * (size_t)rows);
+    } else {
+        for (int y = 0; y < rows; ++y) std::memcpy(dst + (size_t)y * dst_step, pin + (size_t)y * row_bytes, row_bytes);
+    }
+    return PRL_OK;
+}
+
 int ensure_pinned(DeviceCtx* ctx, size_t bytes)
 {
     if (ctx->pinned_bytes >= bytes) return PRL_OK;
@@ -478,6 +519,9 @@ int prl_hip_release_workspace(void)
     if (ctx->stage) PRL_HIP_CHECK(hipFree(ctx->stage));
     ctx->stage = nullptr;
     ctx->stage_bytes = 0;
+    if (ctx->stage_pinned) PRL_HIP_CHECK(hipHostFree(ctx->stage_pinned));
+    ctx->stage_pinned = nullptr;
+    ctx->stage_pinned_bytes = 0;
     return PRL_OK;
 }
 
@@ -575,28 +619,24 @@ int prl_hip_binarize_host(const prl_binarize_params* p, const uint8_t* src, size
     st = current_device(&dev);
     if (st != PRL_OK) return st;
 
-    const size_t in_pitch = ((size_t)width + 255) / 256 * 256;
-    const size_t out_pitch = ((size_t)g.out_w + 255) / 256 * 256;
-    const size_t in_bytes = in_pitch * (size_t)height, out_bytes = out_pitch * (size_t)g.out_h;
+    // rows packed tightly on the device (the kernels take any step >= width); 256-byte aligned page starts
+    const size_t in_pitch = (size_t)width, out_pitch = (size_t)g.out_w;
+    const size_t in_bytes = (in_pitch * (size_t)height + 255) / 256 * 256, out_bytes = out_pitch * (size_t)g.out_h;
     DeviceCtx* ctx = device_ctx(dev);
-    std::lock_guard<std::mutex> slk(ctx->stage_mu);  // cached device staging: no hipMalloc/hipFree per page
+    std::lock_guard<std::mutex> slk(ctx->stage_mu);  // cached device + pinned staging: no allocation per page
     st = ensure_stage(ctx, in_bytes + out_bytes);
+    if (st != PRL_OK) return st;
+    st = ensure_stage_pinned(ctx, in_bytes + out_bytes);
     if (st != PRL_OK) return st;
     uint8_t* d_in = static_cast<uint8_t*>(ctx->stage);
     uint8_t* d_out = d_in + in_bytes;
     hipStream_t stream = nullptr;
-    hipError_t e = hipMemcpy2D(d_in, in_pitch, src, src_step, (size_t)width, (size_t)height, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        set_error_detail(std::string("hipMemcpy2D H2D: ") + hipGetErrorString(e));
-        return PRL_ERR_HIP;
-    }
+    st = stage_upload(ctx, 0, src, src_step, (size_t)width, height, d_in, stream);
+    if (st != PRL_OK) return st;
     st = prl_hip_binarize_batch_device(p, 1, d_in, in_bytes, in_pitch, width, height, d_out, out_bytes, out_pitch, stream);
     if (st != PRL_OK) return st;
-    e = hipMemcpy2D(dst, dst_step, d_out, out_pitch, (size_t)g.out_w, (size_t)g.out_h, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) {
-        set_error_detail(std::string("hipMemcpy2D D2H: ") + hipGetErrorString(e));
-        return PRL_ERR_HIP;
-    }
+    st = stage_download(ctx, in_bytes, d_out, (size_t)g.out_w, g.out_h, dst, dst_step, stream);
+    if (st != PRL_OK) return st;
     if (padded_out) {
         // cv::copyMakeBorder(in, in, h, h, h, h, BORDER_REPLICATE) side effect on the caller's Mat
         // (binarizeSauvola.cpp:65): pure data movement of the caller's own host pixels.

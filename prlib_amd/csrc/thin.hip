@@ -280,20 +280,19 @@ int prl_hip_thin_host(int method, const uint8_t* src, size_t src_step, int width
     int dev;
     int st = current_device(&dev);
     if (st != PRL_OK) return st;
-    const size_t pitch = ((size_t)width + 255) / 256 * 256;
-    uint8_t* d = nullptr;
-    PRL_HIP_CHECK(hipMalloc(&d, pitch * (size_t)height));
-    if (hipMemcpy2D(d, pitch, src, src_step, (size_t)width, (size_t)height, hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(d);
-        return PRL_ERR_HIP;
-    }
-    st = prl_hip_thin_batch_device(method, 1, d, pitch * (size_t)height, pitch, width, height, d, pitch * (size_t)height,
-                                   pitch, nullptr);
-    if (st == PRL_OK &&
-        hipMemcpy2D(dst, dst_step, d, pitch, (size_t)width, (size_t)height, hipMemcpyDeviceToHost) != hipSuccess)
-        st = PRL_ERR_HIP;
-    (void)hipFree(d);
-    return st;
+    const size_t bytes = ((size_t)width * height + 255) / 256 * 256;
+    DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> slk(ctx->stage_mu);  // cached device + pinned staging (lock order: stage_mu, then mu)
+    st = ensure_stage(ctx, bytes);
+    if (st != PRL_OK) return st;
+    st = ensure_stage_pinned(ctx, bytes);
+    if (st != PRL_OK) return st;
+    uint8_t* d = static_cast<uint8_t*>(ctx->stage);
+    st = stage_upload(ctx, 0, src, src_step, (size_t)width, height, d, nullptr);
+    if (st != PRL_OK) return st;
+    st = prl_hip_thin_batch_device(method, 1, d, bytes, (size_t)width, width, height, d, bytes, (size_t)width, nullptr);
+    if (st != PRL_OK) return st;
+    return stage_download(ctx, 0, d, (size_t)width, height, dst, dst_step, nullptr);
 }
 
 }  // extern "C"
