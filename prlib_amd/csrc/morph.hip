@@ -6,10 +6,10 @@
 // OpenCV folds into one (2n+1)x(2n+1) rectangle; the default border value makes out-of-image pixels
 // neutral (ignored) for both operations.
 //
-// One workgroup produces a 64x32 output tile.  The source tile plus a 2n halo is staged in LDS once
-// (coalesced row-major global reads), the two rectangle passes run separably (rows then columns)
-// entirely in LDS, and the tile is written back with coalesced row stores — both operators for the
-// price of one read and one write of the mask (2 B/px, HBM-bound).
+// Binary masks (the pipeline's own threshold output) go through k_morph_bits: both operators on bit-packed rows held
+// in registers, one read and one write of the mask (2 B/px, HBM-bound; see the kernel's comment).  k_morph_stream /
+// k_morph_binary are the older byte-dword forms kept for radius 5..8 and unaligned sources; k_morph / k_rect are the
+// byte-wise max/min kernels behind the public prl_hip_morph_batch_device entry (any 8-bit image).
 #include "prl_internal.h"
 
 namespace prl_hip {
@@ -391,6 +391,184 @@ __global__ void __launch_bounds__(256) k_morph_stream(PageSet src, PageSetOut ds
     }
 }
 
+// ---- bit-domain streaming kernel (binary masks, radius <= 4: the reference's default is 2) --------------------
+// The two rectangle operators run on BITS: horizontal neighbours by shifts against the words of lane -+ 1 (DPP),
+// vertical windows as OR / AND over a (2n+1)-deep register ring, no LDS; ~0.3 vector instructions per pixel, so the
+// kernel runs at the speed of its 2 B/px of traffic (the byte-per-lane-dword version above spends ~10x the ALU work
+// and two LDS rings per row).
+// Lane layout: a wavefront covers 2048 pixels of a row as 128 chunks of 16; lane L owns chunk L (low 16 bits of its
+// word) and chunk 64 + L (high 16 bits), so each of the two 16-byte loads / stores per lane is one contiguous 1 KiB
+// (whole cache lines) across the wavefront.  (One 32-pixel word per lane needs two stores of alternate 16-byte pieces
+// per lane: the write path then took 190 of 330 us.)  Bitwise work is the same for both halves at once; only the
+// horizontal shifts mask the bits that would cross from one half into the other, and lane 0 / 63 take their missing
+// neighbour half from the other end of the wavefront (DPP wave_ror / wave_rol + half swap).
+// The destination is the caller's buffer and may have any alignment: output chunks are the 16-byte-ALIGNED chunks of
+// the destination row, chunk c = the top A bits of source chunk c-1 and the low 16-A bits of chunk c (A = row address
+// mod 16); strips advance by 125 chunks (2000 px) so that consecutive strips tile the row for every A.
+constexpr int kBitsMaxN = 4;
+constexpr int kBitsAdvance = 2000;  // output pixels per strip: chunks 2 .. 126
+
+__device__ __forceinline__ unsigned pack_nibble(unsigned x)  // bytes 0x00 / 0xFF -> 4 bits (byte j -> bit j)
+{
+    return ((x & 0x01010101u) * 0x01020408u) >> 24;
+}
+
+__device__ __forceinline__ unsigned pack16(uint4 a)
+{
+    return pack_nibble(a.x) | (pack_nibble(a.y) << 4) | (pack_nibble(a.z) << 8) | (pack_nibble(a.w) << 12);
+}
+
+__device__ __forceinline__ unsigned unpack_nibble(unsigned nib)  // 4 bits -> 4 bytes of 0x00 / 0xFF
+{
+    const unsigned ones = (nib * 0x00204081u) & 0x01010101u;  // copies 7 bits apart: bit j lands on bit 8j
+    return (ones << 8) - ones;                                 // * 255
+}
+
+__device__ __forceinline__ uint4 unpack16(unsigned h)
+{
+    return make_uint4(unpack_nibble(h & 15u), unpack_nibble((h >> 4) & 15u), unpack_nibble((h >> 8) & 15u),
+                      unpack_nibble((h >> 12) & 15u));
+}
+
+// words of the previous / next chunk for both halves of `c`
+__device__ __forceinline__ void neighbours(unsigned c, int lane, unsigned* prev, unsigned* next)
+{
+    unsigned p = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x13C, 0xf, 0xf, false);  // wave_ror:1 = lane - 1
+    unsigned n = (unsigned)__builtin_amdgcn_update_dpp(0, (int)c, 0x134, 0xf, 0xf, false);  // wave_rol:1 = lane + 1
+    // chunk 64 (high half of lane 0) follows chunk 63 (low half of lane 63)
+    if (lane == 0) p = (p << 16) | (p >> 16);
+    if (lane == 63) n = (n << 16) | (n >> 16);
+    *prev = p;
+    *next = n;
+}
+
+// both 16-bit halves shifted towards higher x by k (pixel x takes pixel x - k), 0 <= k <= 15
+__device__ __forceinline__ unsigned shift_up(unsigned c, unsigned prev, unsigned k)
+{
+    const unsigned m = ((1u << k) - 1u) * 0x00010001u;  // low k bits of each half come from the previous chunk
+    return ((c << k) & ~m) | ((prev >> (16u - k)) & m);
+}
+
+// both halves shifted towards lower x by k (pixel x takes pixel x + k), 1 <= k <= 15
+__device__ __forceinline__ unsigned shift_down(unsigned c, unsigned next, unsigned k)
+{
+    const unsigned m = ((0xffffu << (16u - k)) & 0xffffu) * 0x00010001u;  // top k bits of each half come from the next chunk
+    return ((c >> k) & ~m) | ((next << (16u - k)) & m);
+}
+
+template <bool IS_OR, int N>
+__device__ __forceinline__ unsigned hop_bits(unsigned c, int lane)
+{
+    unsigned prev, next;
+    neighbours(c, lane, &prev, &next);
+    unsigned v = c;
+#pragma unroll
+    for (int k = 1; k <= N; ++k) v = comb<IS_OR>(v, comb<IS_OR>(shift_up(c, prev, k), shift_down(c, next, k)));
+    return v;
+}
+
+template <int N, bool FIRST_OR>
+__global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst, int width, int height, int n_strips,
+                                                   int n_segs, int rows_per_seg, unsigned total_waves)
+{
+    constexpr int K = 2 * N + 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
+    if (wid >= total_waves) return;
+    const int per_page = n_strips * n_segs;
+    const int page = (int)(wid / (unsigned)per_page);
+    const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
+    const int seg = rem / n_strips, strip = rem - seg * n_strips;
+
+    const uint8_t* in = src.page(page);
+    uint8_t* out = dst.page(page);
+    const int base_px = strip * kBitsAdvance - 32;                 // source pixel of chunk 0
+    const int gx0 = base_px + 16 * lane, gx1 = gx0 + 1024;         // first pixel of this lane's two chunks
+    const int ys = seg * rows_per_seg, ye = min(ys + rows_per_seg, height);
+    const unsigned neutral1 = FIRST_OR ? 0u : 0xffffffffu, neutral2 = ~neutral1;
+    // bits of the two halves that are pixels of the page row
+    auto inside16 = [&](int gx) -> unsigned {
+        if (gx + 16 <= 0 || gx >= width) return 0u;
+        const int b0 = max(0, -gx), b1 = min(16, width - gx);  // [b0, b1)
+        return (((1u << (b1 - b0)) - 1u) << b0) & 0xffffu;
+    };
+    const unsigned in0 = inside16(gx0), in1 = inside16(gx1);
+    const unsigned inside = in0 | (in1 << 16);
+
+    // page row r as bits.  Source rows are 16-byte aligned and padded to whole chunks (checked by the host: the
+    // pipeline's own mask buffer), so an edge chunk is fetched whole and masked.
+    auto fetch = [&](int r) -> unsigned {
+        if (r < 0 || r >= height) return neutral1;
+        const uint8_t* row = in + (size_t)r * src.step;
+        unsigned v = 0;
+        if (in0) v = pack16(*reinterpret_cast<const uint4*>(row + gx0));
+        if (in1) v |= pack16(*reinterpret_cast<const uint4*>(row + gx1)) << 16;
+        return (v & inside) | (neutral1 & ~inside);
+    };
+
+    unsigned ring1[K], ring2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        ring1[k] = neutral1;
+        ring2[k] = neutral2;
+    }
+    unsigned vnext = fetch(ys - 2 * N);
+#pragma unroll 1
+    for (int r = ys - 2 * N; r < ye + 2 * N; ++r) {
+        const unsigned v = vnext;
+        vnext = fetch(r + 1);  // one row ahead; the rest of the latency is hidden by the other wavefronts
+#pragma unroll
+        for (int k = K - 1; k > 0; --k) ring1[k] = ring1[k - 1];
+        ring1[0] = hop_bits<FIRST_OR, N>(v, lane);
+        const int rc = r - N;  // centre row of the first operator's vertical window (complete once r >= ys)
+        if (r < ys) continue;  // wave-uniform
+        unsigned v1 = ring1[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) v1 = comb<FIRST_OR>(v1, ring1[k]);
+        // pixels outside the page do not exist for the second operator
+        v1 = (rc < 0 || rc >= height) ? neutral2 : ((v1 & inside) | (neutral2 & ~inside));
+#pragma unroll
+        for (int k = K - 1; k > 0; --k) ring2[k] = ring2[k - 1];
+        ring2[0] = hop_bits<!FIRST_OR, N>(v1, lane);
+        const int ro = r - 2 * N;  // output row (its window is complete once ro >= ys)
+        if (ro < ys) continue;
+        unsigned o = ring2[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) o = comb<!FIRST_OR>(o, ring2[k]);
+
+        // destination-aligned chunks: chunk c covers pixels [base_px + 16 c - A, + 16)
+        uint8_t* orow = out + (size_t)ro * dst.step;
+        const unsigned A = (unsigned)((size_t)orow & 15u);  // wave-uniform
+        unsigned oprev, onext;
+        neighbours(o, lane, &oprev, &onext);
+        const unsigned bits = shift_up(o, oprev, A);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int c = half * 64 + lane;
+            const int px = base_px + 16 * c - (int)A;
+            if (c >= 2 && c <= 126 && px + 16 > 0 && px < width) {
+                const uint4 d = unpack16((bits >> (16 * half)) & 0xffffu);
+                if (px >= 0 && px + 16 <= width) {
+                    *reinterpret_cast<uint4*>(orow + px) = d;
+                } else {  // ragged ends of the row: dwords that lie inside, then bytes
+                    const unsigned dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int p4 = px + 4 * q;
+                        if (p4 >= 0 && p4 + 4 <= width) {
+                            *reinterpret_cast<unsigned*>(orow + p4) = dw[q];
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b)
+                                if (p4 + b >= 0 && p4 + b < width) orow[p4 + b] = (uint8_t)(dw[q] >> (8 * b));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // The rectangle of n iterations equals n applications of the 3x3 one, and a closing/opening with
@@ -435,6 +613,38 @@ int morph_binary_run(int iterations, const PageSet& src, int n_pages, int width,
     if (n == 0 || n > kMaxN) {
         set_error_detail("radius above " + std::to_string(kMaxN) + " goes through morph_large_run");
         return PRL_ERR_BAD_ARG;
+    }
+    if (n <= kBitsMaxN && (((size_t)src.base | src.page_stride | src.step) & 15) == 0 && !src.table && !dst.table &&
+        src.step >= (size_t)((width + 15) / 16) * 16) {
+        // bit-domain streaming kernel: needs 16-byte aligned source rows padded to whole 16-pixel chunks (the
+        // pipeline's own mask buffer always is)
+        const int n_strips = (width + 15 + kBitsAdvance - 1) / kBitsAdvance;
+        int rps = 128;
+        while (rps > 32 && (long long)n_pages * n_strips * ((height + rps - 1) / rps) < 16384) rps /= 2;
+        if (const char* e = std::getenv("PRL_MORPH_RPS")) rps = std::max(8, std::atoi(e));
+        const int n_segs = (height + rps - 1) / rps;
+        const unsigned long long tw = (unsigned long long)n_pages * n_strips * n_segs;
+        if (tw < 0xfffffff0ull) {
+            const dim3 grid((unsigned)((tw + 3) / 4)), block(256);
+#define PRL_LAUNCH_BITS(NV)                                                                                         \
+    do {                                                                                                            \
+        if (iterations > 0)                                                                                         \
+            hipLaunchKernelGGL((k_morph_bits<NV, true>), grid, block, 0, stream, src, dst, width, height, n_strips, \
+                               n_segs, rps, (unsigned)tw);                                                          \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_morph_bits<NV, false>), grid, block, 0, stream, src, dst, width, height, n_strips, \
+                               n_segs, rps, (unsigned)tw);                                                          \
+    } while (0)
+            switch (n) {
+            case 1: PRL_LAUNCH_BITS(1); break;
+            case 2: PRL_LAUNCH_BITS(2); break;
+            case 3: PRL_LAUNCH_BITS(3); break;
+            default: PRL_LAUNCH_BITS(4); break;
+            }
+#undef PRL_LAUNCH_BITS
+            PRL_HIP_CHECK(hipGetLastError());
+            return PRL_OK;
+        }
     }
     if ((((size_t)src.base | src.page_stride | src.step) & 3) == 0 && !src.table) {
         // streaming kernel: needs 4-byte aligned source rows (the pipeline's own mask buffer always is)
