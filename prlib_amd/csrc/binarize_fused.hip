@@ -82,6 +82,7 @@ struct FusedParams {
     float rho;         // Wolf: relative error bound of the float32 variance v~
     float ev2;         // Wolf: 2 * Ev (literal variance noise)
     float* segmax;     // Wolf: per-wavefront maximum of v~ (sweep A -> sweep B)
+    int bit_out;       // the mask is written as a bit plane (1 bit per pixel) for the bit-domain morphology pass
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -201,6 +202,21 @@ __device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, 
     if (T < P - ET) return 255;
     if (T > P + ET) return 0;
     return 2;
+}
+
+// one decided pixel (k_refine / k_fixup_final): byte mask, or one bit of the bit plane (other threads may own
+// neighbouring bits of the word: atomics)
+__device__ __forceinline__ void store_decision(const PageSetOut& dst, int bit_out, int page, int y, int x, unsigned r)
+{
+    uint8_t* row = dst.page(page) + (size_t)y * dst.step;
+    if (!bit_out) {
+        row[x] = (uint8_t)r;
+    } else {
+        unsigned* w = reinterpret_cast<unsigned*>(row) + (x >> 5);
+        const unsigned m = 1u << (x & 31);
+        if (r) atomicOr(w, m);
+        else atomicAnd(w, ~m);
+    }
 }
 
 typedef const uint8_t __attribute__((address_space(1)))* gcptr;  // known-global pointers: global_load, not flat_load
@@ -465,8 +481,14 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                 }
             }
 
-            // store 8 mask bytes
-            if (full8) {
+            if (fp.bit_out) {
+                // bit plane: this lane's 8 pixels are one whole byte (x0 is a multiple of 8); 0x00 / 0xFF bytes -> bits
+                if (lane_has_out) {
+                    unsigned b = (((lo & 0x01010101u) * 0x01020408u) >> 24) | ((((hi & 0x01010101u) * 0x01020408u) >> 20) & 0xf0u);
+                    if (EDGE && !full8) b &= (1u << (tp.ow - x0)) - 1u;  // pixels past the row end stay 0
+                    out[(size_t)y * ostep + (x0 >> 3)] = (uint8_t)b;
+                }
+            } else if (full8) {  // store 8 mask bytes
                 uint2 o = make_uint2(lo, hi);
                 __builtin_memcpy((uint8_t*)(out + (size_t)y * ostep + x0), &o, 8);
             } else if (EDGE && lane_has_out) {
@@ -576,7 +598,7 @@ __global__ void __launch_bounds__(256) k_refine(PageSetOut dst, FusedParams fp, 
         const RefItem it = rl[i];
         const unsigned r = refine64<METHOD>(fp, it.S, it.Q, it.p, (double)g[it.page].imin, g[it.page].coeff);
         if (r != 2) {
-            dst.page(it.page)[(size_t)it.y * dst.step + it.x] = (uint8_t)r;
+            store_decision(dst, fp.bit_out, it.page, it.y, it.x, r);
             atomicAdd(&g[it.page].n_refined, 1u);
         } else {
             atomicAdd(&g[it.page].n_exact, 1u);
@@ -721,7 +743,7 @@ __global__ void __launch_bounds__(256) k_fixup_final(PageSet src, PageSetOut dst
         const PageGlobals& pg = g[wi.page];
         const double T = threshold_literal(tp, m, s, (double)pg.imin, pg.coeff);
         const unsigned p = src.page(wi.page)[(size_t)wi.y * src.step + wi.x];
-        dst.page(wi.page)[(size_t)wi.y * dst.step + wi.x] = decide_literal(p, T);
+        store_decision(dst, fp.bit_out, wi.page, wi.y, wi.x, decide_literal(p, T));
     }
 }
 
@@ -911,10 +933,11 @@ size_t fused_small_bytes(int)
 }
 
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst, void* small,
-              PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop)
+              PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool bit_out)
 {
     FusedParams fp{};
     fp.tp = tp;
+    fp.bit_out = bit_out ? 1 : 0;
     fp.uo = ((SW - (tp.w - 1)) / 8) * 8;
     fp.n_strips = (tp.ow + fp.uo - 1) / fp.uo;
     // rows per segment: long segments amortise the (w-1)-row warm-up, short ones fill the chip

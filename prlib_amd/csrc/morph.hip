@@ -467,7 +467,9 @@ __device__ __forceinline__ unsigned hop_bits(unsigned c, int lane)
     return v;
 }
 
-template <int N, bool FIRST_OR>
+// BITSRC: the source is already a bit plane (1 bit per pixel, rows of src.step bytes, written by the fused threshold
+// kernel): a chunk is one 16-bit load instead of 16 bytes.
+template <int N, bool FIRST_OR, bool BITSRC>
 __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst, int width, int height, int n_strips,
                                                    int n_segs, int rows_per_seg, unsigned total_waves)
 {
@@ -501,8 +503,13 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
         if (r < 0 || r >= height) return neutral1;
         const uint8_t* row = in + (size_t)r * src.step;
         unsigned v = 0;
-        if (in0) v = pack16(*reinterpret_cast<const uint4*>(row + gx0));
-        if (in1) v |= pack16(*reinterpret_cast<const uint4*>(row + gx1)) << 16;
+        if (BITSRC) {
+            if (in0) v = *reinterpret_cast<const unsigned short*>(row + (gx0 >> 3));
+            if (in1) v |= (unsigned)*reinterpret_cast<const unsigned short*>(row + (gx1 >> 3)) << 16;
+        } else {
+            if (in0) v = pack16(*reinterpret_cast<const uint4*>(row + gx0));
+            if (in1) v |= pack16(*reinterpret_cast<const uint4*>(row + gx1)) << 16;
+        }
         return (v & inside) | (neutral1 & ~inside);
     };
 
@@ -569,6 +576,56 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
     }
 }
 
+// launches k_morph_bits; PRL_ERR_BAD_ARG when the grid would not fit (the caller falls back)
+int launch_morph_bits(int iterations, bool bitsrc, const PageSet& src, int n_pages, int width, int height,
+                      const PageSetOut& dst, hipStream_t stream)
+{
+    const int n = iterations > 0 ? iterations : -iterations;
+    const int n_strips = (width + 15 + kBitsAdvance - 1) / kBitsAdvance;
+    int rps = 128;
+    while (rps > 32 && (long long)n_pages * n_strips * ((height + rps - 1) / rps) < 16384) rps /= 2;
+    if (const char* e = std::getenv("PRL_MORPH_RPS")) rps = std::max(8, std::atoi(e));  // tuning knob
+    const int n_segs = (height + rps - 1) / rps;
+    const unsigned long long tw = (unsigned long long)n_pages * n_strips * n_segs;
+    if (tw >= 0xfffffff0ull) return PRL_ERR_BAD_ARG;
+    const dim3 grid((unsigned)((tw + 3) / 4)), block(256);
+#define PRL_LAUNCH_BITS2(NV, OR1, BS)                                                                                  \
+    hipLaunchKernelGGL((k_morph_bits<NV, OR1, BS>), grid, block, 0, stream, src, dst, width, height, n_strips, n_segs, \
+                       rps, (unsigned)tw)
+#define PRL_LAUNCH_BITS(NV)                                          \
+    do {                                                             \
+        if (iterations > 0) {                                        \
+            if (bitsrc) PRL_LAUNCH_BITS2(NV, true, true);            \
+            else PRL_LAUNCH_BITS2(NV, true, false);                  \
+        } else {                                                     \
+            if (bitsrc) PRL_LAUNCH_BITS2(NV, false, true);           \
+            else PRL_LAUNCH_BITS2(NV, false, false);                 \
+        }                                                            \
+    } while (0)
+    switch (n) {
+    case 1: PRL_LAUNCH_BITS(1); break;
+    case 2: PRL_LAUNCH_BITS(2); break;
+    case 3: PRL_LAUNCH_BITS(3); break;
+    default: PRL_LAUNCH_BITS(4); break;
+    }
+#undef PRL_LAUNCH_BITS
+#undef PRL_LAUNCH_BITS2
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
+// bytes 0 / 255 -> bit plane, one thread per 8 pixels (overflow pages redone by the literal pipeline)
+__global__ void __launch_bounds__(256) k_pack_mask(const uint8_t* __restrict__ src, size_t src_step, int width, int height,
+                                                  uint8_t* __restrict__ bits, size_t bit_step)
+{
+    const int y = blockIdx.y, xb = blockIdx.x * 256 + threadIdx.x;  // byte of the bit row
+    if (xb * 8 >= width) return;
+    const uint8_t* s = src + (size_t)y * src_step + (size_t)xb * 8;
+    unsigned b = 0;
+    for (int i = 0; i < 8 && xb * 8 + i < width; ++i) b |= (unsigned)(s[i] & 1u) << i;
+    bits[(size_t)y * bit_step + xb] = (uint8_t)b;
+}
+
 }  // namespace
 
 // The rectangle of n iterations equals n applications of the 3x3 one, and a closing/opening with
@@ -614,37 +671,11 @@ int morph_binary_run(int iterations, const PageSet& src, int n_pages, int width,
         set_error_detail("radius above " + std::to_string(kMaxN) + " goes through morph_large_run");
         return PRL_ERR_BAD_ARG;
     }
-    if (n <= kBitsMaxN && (((size_t)src.base | src.page_stride | src.step) & 15) == 0 && !src.table && !dst.table &&
+    if (n <= kBitsMaxN && (((size_t)src.base | src.page_stride | src.step) & 15) == 0 && !src.table &&
         src.step >= (size_t)((width + 15) / 16) * 16) {
         // bit-domain streaming kernel: needs 16-byte aligned source rows padded to whole 16-pixel chunks (the
         // pipeline's own mask buffer always is)
-        const int n_strips = (width + 15 + kBitsAdvance - 1) / kBitsAdvance;
-        int rps = 128;
-        while (rps > 32 && (long long)n_pages * n_strips * ((height + rps - 1) / rps) < 16384) rps /= 2;
-        if (const char* e = std::getenv("PRL_MORPH_RPS")) rps = std::max(8, std::atoi(e));
-        const int n_segs = (height + rps - 1) / rps;
-        const unsigned long long tw = (unsigned long long)n_pages * n_strips * n_segs;
-        if (tw < 0xfffffff0ull) {
-            const dim3 grid((unsigned)((tw + 3) / 4)), block(256);
-#define PRL_LAUNCH_BITS(NV)                                                                                         \
-    do {                                                                                                            \
-        if (iterations > 0)                                                                                         \
-            hipLaunchKernelGGL((k_morph_bits<NV, true>), grid, block, 0, stream, src, dst, width, height, n_strips, \
-                               n_segs, rps, (unsigned)tw);                                                          \
-        else                                                                                                        \
-            hipLaunchKernelGGL((k_morph_bits<NV, false>), grid, block, 0, stream, src, dst, width, height, n_strips, \
-                               n_segs, rps, (unsigned)tw);                                                          \
-    } while (0)
-            switch (n) {
-            case 1: PRL_LAUNCH_BITS(1); break;
-            case 2: PRL_LAUNCH_BITS(2); break;
-            case 3: PRL_LAUNCH_BITS(3); break;
-            default: PRL_LAUNCH_BITS(4); break;
-            }
-#undef PRL_LAUNCH_BITS
-            PRL_HIP_CHECK(hipGetLastError());
-            return PRL_OK;
-        }
+        if (launch_morph_bits(iterations, false, src, n_pages, width, height, dst, stream) == PRL_OK) return PRL_OK;
     }
     if ((((size_t)src.base | src.page_stride | src.step) & 3) == 0 && !src.table) {
         // streaming kernel: needs 4-byte aligned source rows (the pipeline's own mask buffer always is)
@@ -674,6 +705,28 @@ int morph_binary_run(int iterations, const PageSet& src, int n_pages, int width,
         hipLaunchKernelGGL(k_morph_binary<true>, grid, dim3(256), 0, stream, src, dst, width, height, n, btw);
     else
         hipLaunchKernelGGL(k_morph_binary<false>, grid, dim3(256), 0, stream, src, dst, width, height, n, btw);
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
+// binary masks kept as bit planes (rows of src.step bytes, 1 bit per pixel): radius <= morph_bits_max_radius()
+int morph_bits_max_radius() { return kBitsMaxN; }
+
+int morph_bitplane_run(int iterations, const PageSet& bits, int n_pages, int width, int height, const PageSetOut& dst,
+                       hipStream_t stream)
+{
+    const int n = iterations > 0 ? iterations : -iterations;
+    if (n == 0 || n > kBitsMaxN || bits.table || (((size_t)bits.base | bits.page_stride | bits.step) & 1) != 0 ||
+        bits.step < (size_t)((width + 15) / 16) * 2)
+        return PRL_ERR_BAD_ARG;
+    return launch_morph_bits(iterations, true, bits, n_pages, width, height, dst, stream);
+}
+
+int pack_mask_run(const uint8_t* src, size_t src_step, int width, int height, uint8_t* bits, size_t bit_step,
+                  hipStream_t stream)
+{
+    const dim3 grid((unsigned)(((width + 7) / 8 + 255) / 256), (unsigned)height);
+    hipLaunchKernelGGL(k_pack_mask, grid, dim3(256), 0, stream, src, src_step, width, height, bits, bit_step);
     PRL_HIP_CHECK(hipGetLastError());
     return PRL_OK;
 }

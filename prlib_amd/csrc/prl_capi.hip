@@ -330,14 +330,20 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         st = ensure_scratch(ctx, literal_per_page * literal_pages_per_chunk);
         if (st != PRL_OK) return st;
     }
+    // With morphology the thresholded mask goes to a scratch buffer first, then the morph kernel writes dst.  When the
+    // fused kernel runs and the radius allows it, that buffer is a BIT plane (1/8 B per pixel written and re-read
+    // instead of 1 B): [bit planes of all pages][one byte page for a literal redo of an overflowing page].
+    const bool bit_mask = use_fused && morph != 0 && std::abs(morph) <= morph_bits_max_radius() && !std::getenv("PRL_HIP_BYTE_MASK");
+    const size_t bit_step = ((size_t)g.out_w + 127) / 128 * 16;
+    const size_t bit_page = (bit_step * (size_t)g.out_h + 255) / 256 * 256;
     PageSetOut thr_dst = dst;
     if (morph != 0) {
-        st = ensure_mask(ctx, mask_bytes);
+        st = ensure_mask(ctx, bit_mask ? bit_page * (size_t)n_pages + mask_page : mask_bytes);
         if (st != PRL_OK) return st;
         thr_dst = PageSetOut{};
         thr_dst.base = static_cast<uint8_t*>(ctx->mask);
-        thr_dst.page_stride = mask_page;
-        thr_dst.step = mask_step;
+        thr_dst.page_stride = bit_mask ? bit_page : mask_page;
+        thr_dst.step = bit_mask ? bit_step : mask_step;
     }
 
     st = init_globals_run(d_globals, n_pages, stream);
@@ -360,7 +366,7 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         ev1 = ctx->prof_stop;
     }
     if (use_fused) {
-        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1);
+        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask);
         if (st != PRL_OK) return st;
         // Pages whose fix-up list overflowed (pathological: a large share of their pixels sits within
         // ~1e-6 of the decision boundary) are redone by the literal pipeline.  Knowing that needs the
@@ -374,7 +380,18 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
             st = ensure_scratch(ctx, literal_per_page);
             if (st != PRL_OK) return st;
             // (the page minimum Feng needs is already in the globals: fused_run reduced it)
-            st = literal_run(tp, src, i, 1, thr_dst, ctx->scratch, d_globals, stream);
+            if (bit_mask) {
+                // literal result as bytes into the spare page, then packed into this page's bit plane
+                PageSetOut one{};
+                one.base = static_cast<uint8_t*>(ctx->mask) + bit_page * (size_t)n_pages;
+                one.page_stride = 0;  // page(i) == base for every i
+                one.step = mask_step;
+                st = literal_run(tp, src, i, 1, one, ctx->scratch, d_globals, stream);
+                if (st != PRL_OK) return st;
+                st = pack_mask_run(one.base, mask_step, g.out_w, g.out_h, thr_dst.page(i), bit_step, stream);
+            } else {
+                st = literal_run(tp, src, i, 1, thr_dst, ctx->scratch, d_globals, stream);
+            }
             if (st != PRL_OK) return st;
             t_last.literal_pages += 1;
         }
@@ -398,7 +415,9 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         msrc.base = thr_dst.base;
         msrc.page_stride = thr_dst.page_stride;
         msrc.step = thr_dst.step;
-        if (std::abs(morph) <= kMorphMaxFusedRadius) {
+        if (bit_mask) {
+            st = morph_bitplane_run(morph, msrc, n_pages, g.out_w, g.out_h, dst, stream);
+        } else if (std::abs(morph) <= kMorphMaxFusedRadius) {
             st = morph_binary_run(morph, msrc, n_pages, g.out_w, g.out_h, dst, stream);
         } else {
             // large radii: chained single-operator passes through one more page-sized buffer

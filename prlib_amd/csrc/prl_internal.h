@@ -118,9 +118,10 @@ int literal_run(const ThrParams& tp, const PageSet& src, int first_page, int n_p
 
 // ---- fused pipeline (binarize_fused.hip) -------------------------------------------------------
 size_t fused_small_bytes(int n_pages);
+// bit_out: dst is a bit plane (rows of dst.step bytes, 1 bit per output pixel) instead of a 0/255 byte mask
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst,
               void* small, PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start,
-              hipEvent_t ev_stop);
+              hipEvent_t ev_stop, bool bit_out = false);
 bool fused_supports(const ThrParams& tp);
 
 // ---- morphology (morph.hip) ------------------------------------------------------------------
@@ -130,6 +131,12 @@ int morph_binary_run(int iterations, const PageSet& src, int n_pages, int width,
                      const PageSetOut& dst, hipStream_t stream);
 int morph_large_run(int iterations, const PageSet& src, int n_pages, int width, int height, const PageSetOut& dst,
                     uint8_t* tmp, size_t tmp_step, hipStream_t stream);
+int morph_bits_max_radius();
+// source = bit plane (rows of bits.step bytes, 1 bit per pixel, bit j of byte i = pixel 8 i + j)
+int morph_bitplane_run(int iterations, const PageSet& bits, int n_pages, int width, int height, const PageSetOut& dst,
+                       hipStream_t stream);
+int pack_mask_run(const uint8_t* src, size_t src_step, int width, int height, uint8_t* bits, size_t bit_step,
+                  hipStream_t stream);
 constexpr int kMorphMaxFusedRadius = 8;  // morph_run / morph_binary_run handle |iterations| up to this
 
 // ---- page reductions (binarize_literal.hip) ---------------------------------------------------
