@@ -556,7 +556,9 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
             if (c >= 2 && c <= 126 && px + 16 > 0 && px < width) {
                 const uint4 d = unpack16((bits >> (16 * half)) & 0xffffu);
                 if (px >= 0 && px + 16 <= width) {
-                    *reinterpret_cast<uint4*>(orow + px) = d;
+                    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                    const u4v dv = {d.x, d.y, d.z, d.w};
+                    __builtin_nontemporal_store(dv, reinterpret_cast<u4v*>(orow + px));  // streamed out, never re-read
                 } else {  // ragged ends of the row: dwords that lie inside, then bytes
                     const unsigned dw[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
