@@ -14,6 +14,7 @@
 // Integer/boolean throughout: bit-exact by construction.  Bound: latency/launch (each sub-iteration touches
 // 1/8 B per pixel out of L2); HBM traffic is one u8 read (pack) and one u8 write (unpack) per pixel.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "prl_internal.h"
@@ -113,7 +114,47 @@ struct Count8 {
     }
 };
 
-// One sub-iteration on the words of one row.  METHOD 0 = Zhang-Suen, 1 = Guo-Hall; `iteration` as in the reference.
+// Marker bits of one sub-iteration for the 32 pixels of word `c`, given the eight surrounding words.
+// METHOD 0 = Zhang-Suen, 1 = Guo-Hall; `iteration` as in the reference.
+template <int METHOD>
+__device__ __forceinline__ unsigned thin_mark(int iteration, unsigned c, unsigned up, unsigned dn, unsigned cl, unsigned cr,
+                                              unsigned ul, unsigned ur, unsigned dl, unsigned dr)
+{
+    // bit b of each plane = neighbour of pixel x = 32k + b      (thinZhangSuen.cpp:28-35)
+    const unsigned p2 = up;                                  // (i-1, j)
+    const unsigned p3 = (up >> 1) | (ur << 31);              // (i-1, j+1)
+    const unsigned p4 = (c >> 1) | (cr << 31);               // (i,   j+1)
+    const unsigned p5 = (dn >> 1) | (dr << 31);              // (i+1, j+1)
+    const unsigned p6 = dn;                                  // (i+1, j)
+    const unsigned p7 = (dn << 1) | (dl >> 31);              // (i+1, j-1)
+    const unsigned p8 = (c << 1) | (cl >> 31);               // (i,   j-1)
+    const unsigned p9 = (up << 1) | (ul >> 31);              // (i-1, j-1)
+    if (METHOD == 0) {
+        OneOf A;                                             // :37-40
+        A.add(~p2 & p3); A.add(~p3 & p4); A.add(~p4 & p5); A.add(~p5 & p6);
+        A.add(~p6 & p7); A.add(~p7 & p8); A.add(~p8 & p9); A.add(~p9 & p2);
+        Count8 B;                                            // :42
+        B.add(p2); B.add(p3); B.add(p4); B.add(p5); B.add(p6); B.add(p7); B.add(p8); B.add(p9);
+        const unsigned ge2 = B.s3 | B.s2 | B.s1;
+        const unsigned le6 = ~(B.s3 | (B.s2 & B.s1 & B.s0));
+        const unsigned m1 = iteration == 0 ? (p2 & p4 & p6) : (p2 & p4 & p8);   // :44
+        const unsigned m2 = iteration == 0 ? (p4 & p6 & p8) : (p2 & p6 & p8);   // :45
+        return A.exactly_one() & ge2 & le6 & ~m1 & ~m2;      // :47
+    } else {
+        OneOf Cn;                                            // thinGuoHall.cpp:40-41
+        Cn.add(~p2 & (p3 | p4)); Cn.add(~p4 & (p5 | p6)); Cn.add(~p6 & (p7 | p8)); Cn.add(~p8 & (p9 | p2));
+        Count8 N1, N2;                                       // :42-43
+        N1.add(p9 | p2); N1.add(p3 | p4); N1.add(p5 | p6); N1.add(p7 | p8);
+        N2.add(p2 | p3); N2.add(p4 | p5); N2.add(p6 | p7); N2.add(p8 | p9);
+        const unsigned n1_ge2 = N1.s2 | N1.s1, n2_ge2 = N2.s2 | N2.s1;
+        const unsigned n1_le3 = ~N1.s2, n2_le3 = ~N2.s2;
+        const unsigned n_ok = n1_ge2 & n2_ge2 & (n1_le3 | n2_le3);              // 2 <= min(N1,N2) <= 3   :44,47
+        const unsigned m = iteration == 0 ? ((p6 | p7 | ~p9) & p8) : ((p2 | p3 | ~p5) & p4);   // :45
+        return Cn.exactly_one() & n_ok & ~m;
+    }
+}
+
+// One sub-iteration on the words of one row (kept for reference / tiny pages; the passes below use k_thin_pass).
 template <int METHOD>
 __global__ void __launch_bounds__(256) k_thin_iter(const unsigned* __restrict__ in, unsigned* __restrict__ out,
                                                   size_t plane_words, int wpr, int width, int height, int iteration,
@@ -135,44 +176,8 @@ __global__ void __launch_bounds__(256) k_thin_iter(const unsigned* __restrict__ 
     unsigned res = c;
     // rows/columns 0 and last are never marked (loops run 1 .. rows-2 / 1 .. cols-2)
     if (c != 0 && y >= 1 && y <= height - 2) {
-        const unsigned up = word(y - 1, k), dn = word(y + 1, k);
-        const unsigned cl = word(y, k - 1), cr = word(y, k + 1);
-        const unsigned ul = word(y - 1, k - 1), ur = word(y - 1, k + 1);
-        const unsigned dl = word(y + 1, k - 1), dr = word(y + 1, k + 1);
-        // bit b of each plane = neighbour of pixel x = 32k + b      (thinZhangSuen.cpp:28-35)
-        const unsigned p2 = up;                                  // (i-1, j)
-        const unsigned p3 = (up >> 1) | (ur << 31);              // (i-1, j+1)
-        const unsigned p4 = (c >> 1) | (cr << 31);               // (i,   j+1)
-        const unsigned p5 = (dn >> 1) | (dr << 31);              // (i+1, j+1)
-        const unsigned p6 = dn;                                  // (i+1, j)
-        const unsigned p7 = (dn << 1) | (dl >> 31);              // (i+1, j-1)
-        const unsigned p8 = (c << 1) | (cl >> 31);               // (i,   j-1)
-        const unsigned p9 = (up << 1) | (ul >> 31);              // (i-1, j-1)
-        unsigned mark;
-        if (METHOD == 0) {
-            OneOf A;                                             // :37-40
-            A.add(~p2 & p3); A.add(~p3 & p4); A.add(~p4 & p5); A.add(~p5 & p6);
-            A.add(~p6 & p7); A.add(~p7 & p8); A.add(~p8 & p9); A.add(~p9 & p2);
-            Count8 B;                                            // :42
-            B.add(p2); B.add(p3); B.add(p4); B.add(p5); B.add(p6); B.add(p7); B.add(p8); B.add(p9);
-            const unsigned ge2 = B.s3 | B.s2 | B.s1;
-            const unsigned le6 = ~(B.s3 | (B.s2 & B.s1 & B.s0));
-            const unsigned m1 = iteration == 0 ? (p2 & p4 & p6) : (p2 & p4 & p8);   // :44
-            const unsigned m2 = iteration == 0 ? (p4 & p6 & p8) : (p2 & p6 & p8);   // :45
-            mark = A.exactly_one() & ge2 & le6 & ~m1 & ~m2;      // :47
-        } else {
-            OneOf Cn;                                            // thinGuoHall.cpp:40-41
-            Cn.add(~p2 & (p3 | p4)); Cn.add(~p4 & (p5 | p6)); Cn.add(~p6 & (p7 | p8)); Cn.add(~p8 & (p9 | p2));
-            Count8 N1, N2;                                       // :42-43
-            N1.add(p9 | p2); N1.add(p3 | p4); N1.add(p5 | p6); N1.add(p7 | p8);
-            N2.add(p2 | p3); N2.add(p4 | p5); N2.add(p6 | p7); N2.add(p8 | p9);
-            const unsigned n1_ge2 = N1.s2 | N1.s1, n2_ge2 = N2.s2 | N2.s1;
-            const unsigned n1_le3 = ~N1.s2, n2_le3 = ~N2.s2;
-            const unsigned n_ok = n1_ge2 & n2_ge2 & (n1_le3 | n2_le3);              // 2 <= min(N1,N2) <= 3   :44,47
-            const unsigned m = iteration == 0 ? ((p6 | p7 | ~p9) & p8) : ((p2 | p3 | ~p5) & p4);   // :45
-            mark = Cn.exactly_one() & n_ok & ~m;
-        }
-        // columns 0 and width-1 never marked; bits beyond the row are zero anyway
+        unsigned mark = thin_mark<METHOD>(iteration, c, word(y - 1, k), word(y + 1, k), word(y, k - 1), word(y, k + 1),
+                                          word(y - 1, k - 1), word(y - 1, k + 1), word(y + 1, k - 1), word(y + 1, k + 1));
         unsigned col_ok = 0xffffffffu;
         if (k == 0) col_ok &= ~1u;
         const int last = width - 1;
@@ -183,6 +188,83 @@ __global__ void __launch_bounds__(256) k_thin_iter(const unsigned* __restrict__ 
     out[(size_t)page * plane_words + gid] = res;
     // one plain store per wave that changed something (every writer stores the same 1: no atomic needed)
     if (__ballot(res != c) != 0ull && (threadIdx.x & 63) == 0) changed[page] = 1u;
+}
+
+// One whole pass (both sub-iterations, thinZhangSuen.cpp:90-91) in one launch.  A wavefront streams down a strip of 64
+// words: a lane keeps the last three input rows of its word, gets the left / right words from its neighbour lanes
+// (DPP wave_shr/shl:1), forms sub-iteration 1 for the middle row, keeps the last three such rows and forms
+// sub-iteration 2 one row behind - registers only, one load and one store per word and pass (the per-sub-iteration
+// kernel above reads nine words and needs two launches).  Lanes 0,1 / 62,63 and two rows above / below a segment are
+// halo.
+constexpr int kThinUseful = 60;  // output words per 64-lane strip (lanes 2 .. 61)
+
+__device__ __forceinline__ unsigned lane_dn(unsigned v)  // word of lane - 1 (0 at the wavefront edge)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned lane_up(unsigned v)  // word of lane + 1
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+}
+
+template <int METHOD>
+__global__ void __launch_bounds__(256) k_thin_pass(const unsigned* __restrict__ in, unsigned* __restrict__ out,
+                                                  size_t plane_words, int wpr, int width, int height, int n_strips,
+                                                  int n_segs, int rows_per_seg, unsigned total_waves,
+                                                  unsigned* __restrict__ changed, const unsigned* __restrict__ done)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
+    if (wid >= total_waves) return;
+    const int per_page = n_strips * n_segs;
+    const int page = (int)(wid / (unsigned)per_page);
+    if (done[page]) return;  // converged: its bit plane is final and stays in buffer A
+    const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
+    const int seg = rem / n_strips, strip = rem - seg * n_strips;
+    const int k = strip * kThinUseful - 2 + lane;  // this lane's word of the row
+    const bool kin = k >= 0 && k < wpr;
+    const unsigned* pin = in + (size_t)page * plane_words + (kin ? k : 0);
+    unsigned* pout = out + (size_t)page * plane_words + (kin ? k : 0);
+    const int ys = seg * rows_per_seg, ye = min(ys + rows_per_seg, height);
+    // columns 0 and width-1 are never marked; bits beyond the row are zero anyway
+    unsigned col_ok = 0xffffffffu;
+    if (k == 0) col_ok &= ~1u;
+    if (((width - 1) >> 5) == k) col_ok &= ~(1u << ((width - 1) & 31));
+
+    auto fetch = [&](int r) -> unsigned { return (kin && r >= 0 && r < height) ? pin[(size_t)r * wpr] : 0u; };
+
+    // input rows r-2, r-1, r with their neighbour words; sub-iteration-1 rows r-3, r-2, r-1 likewise
+    unsigned a0 = 0, a0l = 0, a0r = 0, a1 = 0, a1l = 0, a1r = 0;          // a0 = in[r-2], a1 = in[r-1]
+    unsigned b0 = 0, b0l = 0, b0r = 0, b1 = 0, b1l = 0, b1r = 0;          // b0 = I1[r-3], b1 = I1[r-2]
+    bool any_change = false;
+    unsigned vnext = fetch(ys - 2);
+#pragma unroll 1
+    for (int r = ys - 2; r <= ye + 1; ++r) {
+        const unsigned a2 = vnext;
+        vnext = fetch(r + 1);
+        const unsigned a2l = lane_dn(a2), a2r = lane_up(a2);
+        // sub-iteration 1 for row r-1 (rows 0 and height-1 are never marked)
+        // (a word without foreground cannot lose a pixel: whole wavefronts of background skip the logic)
+        unsigned i1 = a1;
+        if (r - 1 >= 1 && r - 1 <= height - 2 && __ballot(a1 != 0u) != 0ull)
+            i1 = a1 & ~(thin_mark<METHOD>(0, a1, a0, a2, a1l, a1r, a0l, a0r, a2l, a2r) & col_ok);
+        const unsigned i1l = lane_dn(i1), i1r = lane_up(i1);
+        // sub-iteration 2 for row r-2
+        unsigned o = b1;
+        if (r - 2 >= 1 && r - 2 <= height - 2 && __ballot(b1 != 0u) != 0ull)
+            o = b1 & ~(thin_mark<METHOD>(1, b1, b0, i1, b1l, b1r, b0l, b0r, i1l, i1r) & col_ok);
+        const int ro = r - 2;
+        if (ro >= ys && ro < ye && lane >= 2 && lane <= 61 && kin) {
+            pout[(size_t)ro * wpr] = o;
+            any_change |= (o != a0);  // a0 = in[r-2]: the word this pass started from
+        }
+        // shift the windows
+        a0 = a1; a0l = a1l; a0r = a1r;
+        a1 = a2; a1l = a2l; a1r = a2r;
+        b0 = b1; b0l = b1l; b0r = b1r;
+        b1 = i1; b1l = i1l; b1r = i1r;
+    }
+    if (__ballot(any_change) != 0ull && lane == 0) changed[page] = 1u;
 }
 
 // after both sub-iterations of a pass: a page whose pass changed nothing is final (do-while test, :93-96)
@@ -246,19 +328,28 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
     std::vector<unsigned> h_done((size_t)n_pages);
     const int max_passes = std::max(width, height) + 2;  // every effective pass removes at least one pixel layer
     const int group = 4;                                 // passes per host check; extra passes change nothing
+    // one launch per pass: strips of 60 words x segments of rows, one wavefront each
+    const int n_strips = (wpr + kThinUseful - 1) / kThinUseful;
+    int rps = 256;  // measured (16 A4 pages): 32 rows 31 us per pass, 16: 26, 8: 26, 4: 31
+    while (rps > 16 && (long long)n_pages * n_strips * ((height + rps - 1) / rps) < 16384) rps /= 2;
+    if (const char* e = std::getenv("PRL_THIN_RPS")) rps = std::max(4, std::atoi(e));
+    const int n_segs = (height + rps - 1) / rps;
+    const unsigned long long tw = (unsigned long long)n_pages * n_strips * n_segs;
+    if (tw >= 0xfffffff0ull) return PRL_ERR_BAD_ARG;
+    const dim3 gp((unsigned)((tw + 3) / 4));
+    // Passes alternate A -> B -> A.  The pass that finds a page unchanged has just written a copy of its input, so
+    // from then on BOTH buffers hold that page's final plane (later passes skip it): k_thin_unpack can always read A.
     for (int pass = 0; pass < max_passes;) {
         for (int gidx = 0; gidx < group && pass < max_passes; ++gidx, ++pass) {
-            for (int it = 0; it < 2; ++it) {
-                const unsigned* in = it == 0 ? A : B;
-                unsigned* out = it == 0 ? B : A;
-                if (method == PRL_THIN_ZHANGSUEN)
-                    hipLaunchKernelGGL(k_thin_iter<0>, gw, dim3(256), 0, s, in, out, plane_words, wpr, width, height, it,
-                                       changed, done);
-                else
-                    hipLaunchKernelGGL(k_thin_iter<1>, gw, dim3(256), 0, s, in, out, plane_words, wpr, width, height, it,
-                                       changed, done);
-                PRL_HIP_CHECK(hipGetLastError());
-            }
+            const unsigned* in = (pass & 1) ? B : A;
+            unsigned* out = (pass & 1) ? A : B;
+            if (method == PRL_THIN_ZHANGSUEN)
+                hipLaunchKernelGGL(k_thin_pass<0>, gp, dim3(256), 0, s, in, out, plane_words, wpr, width, height, n_strips,
+                                   n_segs, rps, (unsigned)tw, changed, done);
+            else
+                hipLaunchKernelGGL(k_thin_pass<1>, gp, dim3(256), 0, s, in, out, plane_words, wpr, width, height, n_strips,
+                                   n_segs, rps, (unsigned)tw, changed, done);
+            PRL_HIP_CHECK(hipGetLastError());
             hipLaunchKernelGGL(k_thin_endpass, dim3((n_pages + 255) / 256), dim3(256), 0, s, changed, done, n_pages);
             PRL_HIP_CHECK(hipGetLastError());
         }
