@@ -303,3 +303,35 @@ def test_unaligned_output_pitch(prl, oracle, cuda_device, method, morph):
     big[:, :, 3:1045] = dev_pages
     got2 = prl.binarize(big[:, :, 3:1045], p).cpu().numpy()
     assert np.array_equal(got2, got)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PRL_SWEEP_SEEDS", "24"))))
+def test_random_sweep(prl, oracle, cuda_device, seed):
+    """Seeded random configurations: shape, method, window, k, morphology radius (bit-plane and byte hand-off paths),
+    page kinds, and an output view with a row step larger than the row."""
+    import torch
+
+    rng = np.random.default_rng(1000 + seed)
+    method = int(rng.integers(0, 5))
+    h, w = int(rng.integers(40, 330)), int(rng.integers(40, 700))
+    win = int(rng.choice([3, 5, 7, 9, 15, 21, 31, 33, 35, 41, 51, 101]))
+    if method in (WOLFJOLION, NICK, FENG):  # output (H-w) x (W-w) must not be empty
+        win = min(win, 2 * ((min(h, w) - 2) // 2) - 1)
+    k = float(rng.choice([0.34, 0.2, 0.01, -0.01, -0.2, 0.5]))
+    morph = int(rng.choice([0, 0, 1, 2, 2, -1, -2, 3, 4, -4, 5, 8]))
+    kinds = [str(x) for x in rng.choice(["doc", "noise", "binary", "flat", "ramp", "dark_corner", "white", "black"], 3)]
+    pages = _pages((h, w), kinds, seed=seed + 50)
+    params = prl.make_params(method, win, k, morph)
+    g = prl.geometry(params, w, h)
+    dev_pages = torch.from_numpy(np.stack(pages)).to(cuda_device)
+    pad = int(rng.integers(0, 9))
+    buf = torch.full((3, g.out_h, g.out_w + pad), 77, dtype=torch.uint8, device=cuda_device)
+    out = buf[:, :, :g.out_w]
+    prl.binarize(dev_pages, params, out=out)
+    got = buf.cpu().numpy()
+    p = oracle.make_params(method, win, k, morph)
+    for i, pg in enumerate(pages):
+        want = oracle.binarize(pg, p)
+        bad = int((got[i, :, :g.out_w] != want).sum())
+        assert bad == 0, f"seed {seed} page {i} ({kinds[i]}): {bad} mismatches, method {method} w {win} k {k} morph {morph} {h}x{w}"
+    assert (got[:, :, g.out_w:] == 77).all()

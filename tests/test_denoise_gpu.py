@@ -95,3 +95,24 @@ def test_golden_nlm_fixture_on_device(prl, cuda_device):
     assert np.array_equal(prl.nlm_planes(dev_l, 10.0).cpu().numpy(), z["l_h10"])
     assert np.array_equal(prl.nlm_planes(dev_ab, 3.0).cpu().numpy(), z["ab_h3"])
     assert np.array_equal(prl.denoise(torch.from_numpy(z["noisy"]).to(cuda_device), 10.0).cpu().numpy(), z["denoised_s10"])
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PRL_SWEEP_SEEDS", "12"))))
+def test_nlm_random_sweep(prl, oracle, cuda_device, seed):
+    """Seeded random shapes (tile-ragged, narrower than the halo), channel counts, strengths and noise levels."""
+    import torch
+
+    rng = np.random.default_rng(7000 + seed)
+    h, w = int(rng.integers(1, 150)), int(rng.integers(1, 200))
+    channels = int(rng.choice([1, 1, 2, 2, 3]))
+    strength = float(rng.choice([1.0, 3.0, 5.5, 10.0, 14.0, 25.0]))
+    sigma = float(rng.choice([0.0, 4.0, 15.0, 40.0]))
+    img = _noisy((h, w), seed=seed, sigma=sigma, channels=None if channels == 1 else channels)
+    got = prl.nlm_planes(torch.from_numpy(img).to(cuda_device), strength).cpu().numpy()
+    want = oracle.nlm_planes(img, strength, threads=8)
+    assert np.array_equal(got, want), f"seed {seed}: {int((got != want).sum())} mismatches ({h}x{w}x{channels}, h={strength}, sigma={sigma})"
+    if seed % 3 == 0:  # the colour pipeline on the same geometry
+        c = 3 + (seed % 2)
+        col = _noisy((h, w), seed=seed + 1, sigma=sigma, channels=c)
+        got = prl.denoise(torch.from_numpy(col).to(cuda_device), strength).cpu().numpy()
+        assert np.array_equal(got, oracle.denoise(col, strength, threads=8))
