@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
 {
     constexpr int K = 2 * N + 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
+    const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wv);
     if (wid >= total_waves) return;
     const int per_page = n_strips * n_segs;
     const int page = (int)(wid / (unsigned)per_page);
@@ -590,7 +590,9 @@ int launch_morph_bits(int iterations, bool bitsrc, const PageSet& src, int n_pag
     const int n_segs = (height + rps - 1) / rps;
     const unsigned long long tw = (unsigned long long)n_pages * n_strips * n_segs;
     if (tw >= 0xfffffff0ull) return PRL_ERR_BAD_ARG;
-    const dim3 grid((unsigned)((tw + 3) / 4)), block(256);
+    // independent wavefronts: one per workgroup refills a finished slot at once (see launch_sweep in binarize_fused.hip)
+    const unsigned wpb = std::getenv("PRL_MORPH_WPB") ? (unsigned)std::max(1, std::min(4, std::atoi(std::getenv("PRL_MORPH_WPB")))) : 1u;
+    const dim3 grid((unsigned)((tw + wpb - 1) / wpb)), block(64 * wpb);
 #define PRL_LAUNCH_BITS2(NV, OR1, BS)                                                                                  \
     hipLaunchKernelGGL((k_morph_bits<NV, OR1, BS>), grid, block, 0, stream, src, dst, width, height, n_strips, n_segs, \
                        rps, (unsigned)tw)

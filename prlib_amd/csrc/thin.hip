@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256) k_thin_pass(const unsigned* __restrict__ 
                                                   unsigned* __restrict__ changed, const unsigned* __restrict__ done)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wv);
+    const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wv);
     if (wid >= total_waves) return;
     const int per_page = n_strips * n_segs;
     const int page = (int)(wid / (unsigned)per_page);
@@ -336,7 +336,8 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
     const int n_segs = (height + rps - 1) / rps;
     const unsigned long long tw = (unsigned long long)n_pages * n_strips * n_segs;
     if (tw >= 0xfffffff0ull) return PRL_ERR_BAD_ARG;
-    const dim3 gp((unsigned)((tw + 3) / 4));
+    const unsigned wpb = std::getenv("PRL_THIN_WPB") ? (unsigned)std::max(1, std::min(4, std::atoi(std::getenv("PRL_THIN_WPB")))) : 4u;
+    const dim3 gp((unsigned)((tw + wpb - 1) / wpb)), bp(64 * wpb);  // short wavefronts: 4 per workgroup measured best (26.1 vs 28.4 us)
     // Passes alternate A -> B -> A.  The pass that finds a page unchanged has just written a copy of its input, so
     // from then on BOTH buffers hold that page's final plane (later passes skip it): k_thin_unpack can always read A.
     for (int pass = 0; pass < max_passes;) {
@@ -344,10 +345,10 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
             const unsigned* in = (pass & 1) ? B : A;
             unsigned* out = (pass & 1) ? A : B;
             if (method == PRL_THIN_ZHANGSUEN)
-                hipLaunchKernelGGL(k_thin_pass<0>, gp, dim3(256), 0, s, in, out, plane_words, wpr, width, height, n_strips,
+                hipLaunchKernelGGL(k_thin_pass<0>, gp, bp, 0, s, in, out, plane_words, wpr, width, height, n_strips,
                                    n_segs, rps, (unsigned)tw, changed, done);
             else
-                hipLaunchKernelGGL(k_thin_pass<1>, gp, dim3(256), 0, s, in, out, plane_words, wpr, width, height, n_strips,
+                hipLaunchKernelGGL(k_thin_pass<1>, gp, bp, 0, s, in, out, plane_words, wpr, width, height, n_strips,
                                    n_segs, rps, (unsigned)tw, changed, done);
             PRL_HIP_CHECK(hipGetLastError());
             hipLaunchKernelGGL(k_thin_endpass, dim3((n_pages + 255) / 256), dim3(256), 0, s, changed, done, n_pages);
