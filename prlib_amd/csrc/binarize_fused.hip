@@ -781,6 +781,7 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     // 1: 4.13 - a finished wavefront's slot is refilled at once instead of when its whole workgroup has drained)
     unsigned wpb = ring ? 2u : 1u;
     if (const char* e = std::getenv("PRL_HIP_WPB")) wpb = (unsigned)std::max(1, std::min(4, std::atoi(e)));
+    if (fp.total_waves > 0x7fffff00u) wpb = std::max(wpb, 4u);  // grid.x is limited to 2^31 - 1 workgroups
     unsigned blocks = (fp.total_waves + wpb - 1) / wpb;
     blocks = (blocks + 7) / 8 * 8;
     const dim3 grid(blocks), block(64 * wpb);

@@ -592,6 +592,7 @@ int launch_morph_bits(int iterations, bool bitsrc, const PageSet& src, int n_pag
     if (tw >= 0xfffffff0ull) return PRL_ERR_BAD_ARG;
     // independent wavefronts: one per workgroup refills a finished slot at once (see launch_sweep in binarize_fused.hip)
     const unsigned wpb = std::getenv("PRL_MORPH_WPB") ? (unsigned)std::max(1, std::min(4, std::atoi(std::getenv("PRL_MORPH_WPB")))) : 1u;
+    if ((tw + wpb - 1) / wpb > 0x7fffff00ull) return PRL_ERR_BAD_ARG;  // grid.x limit: the caller falls back
     const dim3 grid((unsigned)((tw + wpb - 1) / wpb)), block(64 * wpb);
 #define PRL_LAUNCH_BITS2(NV, OR1, BS)                                                                                  \
     hipLaunchKernelGGL((k_morph_bits<NV, OR1, BS>), grid, block, 0, stream, src, dst, width, height, n_strips, n_segs, \

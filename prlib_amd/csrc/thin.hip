@@ -154,47 +154,11 @@ __device__ __forceinline__ unsigned thin_mark(int iteration, unsigned c, unsigne
     }
 }
 
-// One sub-iteration on the words of one row (kept for reference / tiny pages; the passes below use k_thin_pass).
-template <int METHOD>
-__global__ void __launch_bounds__(256) k_thin_iter(const unsigned* __restrict__ in, unsigned* __restrict__ out,
-                                                  size_t plane_words, int wpr, int width, int height, int iteration,
-                                                  unsigned* __restrict__ changed, const unsigned* __restrict__ done)
-{
-    const int page = blockIdx.y;
-    if (done[page]) return;  // converged: its bit plane is final and stays in buffer A
-    const unsigned gid = blockIdx.x * 256u + threadIdx.x;  // 32-bit index math (64-bit division is ~10x slower)
-    if (gid >= plane_words) return;
-    const int y = (int)(gid / (unsigned)wpr), k = (int)(gid - (unsigned)y * (unsigned)wpr);
-    const unsigned* base = in + (size_t)page * plane_words;
-    // clamped (always valid) addresses, out-of-image words forced to zero afterwards: no divergent branches
-    auto word = [&](int yy, int kk) -> unsigned {
-        const int yc = min(max(yy, 0), height - 1), kc = min(max(kk, 0), wpr - 1);
-        const unsigned v = base[(size_t)yc * wpr + kc];
-        return (yy == yc && kk == kc) ? v : 0u;
-    };
-    const unsigned c = word(y, k);
-    unsigned res = c;
-    // rows/columns 0 and last are never marked (loops run 1 .. rows-2 / 1 .. cols-2)
-    if (c != 0 && y >= 1 && y <= height - 2) {
-        unsigned mark = thin_mark<METHOD>(iteration, c, word(y - 1, k), word(y + 1, k), word(y, k - 1), word(y, k + 1),
-                                          word(y - 1, k - 1), word(y - 1, k + 1), word(y + 1, k - 1), word(y + 1, k + 1));
-        unsigned col_ok = 0xffffffffu;
-        if (k == 0) col_ok &= ~1u;
-        const int last = width - 1;
-        if ((last >> 5) == k) col_ok &= ~(1u << (last & 31));
-        mark &= col_ok;
-        res = c & ~mark;                                         // imageUnderProcessing &= ~marker   :54
-    }
-    out[(size_t)page * plane_words + gid] = res;
-    // one plain store per wave that changed something (every writer stores the same 1: no atomic needed)
-    if (__ballot(res != c) != 0ull && (threadIdx.x & 63) == 0) changed[page] = 1u;
-}
-
 // One whole pass (both sub-iterations, thinZhangSuen.cpp:90-91) in one launch.  A wavefront streams down a strip of 64
 // words: a lane keeps the last three input rows of its word, gets the left / right words from its neighbour lanes
 // (DPP wave_shr/shl:1), forms sub-iteration 1 for the middle row, keeps the last three such rows and forms
-// sub-iteration 2 one row behind - registers only, one load and one store per word and pass (the per-sub-iteration
-// kernel above reads nine words and needs two launches).  Lanes 0,1 / 62,63 and two rows above / below a segment are
+// sub-iteration 2 one row behind - registers only, one load and one store per word and pass (a kernel per
+// sub-iteration reads nine words per word and needs two launches).  Lanes 0,1 / 62,63 and two rows above / below a segment are
 // halo.
 constexpr int kThinUseful = 60;  // output words per 64-lane strip (lanes 2 .. 61)
 
