@@ -54,6 +54,7 @@ struct WorkItem {  // undecided after the float64 interval test
 constexpr int kWolfMax = 100;      // sweep A: float32 variance maximum per page and per wavefront
 constexpr int kWolfCollect = 101;  // sweep B: queue every pixel whose variance could be the literal maximum
 
+constexpr unsigned kSBias = 0x4B000000u;  // float 2^23: window sums S <= 255 * 256^2 < 2^23 ride in its mantissa
 constexpr float kZ = 1073741824.0f;  // 2^30: every float32 threshold quantity is carried times Z (exact scaling)
 
 struct PageK {  // per-page constants of the float32 test
@@ -127,7 +128,9 @@ template <int METHOD>
 __device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsigned Q, float P2, const PageK& pk,
                                         float* k_out)
 {
-    const float Sf = (float)S, Qf = (float)Q;      // S < 2^24: exact
+    // S arrives as 0x4B000000 + S (the horizontal sum carries that bias), whose bit pattern is the float 2^23 + S for
+    // S < 2^23: one 2-cycle v_sub_f32 instead of the 4-cycle v_cvt_f32_u32 (profiles/r01/valu_issue_costs.txt)
+    const float Sf = __uint_as_float(S) - 8388608.0f, Qf = (float)Q;
     const float K = fmaf(fp.w2f, Qf, -(Sf * Sf));
     *k_out = K;
     if (METHOD == PRL_SAUVOLA) {
@@ -379,13 +382,14 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
         }
         }
 #undef PRL_W_STEP
+        const unsigned w0sb = w0s + kSBias, w1sb = w1s + kSBias;  // Ssum comes out as kSBias + S (see eval32)
         unsigned Ssum[CPL], Qsum[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const int sub = (c + SH) & 7;  // compile-time
             const bool far1 = (c + SH) >= 8;
             const int addr = far1 ? far_addr1 : far_addr0;
-            Ssum[c] = ((unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)ES[sub]) - ES[c]) + (far1 ? w1s : w0s);
+            Ssum[c] = ((unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)ES[sub]) - ES[c]) + (far1 ? w1sb : w0sb);
             Qsum[c] = ((unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)EQ[sub]) - EQ[c]) + (far1 ? w1q : w0q);
         }
 
@@ -471,7 +475,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                             it.page = page;
                             it.y = y;
                             it.x = x0 + c;
-                            it.S = S;
+                            it.S = S - kSBias;
                             it.Q = Q;
                             it.p = p;
                             rl[idx] = it;
@@ -925,7 +929,7 @@ extern "C" int prl_hip_internal_fused_bounds(const prl_binarize_params* p, int w
 bool fused_supports(const ThrParams& tp)
 {
     if (((tp.w - 1) & 1) != 0) return false;                 // even (clamped) window: rare, literal
-    if (tp.w - 1 > 256 || tp.w < 3) return false;            // window sums must stay exact in float32/u32
+    if (tp.w - 1 > 181 || tp.w < 3) return false;            // 255 (w-1)^2 < 2^23: S rides in the mantissa of 2^23 (kSBias)
     if (tp.width < 16) return false;                         // the 8-byte row fetch needs a row to clamp into
     if (!std::isfinite(tp.k) || std::fabs(tp.k) > 1e3) return false;
     if (tp.method == PRL_FENG && !(tp.gamma > 0.0)) return false;
