@@ -90,6 +90,13 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). prlib_amd has no CPU fallback.")
+        # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7.  When torch is going to be used (it owns
+        # the device tensors of the Python layer), it must be loaded FIRST so that this library binds to the same
+        # runtime; loaded the other way round, two runtimes open the device and the second finds none.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
         P = C.POINTER
