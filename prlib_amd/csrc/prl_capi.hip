@@ -145,16 +145,27 @@ int ensure_stage_pinned(DeviceCtx* ctx, size_t bytes)
     return PRL_OK;
 }
 
+// The copies run in bands of rows so that the CPU's memcpy of one band overlaps the DMA of the previous one.
+namespace {
+constexpr size_t kStageBand = (size_t)2 << 20;  // ~2 MiB per band
+int rows_per_band(size_t row_bytes, int rows) { return (int)std::max<size_t>(1, std::min<size_t>((size_t)rows, kStageBand / std::max<size_t>(row_bytes, 1))); }
+}  // namespace
+
 int stage_upload(DeviceCtx* ctx, size_t pin_off, const uint8_t* src, size_t src_step, size_t row_bytes, int rows,
                  uint8_t* d_dst, hipStream_t stream)
 {
     uint8_t* pin = static_cast<uint8_t*>(ctx->stage_pinned) + pin_off;
-    if (src_step == row_bytes) {
-        std::memcpy(pin, src, row_bytes * (size_t)rows);
-    } else {
-        for (int y = 0; y < rows; ++y) std::memcpy(pin + (size_t)y * row_bytes, src + (size_t)y * src_step, row_bytes);
+    const int band = rows_per_band(row_bytes, rows);
+    for (int y0 = 0; y0 < rows; y0 += band) {
+        const int n = std::min(band, rows - y0);
+        uint8_t* p = pin + (size_t)y0 * row_bytes;
+        if (src_step == row_bytes) {
+            std::memcpy(p, src + (size_t)y0 * src_step, row_bytes * (size_t)n);
+        } else {
+            for (int y = 0; y < n; ++y) std::memcpy(p + (size_t)y * row_bytes, src + (size_t)(y0 + y) * src_step, row_bytes);
+        }
+        PRL_HIP_CHECK(hipMemcpyAsync(d_dst + (size_t)y0 * row_bytes, p, row_bytes * (size_t)n, hipMemcpyHostToDevice, stream));
     }
-    PRL_HIP_CHECK(hipMemcpyAsync(d_dst, pin, row_bytes * (size_t)rows, hipMemcpyHostToDevice, stream));
     return PRL_OK;
 }
 
@@ -162,12 +173,29 @@ int stage_download(DeviceCtx* ctx, size_t pin_off, const uint8_t* d_src, size_t 
                    size_t dst_step, hipStream_t stream)
 {
     uint8_t* pin = static_cast<uint8_t*>(ctx->stage_pinned) + pin_off;
-    PRL_HIP_CHECK(hipMemcpyAsync(pin, d_src, row_bytes * (size_t)rows, hipMemcpyDeviceToHost, stream));
-    PRL_HIP_CHECK(hipStreamSynchronize(stream));
-    if (dst_step == row_bytes) {
-        std::memcpy(dst, pin, row_bytes * (size_t)rows);
-    } else {
-        for (int y = 0; y < rows; ++y) std::memcpy(dst + (size_t)y * dst_step, pin + (size_t)y * row_bytes, row_bytes);
+    const int band = rows_per_band(row_bytes, rows);
+    const int n_bands = (rows + band - 1) / band;
+    // one event per band: the host copies band k out of the bounce buffer while bands k+1.. are still in flight
+    while ((int)ctx->stage_events.size() < n_bands) {
+        hipEvent_t e;
+        PRL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->stage_events.push_back(e);
+    }
+    for (int k = 0; k < n_bands; ++k) {
+        const int y0 = k * band, n = std::min(band, rows - y0);
+        PRL_HIP_CHECK(hipMemcpyAsync(pin + (size_t)y0 * row_bytes, d_src + (size_t)y0 * row_bytes, row_bytes * (size_t)n,
+                                     hipMemcpyDeviceToHost, stream));
+        PRL_HIP_CHECK(hipEventRecord(ctx->stage_events[(size_t)k], stream));
+    }
+    for (int k = 0; k < n_bands; ++k) {
+        const int y0 = k * band, n = std::min(band, rows - y0);
+        PRL_HIP_CHECK(hipEventSynchronize(ctx->stage_events[(size_t)k]));
+        const uint8_t* p = pin + (size_t)y0 * row_bytes;
+        if (dst_step == row_bytes) {
+            std::memcpy(dst + (size_t)y0 * dst_step, p, row_bytes * (size_t)n);
+        } else {
+            for (int y = 0; y < n; ++y) std::memcpy(dst + (size_t)(y0 + y) * dst_step, p + (size_t)y * row_bytes, row_bytes);
+        }
     }
     return PRL_OK;
 }

@@ -6,6 +6,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <mutex>
+#include <vector>
 #include <string>
 
 #include "../../include/prl_hip.h"
@@ -39,6 +40,7 @@ struct DeviceCtx {
     size_t stage_bytes = 0;
     void* stage_pinned = nullptr;  // pinned host bounce buffer of the *_host entry points (same lock)
     size_t stage_pinned_bytes = 0;
+    std::vector<hipEvent_t> stage_events;  // one per download band (same lock)
     void* pinned = nullptr; // pinned host staging for tiny transfers
     size_t pinned_bytes = 0;
     int cu_count = 0;
