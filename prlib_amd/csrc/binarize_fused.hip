@@ -233,39 +233,33 @@ __device__ __forceinline__ uint2 gload8(gcptr p)
     return v;
 }
 
-// Per-lane constants of the replicate clamp for an 8-byte row fetch: the fetch address is clamped
-// into the row and the bytes are shifted/filled afterwards (edge strips only).
+// Per-lane constants of the replicate clamp for an 8-byte row fetch: the fetch address is clamped into the row
+// (colc) and the wanted bytes are picked out of the fetched ones afterwards (edge strips only).  Wanted byte c is
+// image column clamp(col + c, 0, W-1) = fetched byte clamp(col + c, 0, W-1) - colc, a fixed byte permutation per
+// lane: two v_perm_b32 per fetch (the first version shifted and filled through 64-bit arithmetic, ~20 instructions).
 struct EdgeFix {
-    int colc;   // clamped fetch column
-    int sh;     // wanted column - fetch column: <0 fill from the left edge, >0 from the right edge
+    int colc;        // clamped fetch column
+    unsigned selx;   // v_perm_b32 selectors for wanted bytes 0..3 and 4..7 (0..3 = low dword, 4..7 = high dword)
+    unsigned sely;
 };
 
 __device__ __forceinline__ EdgeFix make_edge(int col, int W)
 {
     EdgeFix e;
     e.colc = clampi(col, 0, W - 8);
-    e.sh = col - e.colc;
+    e.selx = e.sely = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const unsigned idx = (unsigned)(clampi(col + c, 0, W - 1) - e.colc);  // 0..7
+        if (c < 4) e.selx |= idx << (8 * c);
+        else e.sely |= idx << (8 * (c - 4));
+    }
     return e;
 }
 
-__device__ __forceinline__ uint2 apply_edge(uint2 v, int sh)
+__device__ __forceinline__ uint2 apply_edge(uint2 v, const EdgeFix& e)
 {
-    if (sh != 0) {
-        unsigned long long x = ((unsigned long long)v.y << 32) | v.x;
-        const unsigned long long ones = 0x0101010101010101ull;
-        if (sh < 0) {
-            const int k = min(-sh, 8);
-            const unsigned long long b0 = (x & 0xffull) * ones;
-            x = (k >= 8) ? b0 : ((x << (8 * k)) | (b0 & ((1ull << (8 * k)) - 1ull)));
-        } else {
-            const int k = min(sh, 8);
-            const unsigned long long b7 = (x >> 56) * ones;
-            x = (k >= 8) ? b7 : ((x >> (8 * k)) | (b7 << (64 - 8 * k)));
-        }
-        v.x = (unsigned)x;
-        v.y = (unsigned)(x >> 32);
-    }
-    return v;
+    return make_uint2(__builtin_amdgcn_perm(v.y, v.x, e.selx), __builtin_amdgcn_perm(v.y, v.x, e.sely));
 }
 
 // One wavefront: a strip of SW padded columns x a segment of output rows.
@@ -286,7 +280,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     const int x0 = xs + CPL * lane;            // first output column of this lane
     const bool lane_has_out = (CPL * lane < fp.uo) && (x0 < tp.ow);
     const bool full8 = lane_has_out && (x0 + CPL <= tp.ow);
-    const EdgeFix ew = EDGE ? make_edge(col0, W) : EdgeFix{col0, 0};
+    const EdgeFix ew = EDGE ? make_edge(col0, W) : EdgeFix{col0, 0x03020100u, 0x07060504u};
     const EdgeFix ep = make_edge(x0, W);  // lanes without output fetch a clamped (ignored) location
     const int far_addr0 = (lane + fp.lane_off) * 4;  // ds_bpermute byte address of the lane holding E(j0+w-1)
     const int far_addr1 = far_addr0 + 4;
@@ -294,7 +288,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     auto load_win = [&](int padded_row) -> uint2 {
         const size_t ro = (size_t)clampi(padded_row - h, 0, H - 1) * istep;  // wave-uniform
         uint2 v = gload8(img + ro + ew.colc);
-        if (EDGE) v = apply_edge(v, ew.sh);
+        if (EDGE) v = apply_edge(v, ew);
         return v;
     };
 
@@ -338,7 +332,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             if (!SWEEP) pv = gload8(img + (size_t)y * istep + ep.colc);
             vnew_n = load_win(y + 1 + w);
             vold = load_win(y + 1);
-            if (EDGE && !SWEEP) pv = apply_edge(pv, ep.sh);
+            if (EDGE && !SWEEP) pv = apply_edge(pv, ep);
         }
 
         // horizontal window sums: S(j0) = E(j0+w-1) - E(j0) with E the exclusive prefix of the column sums.
