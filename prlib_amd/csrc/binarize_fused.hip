@@ -497,8 +497,23 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                     __builtin_memcpy((uint8_t*)(out + (size_t)y * ostep + x0), &o, 8);
                 }
             } else if (EDGE && lane_has_out) {
-                for (int c = 0; c < CPL && x0 + c < tp.ow; ++c)
-                    out[(size_t)y * ostep + x0 + c] = (uint8_t)(c < 4 ? (lo >> (8 * c)) : (hi >> (8 * (c - 4))));
+                // the lane that straddles the row end: its 1..7 bytes as dword + halfword + byte
+                const int nv = tp.ow - x0;
+                gptr o = out + (size_t)y * ostep + x0;
+                unsigned long long bytes = ((unsigned long long)hi << 32) | lo;
+                if (nv & 4) {
+                    const unsigned d4 = (unsigned)bytes;
+                    __builtin_memcpy((uint8_t*)o, &d4, 4);
+                    o += 4;
+                    bytes >>= 32;
+                }
+                if (nv & 2) {
+                    const unsigned short d2 = (unsigned short)bytes;
+                    __builtin_memcpy((uint8_t*)o, &d2, 2);
+                    o += 2;
+                    bytes >>= 16;
+                }
+                if (nv & 1) *o = (uint8_t)bytes;
             }
         }
 
