@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprlib_hip.so")
+# PRLIB_HIP_SO: load another build of the library (kernel experiments: A/B on one box)
+LIB_PATH = os.environ.get("PRLIB_HIP_SO") or os.path.join(_HERE, "libprlib_hip.so")
 
 PRL_OK = 0
 PRL_ERR_EMPTY = 1
