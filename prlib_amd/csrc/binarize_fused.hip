@@ -377,16 +377,33 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
         }
 #undef PRL_W_STEP
         const unsigned w0sb = w0s + kSBias, w1sb = w1s + kSBias;  // Ssum comes out as kSBias + S (see eval32)
+        // all exchanges first, then the integer arithmetic in one run (integer 2-cycle instructions issue at 4 cycles
+        // next to 4-cycle ones, profiles/r01/valu_issue_costs.txt): 3.86 -> 3.82 ms
         unsigned Ssum[CPL], Qsum[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            const int sub = (c + SH) & 7;  // compile-time
-            const bool far1 = (c + SH) >= 8;
-            const int addr = far1 ? far_addr1 : far_addr0;
-            Ssum[c] = ((unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)ES[sub]) - ES[c]) + (far1 ? w1sb : w0sb);
-            Qsum[c] = ((unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)EQ[sub]) - EQ[c]) + (far1 ? w1q : w0q);
+            const int sub = (c + SH) & 7;
+            const int addr = (c + SH) >= 8 ? far_addr1 : far_addr0;
+            Ssum[c] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)ES[sub]);
         }
-
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int sub = (c + SH) & 7;
+            const int addr = (c + SH) >= 8 ? far_addr1 : far_addr0;
+            Qsum[c] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)EQ[sub]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const bool far1 = (c + SH) >= 8;
+            Ssum[c] = (Ssum[c] - ES[c]) + (far1 ? w1sb : w0sb);
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const bool far1 = (c + SH) >= 8;
+            Qsum[c] = (Qsum[c] - EQ[c]) + (far1 ? w1q : w0q);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (METHOD == kWolfMax) {
             // Wolf sweep A: running maximum of the float32 variance over the wavefront's valid pixels
 #pragma unroll
