@@ -175,7 +175,9 @@ template <int METHOD>
 __global__ void __launch_bounds__(256) k_thin_pass(const unsigned* __restrict__ in, unsigned* __restrict__ out,
                                                   size_t plane_words, int wpr, int width, int height, int n_strips,
                                                   int n_segs, int rows_per_seg, unsigned total_waves,
-                                                  unsigned* __restrict__ changed, const unsigned* __restrict__ done)
+                                                  unsigned* __restrict__ changed, const unsigned* __restrict__ done,
+                                                  const unsigned char* __restrict__ act_prev,
+                                                  unsigned char* __restrict__ act_cur)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned wid = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + wv);
@@ -185,6 +187,23 @@ __global__ void __launch_bounds__(256) k_thin_pass(const unsigned* __restrict__ 
     if (done[page]) return;  // converged: its bit plane is final and stays in buffer A
     const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
     const int seg = rem / n_strips, strip = rem - seg * n_strips;
+    // Activity tracking: a tile (strip x segment) whose own and eight neighbouring tiles came out of the previous pass
+    // unchanged sees the same input (tile + 2-row / 2-word halo) as that pass did, so it would reproduce its input -
+    // which both ping-pong buffers already hold.  Such tiles are skipped; after the first few passes that is most
+    // of the page (only the thickest strokes keep shrinking).
+    {
+        bool active = false;
+        for (int ds = -1; ds <= 1; ++ds)
+            for (int dt = -1; dt <= 1; ++dt) {
+                const int s2 = seg + ds, t2 = strip + dt;
+                if (s2 >= 0 && s2 < n_segs && t2 >= 0 && t2 < n_strips)
+                    active |= act_prev[(size_t)page * per_page + (size_t)s2 * n_strips + t2] != 0;
+            }
+        if (!active) {
+            if (lane == 0) act_cur[wid] = 0;
+            return;
+        }
+    }
     const int k = strip * kThinUseful - 2 + lane;  // this lane's word of the row
     const bool kin = k >= 0 && k < wpr;
     const unsigned* pin = in + (size_t)page * plane_words + (kin ? k : 0);
@@ -228,7 +247,11 @@ __global__ void __launch_bounds__(256) k_thin_pass(const unsigned* __restrict__ 
         b0 = b1; b0l = b1l; b0r = b1r;
         b1 = i1; b1l = i1l; b1r = i1r;
     }
-    if (__ballot(any_change) != 0ull && lane == 0) changed[page] = 1u;
+    const bool tile_changed = __ballot(any_change) != 0ull;
+    if (lane == 0) {
+        act_cur[wid] = tile_changed ? 1 : 0;
+        if (tile_changed) changed[page] = 1u;
+    }
 }
 
 // after both sub-iterations of a pass: a page whose pass changed nothing is final (do-while test, :93-96)
@@ -267,7 +290,16 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
     if (plane_words >= 0x7fffff00ull) return PRL_ERR_BAD_ARG;  // kernels index a page's words with 32 bits
     const size_t bits_bytes = plane_words * sizeof(unsigned) * (size_t)n_pages;
     const size_t flags_bytes = ((size_t)n_pages * sizeof(unsigned) + 255) / 256 * 256;
-    st = ensure_scratch(ctx, 2 * bits_bytes + 2 * flags_bytes);
+    // one launch per pass: strips of 60 words x segments of rows, one wavefront each
+    const int n_strips = (wpr + kThinUseful - 1) / kThinUseful;
+    int rps = 256;  // measured (16 A4 pages): 32 rows 31 us per pass, 16: 26, 8: 26, 4: 31
+    while (rps > 16 && (long long)n_pages * n_strips * ((height + rps - 1) / rps) < 16384) rps /= 2;
+    if (const char* e = std::getenv("PRL_THIN_RPS")) rps = std::max(4, std::atoi(e));
+    const int n_segs = (height + rps - 1) / rps;
+    const unsigned long long tw = (unsigned long long)n_pages * n_strips * n_segs;
+    if (tw >= 0xfffffff0ull) return PRL_ERR_BAD_ARG;
+    const size_t act_cap = ((size_t)tw + 255) / 256 * 256;  // one activity byte per tile and pass parity
+    st = ensure_scratch(ctx, 2 * bits_bytes + 2 * flags_bytes + 2 * act_cap);
     if (st != PRL_OK) return st;
     if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(s, ctx->last_use, 0));
     else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
@@ -276,6 +308,9 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
     auto* changed = reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(B) + bits_bytes);
     auto* done = reinterpret_cast<unsigned*>(reinterpret_cast<uint8_t*>(changed) + flags_bytes);
     PRL_HIP_CHECK(hipMemsetAsync(changed, 0, 2 * flags_bytes, s));
+    auto* act0 = reinterpret_cast<unsigned char*>(done) + flags_bytes;
+    auto* act1 = act0 + act_cap;
+    PRL_HIP_CHECK(hipMemsetAsync(act0, 1, act_cap, s));  // before the first pass every tile counts as changed
 
     PageSet ps{};
     ps.base = d_src;
@@ -292,14 +327,6 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
     std::vector<unsigned> h_done((size_t)n_pages);
     const int max_passes = std::max(width, height) + 2;  // every effective pass removes at least one pixel layer
     const int group = 4;                                 // passes per host check; extra passes change nothing
-    // one launch per pass: strips of 60 words x segments of rows, one wavefront each
-    const int n_strips = (wpr + kThinUseful - 1) / kThinUseful;
-    int rps = 256;  // measured (16 A4 pages): 32 rows 31 us per pass, 16: 26, 8: 26, 4: 31
-    while (rps > 16 && (long long)n_pages * n_strips * ((height + rps - 1) / rps) < 16384) rps /= 2;
-    if (const char* e = std::getenv("PRL_THIN_RPS")) rps = std::max(4, std::atoi(e));
-    const int n_segs = (height + rps - 1) / rps;
-    const unsigned long long tw = (unsigned long long)n_pages * n_strips * n_segs;
-    if (tw >= 0xfffffff0ull) return PRL_ERR_BAD_ARG;
     const unsigned wpb = std::getenv("PRL_THIN_WPB") ? (unsigned)std::max(1, std::min(4, std::atoi(std::getenv("PRL_THIN_WPB")))) : 4u;
     const dim3 gp((unsigned)((tw + wpb - 1) / wpb)), bp(64 * wpb);  // short wavefronts: 4 per workgroup measured best (26.1 vs 28.4 us)
     // Passes alternate A -> B -> A.  The pass that finds a page unchanged has just written a copy of its input, so
@@ -308,12 +335,14 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
         for (int gidx = 0; gidx < group && pass < max_passes; ++gidx, ++pass) {
             const unsigned* in = (pass & 1) ? B : A;
             unsigned* out = (pass & 1) ? A : B;
+            const unsigned char* act_prev = (pass & 1) ? act1 : act0;
+            unsigned char* act_cur = (pass & 1) ? act0 : act1;
             if (method == PRL_THIN_ZHANGSUEN)
                 hipLaunchKernelGGL(k_thin_pass<0>, gp, bp, 0, s, in, out, plane_words, wpr, width, height, n_strips,
-                                   n_segs, rps, (unsigned)tw, changed, done);
+                                   n_segs, rps, (unsigned)tw, changed, done, act_prev, act_cur);
             else
                 hipLaunchKernelGGL(k_thin_pass<1>, gp, bp, 0, s, in, out, plane_words, wpr, width, height, n_strips,
-                                   n_segs, rps, (unsigned)tw, changed, done);
+                                   n_segs, rps, (unsigned)tw, changed, done, act_prev, act_cur);
             PRL_HIP_CHECK(hipGetLastError());
             hipLaunchKernelGGL(k_thin_endpass, dim3((n_pages + 255) / 256), dim3(256), 0, s, changed, done, n_pages);
             PRL_HIP_CHECK(hipGetLastError());
