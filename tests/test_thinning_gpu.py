@@ -90,3 +90,23 @@ def test_thinning_strided_views_keep_their_surroundings(prl, oracle, cuda_device
         guard = got[i].copy()
         guard[1:h + 1, off:off + w] = 7
         assert (guard == 7).all()
+
+
+@pytest.mark.parametrize("method", [0, 1], ids=["zhangsuen", "guohall"])
+def test_thinning_many_passes_on_a_multi_tile_page(prl, oracle, cuda_device, method):
+    """Thick blobs next to thin strokes: tens of passes, during most of which most tiles are idle (activity tracking)."""
+    import torch
+
+    h, w = 700, 4300            # three 1920-pixel strips, many row segments
+    rng = np.random.default_rng(12)
+    img = np.where(_mask((h, w), seed=2, kind="doc") > 0, 255, 0).astype(np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for cy, cx, r in [(120, 300, 60), (400, 1900, 45), (600, 1925, 30), (350, 4200, 80), (20, 2500, 25)]:
+        img[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 255
+    img[500:560, 3000:3600] = 255                      # a bar across a strip boundary
+    img[rng.random((h, w)) < 0.001] = 255
+    fn = prl.thinZhangSuen if method == 0 else prl.thinGuoHall
+    got = fn(torch.from_numpy(img).to(cuda_device)).cpu().numpy()
+    want, passes = oracle.thin(img, method, return_passes=True)
+    assert passes > 20
+    assert np.array_equal(got, want), f"{int((got != want).sum())} mismatching pixels after {passes} passes"
