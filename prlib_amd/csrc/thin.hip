@@ -326,7 +326,7 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
 
     std::vector<unsigned> h_done((size_t)n_pages);
     const int max_passes = std::max(width, height) + 2;  // every effective pass removes at least one pixel layer
-    const int group = 4;                                 // passes per host check; extra passes change nothing
+    int group = 4;  // passes per host check, doubled each time (a pass over converged pages / idle tiles is nearly free)
     const unsigned wpb = std::getenv("PRL_THIN_WPB") ? (unsigned)std::max(1, std::min(4, std::atoi(std::getenv("PRL_THIN_WPB")))) : 4u;
     const dim3 gp((unsigned)((tw + wpb - 1) / wpb)), bp(64 * wpb);  // short wavefronts: 4 per workgroup measured best (26.1 vs 28.4 us)
     // Passes alternate A -> B -> A.  The pass that finds a page unchanged has just written a copy of its input, so
@@ -350,6 +350,7 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
         PRL_HIP_CHECK(hipMemcpyAsync(h_done.data(), done, sizeof(unsigned) * (size_t)n_pages, hipMemcpyDeviceToHost, s));
         PRL_HIP_CHECK(hipStreamSynchronize(s));
         if (std::all_of(h_done.begin(), h_done.end(), [](unsigned v) { return v != 0; })) break;
+        group = std::min(group * 2, 32);
     }
     const dim3 gu((unsigned)(((size_t)(wpr + 1) * height + 255) / 256), n_pages);  // one thread per aligned 32-byte block
     hipLaunchKernelGGL(k_thin_unpack, gu, dim3(256), 0, s, A, plane_words, wpr, pd, width, height);
