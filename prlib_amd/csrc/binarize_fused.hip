@@ -26,6 +26,7 @@
 // see DESIGN.md 4.1.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "prl_device_math.h"
@@ -665,7 +666,8 @@ __global__ void __launch_bounds__(256) k_refine(PageSetOut dst, FusedParams fp, 
 // region [0..y+w-1] x [0..x+w-1] is cut into (top|bottom) x (left|right); every page row is read once
 // (16 workgroups per pixel share the rows, dword loads + V_DOT4_U32_U8 for sum and sum of squares) and
 // weighted by how many padded rows/columns replicate it.  Integer arithmetic: exact.
-constexpr int kSplit = 16;
+constexpr int kSplit = 64;  // workgroups per queued pixel: the row loop of a wavefront is a chain of dependent loads, so the
+                            // parallelism has to come from the grid (16 -> 64: Wolf-Jolion's candidate pass 0.35 -> see DESIGN 4.2)
 struct CornerAcc {
     unsigned long long a[8];  // [0..3] sums of P over top-left, top-right, bottom-left, bottom-right; [4..7] of P*P
 };
@@ -1057,6 +1059,12 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         PRL_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(k_wolf_final, dim3(16), dim3(256), 0, stream, fp, d_globals, cand, acc, cnt);
         PRL_HIP_CHECK(hipGetLastError());
+        if (std::getenv("PRL_HIP_DEBUG")) {
+            unsigned hc[4] = {0, 0, 0, 0};
+            (void)hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, stream);
+            (void)hipStreamSynchronize(stream);
+            std::fprintf(stderr, "[prl_hip] Wolf-Jolion: %u maximum-deviation candidates on %d pages (cap %u)\n", hc[2], n_pages, fp.wl_cap);
+        }
         st = wolf_coeff_run(tp, d_globals, 0, n_pages, stream);
         if (st != PRL_OK) return st;
         return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop);
