@@ -325,7 +325,7 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
     void* d_fused = small + globals_bytes + 2 * table_bytes;
 
     if (h_src_tab || h_dst_tab) {
-        st = ensure_pinned(ctx, 2 * table_bytes);
+        st = ensure_pinned(ctx, 2 * table_bytes + globals_bytes);
         if (st != PRL_OK) return st;
         auto* pin = static_cast<uint8_t*>(ctx->pinned);
         // the pinned staging area is reused by the next call: wait for earlier copies out of it
@@ -399,8 +399,11 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         // Pages whose fix-up list overflowed (pathological: a large share of their pixels sits within
         // ~1e-6 of the decision boundary) are redone by the literal pipeline.  Knowing that needs the
         // per-page flags on the host, hence one stream synchronisation per call.
-        std::vector<PageGlobals> hg((size_t)n_pages);
-        PRL_HIP_CHECK(hipMemcpyAsync(hg.data(), d_globals, sizeof(PageGlobals) * (size_t)n_pages,
+        // (read back through pinned memory: a pageable destination turns the copy into a staged, slower one)
+        st = ensure_pinned(ctx, 2 * table_bytes + globals_bytes);
+        if (st != PRL_OK) return st;
+        const PageGlobals* hg = reinterpret_cast<const PageGlobals*>(static_cast<uint8_t*>(ctx->pinned) + 2 * table_bytes);
+        PRL_HIP_CHECK(hipMemcpyAsync(const_cast<PageGlobals*>(hg), d_globals, sizeof(PageGlobals) * (size_t)n_pages,
                                      hipMemcpyDeviceToHost, stream));
         PRL_HIP_CHECK(hipStreamSynchronize(stream));
         for (int i = 0; i < n_pages; ++i) {
