@@ -324,7 +324,9 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
     hipLaunchKernelGGL(k_thin_pack, gw, dim3(256), 0, s, ps, width, height, wpr, A, plane_words);
     PRL_HIP_CHECK(hipGetLastError());
 
-    std::vector<unsigned> h_done((size_t)n_pages);
+    st = ensure_pinned(ctx, sizeof(unsigned) * (size_t)n_pages);  // flag readback through pinned memory
+    if (st != PRL_OK) return st;
+    unsigned* h_done = static_cast<unsigned*>(ctx->pinned);
     const int max_passes = std::max(width, height) + 2;  // every effective pass removes at least one pixel layer
     int group = 4;  // passes per host check, doubled each time (a pass over converged pages / idle tiles is nearly free)
     const unsigned wpb = std::getenv("PRL_THIN_WPB") ? (unsigned)std::max(1, std::min(4, std::atoi(std::getenv("PRL_THIN_WPB")))) : 4u;
@@ -347,9 +349,9 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
             hipLaunchKernelGGL(k_thin_endpass, dim3((n_pages + 255) / 256), dim3(256), 0, s, changed, done, n_pages);
             PRL_HIP_CHECK(hipGetLastError());
         }
-        PRL_HIP_CHECK(hipMemcpyAsync(h_done.data(), done, sizeof(unsigned) * (size_t)n_pages, hipMemcpyDeviceToHost, s));
+        PRL_HIP_CHECK(hipMemcpyAsync(h_done, done, sizeof(unsigned) * (size_t)n_pages, hipMemcpyDeviceToHost, s));
         PRL_HIP_CHECK(hipStreamSynchronize(s));
-        if (std::all_of(h_done.begin(), h_done.end(), [](unsigned v) { return v != 0; })) break;
+        if (std::all_of(h_done, h_done + n_pages, [](unsigned v) { return v != 0; })) break;
         group = std::min(group * 2, 32);
     }
     const dim3 gu((unsigned)(((size_t)(wpr + 1) * height + 255) / 256), n_pages);  // one thread per aligned 32-byte block
