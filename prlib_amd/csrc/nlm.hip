@@ -580,6 +580,12 @@ constexpr size_t kLutSlot = 512 * 1024;
 
 int upload_lut(DeviceCtx* ctx, int slot, int channels, float h, hipStream_t stream, NlmParams* np)
 {
+    int* dcached = reinterpret_cast<int*>(static_cast<uint8_t*>(ctx->small) + (size_t)slot * kLutSlot);
+    if (ctx->lut_small[slot] == ctx->small && ctx->lut_channels[slot] == channels && ctx->lut_h[slot] == h) {
+        np->n_lut = ctx->lut_n[slot];  // same table as the previous call: still in the workspace (building it costs
+        np->lut = dcached;             // 50-100 thousand exp() calls on the host, a visible share of a single page)
+        return PRL_OK;
+    }
     std::vector<int> lut = build_weights(channels, h);
     int n = (int)lut.size();
     while (n > 0 && lut[(size_t)n - 1] == 0) --n;  // weights are non-increasing: trailing zeros collapse
@@ -595,6 +601,10 @@ int upload_lut(DeviceCtx* ctx, int slot, int channels, float h, hipStream_t stre
     PRL_HIP_CHECK(hipStreamSynchronize(stream));
     np->n_lut = n;
     np->lut = d;
+    ctx->lut_small[slot] = ctx->small;
+    ctx->lut_channels[slot] = channels;
+    ctx->lut_h[slot] = h;
+    ctx->lut_n[slot] = n;
     return PRL_OK;
 }
 

@@ -111,6 +111,7 @@ int ensure_small(DeviceCtx* ctx, size_t bytes)
         ctx->small = nullptr;
         ctx->small_bytes = 0;
     }
+    ctx->lut_small[0] = ctx->lut_small[1] = nullptr;  // cached NL-means tables lived in the old block
     bytes = std::max<size_t>(bytes, 1 << 20);
     PRL_HIP_CHECK(hipMalloc(&ctx->small, bytes));
     ctx->small_bytes = bytes;
@@ -318,6 +319,7 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
     const size_t fused_bytes = fused_small_bytes(n_pages);
     st = ensure_small(ctx, globals_bytes + 2 * table_bytes + fused_bytes);
     if (st != PRL_OK) return st;
+    ctx->lut_small[0] = ctx->lut_small[1] = nullptr;  // this call overwrites the area the NL-means tables live in
     auto* small = static_cast<uint8_t*>(ctx->small);
     auto* d_globals = reinterpret_cast<PageGlobals*>(small);
     auto* d_src_tab = reinterpret_cast<const uint8_t**>(small + globals_bytes);
@@ -563,6 +565,7 @@ int prl_hip_release_workspace(void)
     if (ctx->small) PRL_HIP_CHECK(hipFree(ctx->small));
     ctx->small = nullptr;
     ctx->small_bytes = 0;
+    ctx->lut_small[0] = ctx->lut_small[1] = nullptr;
     if (ctx->pinned) PRL_HIP_CHECK(hipHostFree(ctx->pinned));
     ctx->pinned = nullptr;
     ctx->pinned_bytes = 0;

@@ -41,6 +41,11 @@ struct DeviceCtx {
     void* stage_pinned = nullptr;  // pinned host bounce buffer of the *_host entry points (same lock)
     size_t stage_pinned_bytes = 0;
     std::vector<hipEvent_t> stage_events;  // one per download band (same lock)
+    // NL-means weight tables already resident in `small` (slot 0 / 1): rebuilt only when (channels, h) or `small` change
+    int lut_channels[2] = {0, 0};
+    float lut_h[2] = {0.f, 0.f};
+    int lut_n[2] = {0, 0};
+    const void* lut_small[2] = {nullptr, nullptr};
     void* pinned = nullptr; // pinned host staging for tiny transfers
     size_t pinned_bytes = 0;
     int cu_count = 0;

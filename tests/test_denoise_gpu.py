@@ -116,3 +116,19 @@ def test_nlm_random_sweep(prl, oracle, cuda_device, seed):
         col = _noisy((h, w), seed=seed + 1, sigma=sigma, channels=c)
         got = prl.denoise(torch.from_numpy(col).to(cuda_device), strength).cpu().numpy()
         assert np.array_equal(got, oracle.denoise(col, strength, threads=8))
+
+
+def test_weight_table_cache_survives_interleaved_calls(prl, oracle, cuda_device):
+    """The NL-means weight tables are cached in a workspace the binarizers also use: same / different strengths with
+    binarizer calls in between must keep giving the oracle's result."""
+    import torch
+    from prlib_amd import synth
+
+    col = _noisy((60, 90), seed=21, sigma=10.0, channels=3)
+    t = torch.from_numpy(col).to(cuda_device)
+    page = torch.from_numpy(synth.page_numpy(300, 400, index=2)).to(cuda_device)
+    want10, want4 = oracle.denoise(col, 10.0, threads=8), oracle.denoise(col, 4.0, threads=8)
+    for strength, want in [(10.0, want10), (10.0, want10), (4.0, want4), (10.0, want10)]:
+        assert np.array_equal(prl.denoise(t, strength).cpu().numpy(), want)
+        prl.binarizeSauvola(page, 31, 0.34, 2)          # overwrites the shared workspace
+        assert np.array_equal(prl.denoise(t, strength).cpu().numpy(), want)
