@@ -609,20 +609,28 @@ int upload_lut(DeviceCtx* ctx, int slot, int channels, float h, hipStream_t stre
 }
 
 template <int CH>
-int launch_nlm(const PageSet& src, const PageSetOut& dst, int n_pages, const NlmParams& np, hipStream_t stream)
+int launch_nlm(const PageSet& src_all, const PageSetOut& dst_all, int n_pages, const NlmParams& np, hipStream_t stream)
 {
-    const dim3 grid((np.width + TILE_W - 1) / TILE_W, (np.height + TILE_H - 1) / TILE_H, n_pages);
     const bool lds_lut = np.n_lut <= kLutMax;
-    if (CH <= 2) {
-        constexpr int C = CH <= 2 ? CH : 1;
-        if (lds_lut) hipLaunchKernelGGL((k_nlm_y<C, true>), grid, dim3(256), 0, stream, src, dst, np);
-        else hipLaunchKernelGGL((k_nlm_y<C, false>), grid, dim3(256), 0, stream, src, dst, np);
-    } else {
-        constexpr int C = CH > 2 ? CH : 3;
-        if (lds_lut) hipLaunchKernelGGL((k_nlm<C, true>), grid, dim3(256), 0, stream, src, dst, np);
-        else hipLaunchKernelGGL((k_nlm<C, false>), grid, dim3(256), 0, stream, src, dst, np);
+    if ((np.height + TILE_H - 1) / TILE_H > 65535) return PRL_ERR_BAD_ARG;  // grid.y
+    for (int first = 0; first < n_pages; first += 65535) {  // grid.z holds at most 65535 pages per launch
+        const int cnt = std::min(65535, n_pages - first);
+        PageSet src = src_all;
+        PageSetOut dst = dst_all;
+        if (src.table) src.table += first; else src.base += (size_t)first * src.page_stride;
+        if (dst.table) dst.table += first; else dst.base += (size_t)first * dst.page_stride;
+        const dim3 grid((np.width + TILE_W - 1) / TILE_W, (np.height + TILE_H - 1) / TILE_H, cnt);
+        if (CH <= 2) {
+            constexpr int C = CH <= 2 ? CH : 1;
+            if (lds_lut) hipLaunchKernelGGL((k_nlm_y<C, true>), grid, dim3(256), 0, stream, src, dst, np);
+            else hipLaunchKernelGGL((k_nlm_y<C, false>), grid, dim3(256), 0, stream, src, dst, np);
+        } else {
+            constexpr int C = CH > 2 ? CH : 3;
+            if (lds_lut) hipLaunchKernelGGL((k_nlm<C, true>), grid, dim3(256), 0, stream, src, dst, np);
+            else hipLaunchKernelGGL((k_nlm<C, false>), grid, dim3(256), 0, stream, src, dst, np);
+        }
+        PRL_HIP_CHECK(hipGetLastError());
     }
-    PRL_HIP_CHECK(hipGetLastError());
     return PRL_OK;
 }
 
@@ -692,6 +700,7 @@ int prl_hip_denoise_batch_device(int n_pages, int channels, float strength, cons
     if (n_pages < 0 || !d_src || !d_dst) return PRL_ERR_BAD_ARG;
     if (src_step < (size_t)width * channels || dst_step < (size_t)width * channels) return PRL_ERR_BAD_ARG;
     if (n_pages == 0) return PRL_OK;
+    if (height > 65535) return PRL_ERR_BAD_ARG;  // the colour conversions use one grid row per image row
     int dev;
     int st = current_device(&dev);
     if (st != PRL_OK) return st;
@@ -717,6 +726,7 @@ int prl_hip_denoise_batch_device(int n_pages, int channels, float strength, cons
     const size_t px = (size_t)width * height;
     const size_t budget = (size_t)2 << 30;
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, budget / (6 * px)));
+    chunk = std::min(chunk, 65535);  // grid.z of the per-page kernels
     st = ensure_scratch(ctx, 6 * px * (size_t)chunk);
     if (st != PRL_OK) return st;
     auto* base = static_cast<uint8_t*>(ctx->scratch);

@@ -132,3 +132,14 @@ def test_weight_table_cache_survives_interleaved_calls(prl, oracle, cuda_device)
         assert np.array_equal(prl.denoise(t, strength).cpu().numpy(), want)
         prl.binarizeSauvola(page, 31, 0.34, 2)          # overwrites the shared workspace
         assert np.array_equal(prl.denoise(t, strength).cpu().numpy(), want)
+
+
+def test_nlm_more_pages_than_one_grid_dimension(prl, oracle, cuda_device):
+    """70 000 tiny pages: the per-page grid dimension holds 65 535, so the launch is chunked."""
+    import torch
+
+    rng = np.random.default_rng(0)
+    pages = rng.integers(0, 256, (70000, 6, 7), dtype=np.uint8)
+    got = prl.nlm_planes(torch.from_numpy(pages[..., None]).to(cuda_device), 10.0).cpu().numpy()[..., 0]   # N x H x W x 1
+    for i in (0, 1, 65534, 65535, 65536, 69999):
+        assert np.array_equal(got[i], oracle.nlm_planes(pages[i], 10.0)), i
