@@ -135,7 +135,7 @@ int common_args(int n_pages, const uint8_t* d_src, size_t sps, size_t sstep, siz
 {
     if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
     if (n_pages < 0 || !d_src || !d_dst || sstep < src_row_bytes || dstep < dst_row_bytes) return PRL_ERR_BAD_ARG;
-    if (n_pages > 65535 || height > 65535) return PRL_ERR_BAD_ARG;  // grid.y / grid.z limits
+    if (height > 65535) return PRL_ERR_BAD_ARG;  // grid.y limit (one grid row per image row)
     a->ps.base = d_src; a->ps.page_stride = sps; a->ps.step = sstep;
     a->pd.base = d_dst; a->pd.page_stride = dps; a->pd.step = dstep;
     a->grid = dim3((unsigned)((width + 1023) / 1024), (unsigned)height, (unsigned)n_pages);  // 4 px per thread
@@ -154,6 +154,15 @@ int prl_hip_bgr2gray_batch_device(int n_pages, int channels, const uint8_t* d_sr
                                   void* stream)
 {
     if (channels != 3 && channels != 4) return PRL_ERR_BAD_CHANNELS;
+    if (n_pages > 32768 && d_src && d_dst) {  // grid.z holds at most 65535 pages
+        for (int first = 0; first < n_pages; first += 32768) {
+            const int st2 = prl_hip_bgr2gray_batch_device(std::min(32768, n_pages - first), channels, d_src + (size_t)first * src_page_stride,
+                            src_page_stride, src_step, width, height, d_dst + (size_t)first * dst_page_stride, dst_page_stride,
+                            dst_step, stream);
+            if (st2 != PRL_OK) return st2;
+        }
+        return PRL_OK;
+    }
     Args a;
     int st = common_args(n_pages, d_src, src_page_stride, src_step, (size_t)(width > 0 ? width : 0) * channels, width, height,
                          d_dst, dst_page_stride, dst_step, (size_t)(width > 0 ? width : 0), &a);
@@ -173,6 +182,15 @@ int prl_hip_gray2bgr_batch_device(int n_pages, int channels, const uint8_t* d_sr
                                   void* stream)
 {
     if (channels != 3 && channels != 4) return PRL_ERR_BAD_CHANNELS;
+    if (n_pages > 32768 && d_src && d_dst) {  // grid.z holds at most 65535 pages
+        for (int first = 0; first < n_pages; first += 32768) {
+            const int st2 = prl_hip_gray2bgr_batch_device(std::min(32768, n_pages - first), channels, d_src + (size_t)first * src_page_stride,
+                            src_page_stride, src_step, width, height, d_dst + (size_t)first * dst_page_stride, dst_page_stride,
+                            dst_step, stream);
+            if (st2 != PRL_OK) return st2;
+        }
+        return PRL_OK;
+    }
     Args a;
     int st = common_args(n_pages, d_src, src_page_stride, src_step, (size_t)(width > 0 ? width : 0), width, height, d_dst,
                          dst_page_stride, dst_step, (size_t)(width > 0 ? width : 0) * channels, &a);
@@ -190,6 +208,15 @@ int prl_hip_gray2bgr_batch_device(int n_pages, int channels, const uint8_t* d_sr
 int prl_hip_invert_batch_device(int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step, int width,
                                 int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream)
 {
+    if (n_pages > 32768 && d_src && d_dst) {  // grid.z holds at most 65535 pages
+        for (int first = 0; first < n_pages; first += 32768) {
+            const int st2 = prl_hip_invert_batch_device(std::min(32768, n_pages - first), d_src + (size_t)first * src_page_stride,
+                                                        src_page_stride, src_step, width, height,
+                                                        d_dst + (size_t)first * dst_page_stride, dst_page_stride, dst_step, stream);
+            if (st2 != PRL_OK) return st2;
+        }
+        return PRL_OK;
+    }
     Args a;
     int st = common_args(n_pages, d_src, src_page_stride, src_step, (size_t)(width > 0 ? width : 0), width, height, d_dst,
                          dst_page_stride, dst_step, (size_t)(width > 0 ? width : 0), &a);
@@ -235,7 +262,8 @@ int prl_hip_chain_batch_device(const prl_chain_params* cp, int n_pages, int chan
     auto r256 = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t per_page = (cp->denoise ? r256(cpx) : 0) + (channels != 1 ? r256(px) : 0) + (thin ? r256(mpx) : 0);
     const size_t budget = (size_t)1 << 30;
-    const int chunk = per_page == 0 ? n_pages : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, budget / per_page));
+    int chunk = per_page == 0 ? n_pages : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, budget / per_page));
+    chunk = std::min(chunk, 32768);
     if (per_page) {
         st = ensure_stage(ctx, per_page * (size_t)chunk);
         if (st != PRL_OK) return st;

@@ -472,6 +472,10 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
 
 using namespace prl_hip;
 
+namespace {
+constexpr int kMaxPagesPerLaunch = 32768;
+}
+
 extern "C" {
 
 int prl_hip_abi_version(void) { return PRL_HIP_ABI_VERSION; }
@@ -642,8 +646,18 @@ int prl_hip_binarize_batch_device(const prl_binarize_params* p, int n_pages, con
     d.base = d_dst;
     d.page_stride = dst_page_stride;
     d.step = dst_step;
-    return binarize_common(p, n_pages, s, width, height, d, nullptr, nullptr,
-                           static_cast<hipStream_t>(stream));
+    // several kernels put the page index in a grid dimension limited to 65535: longer batches go in chunks
+    // (prl_hip_last_stats then describes the last chunk)
+    for (int first = 0; first < n_pages || first == 0; first += kMaxPagesPerLaunch) {
+        const int cnt = std::min(kMaxPagesPerLaunch, n_pages - first);
+        PageSet sc = s;
+        PageSetOut dc = d;
+        sc.base = d_src ? d_src + (size_t)first * src_page_stride : nullptr;
+        dc.base = d_dst ? d_dst + (size_t)first * dst_page_stride : nullptr;
+        const int st = binarize_common(p, cnt, sc, width, height, dc, nullptr, nullptr, static_cast<hipStream_t>(stream));
+        if (st != PRL_OK || n_pages <= 0) return st;
+    }
+    return PRL_OK;
 }
 
 int prl_hip_binarize_pages_device(const prl_binarize_params* p, int n_pages,
@@ -655,8 +669,13 @@ int prl_hip_binarize_pages_device(const prl_binarize_params* p, int n_pages,
     s.step = src_step;
     PageSetOut d{};
     d.step = dst_step;
-    return binarize_common(p, n_pages, s, width, height, d, d_src_pages, d_dst_pages,
-                           static_cast<hipStream_t>(stream));
+    for (int first = 0; first < n_pages || first == 0; first += kMaxPagesPerLaunch) {
+        const int cnt = std::min(kMaxPagesPerLaunch, n_pages - first);
+        const int st = binarize_common(p, cnt, s, width, height, d, d_src_pages ? d_src_pages + first : nullptr,
+                                       d_dst_pages ? d_dst_pages + first : nullptr, static_cast<hipStream_t>(stream));
+        if (st != PRL_OK || n_pages <= 0) return st;
+    }
+    return PRL_OK;
 }
 
 int prl_hip_binarize_host(const prl_binarize_params* p, const uint8_t* src, size_t src_step, int width,
@@ -713,6 +732,16 @@ int prl_hip_morph_batch_device(int morph_iterations, int n_pages, const uint8_t*
     if (n_pages < 0 || !d_src || !d_dst || d_src == d_dst) return PRL_ERR_BAD_ARG;
     if (src_step < (size_t)width || dst_step < (size_t)width) return PRL_ERR_BAD_ARG;
     if (n_pages == 0) return PRL_OK;
+    if (n_pages > kMaxPagesPerLaunch) {  // the page index sits in a grid dimension limited to 65535
+        for (int first = 0; first < n_pages; first += kMaxPagesPerLaunch) {
+            const int st2 = prl_hip_morph_batch_device(morph_iterations, std::min(kMaxPagesPerLaunch, n_pages - first),
+                                                       d_src + (size_t)first * src_page_stride, src_page_stride, src_step, width,
+                                                       height, d_dst + (size_t)first * dst_page_stride, dst_page_stride, dst_step,
+                                                       stream);
+            if (st2 != PRL_OK) return st2;
+        }
+        return PRL_OK;
+    }
     int dev;
     int st = current_device(&dev);
     if (st != PRL_OK) return st;

@@ -278,6 +278,16 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
     if (method != PRL_THIN_ZHANGSUEN && method != PRL_THIN_GUOHALL) return PRL_ERR_BAD_ARG;
     if (n_pages < 0 || !d_src || !d_dst || src_step < (size_t)width || dst_step < (size_t)width) return PRL_ERR_BAD_ARG;
     if (n_pages == 0) return PRL_OK;
+    if (n_pages > 32768) {  // the page index sits in a grid dimension limited to 65535
+        for (int first = 0; first < n_pages; first += 32768) {
+            const int st2 = prl_hip_thin_batch_device(method, std::min(32768, n_pages - first),
+                                                      d_src + (size_t)first * src_page_stride, src_page_stride, src_step, width,
+                                                      height, d_dst + (size_t)first * dst_page_stride, dst_page_stride, dst_step,
+                                                      stream);
+            if (st2 != PRL_OK) return st2;
+        }
+        return PRL_OK;
+    }
     int dev;
     int st = current_device(&dev);
     if (st != PRL_OK) return st;

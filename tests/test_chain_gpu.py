@@ -112,3 +112,28 @@ def test_chain_gray_input_other_methods_and_errors(prl, oracle, cuda_device):
         prl.process_pages(t, 1, prl.SAUVOLA, 31, 0.34, 0, thin=7)
     with pytest.raises(ValueError):         # even window: std::invalid_argument in the reference
         prl.process_pages(t, 1, prl.SAUVOLA, 30, 0.34, 0)
+
+
+def test_more_pages_than_one_grid_dimension(prl, oracle, cuda_device):
+    """70 000 tiny pages per call: every entry point that keeps the page index in a 65 535-limited grid dimension
+    has to chunk."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    n, h, w = 70000, 20, 24
+    gray = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    t = torch.from_numpy(gray).to(cuda_device)
+    probe = (0, 1, 32767, 32768, 65535, 65536, n - 1)
+    mask = prl.binarizeSauvola(t, 7, 0.2, 1).cpu().numpy()
+    p = oracle.make_params(oracle.SAUVOLA, 7, 0.2, 1)
+    for i in probe:
+        assert np.array_equal(mask[i], oracle.binarize(gray[i], p)), i
+    inv = prl.bitwise_not(t).cpu().numpy()
+    assert np.array_equal(inv[list(probe)], 255 - gray[list(probe)])
+    skel = prl.thinGuoHall(torch.from_numpy(np.where(gray > 128, 255, 0).astype(np.uint8)).to(cuda_device)).cpu().numpy()
+    for i in probe:
+        assert np.array_equal(skel[i], oracle.thin(np.where(gray[i] > 128, 255, 0).astype(np.uint8), 1)), i
+    bgr = torch.from_numpy(np.repeat(gray[:66000, :, :, None], 3, axis=3).copy()).to(cuda_device)
+    g2 = prl.cvtColorBGR2GRAY(bgr).cpu().numpy()
+    for i in (0, 32768, 65535, 65999):
+        assert np.array_equal(g2[i], oracle.bgr2gray(np.repeat(gray[i][:, :, None], 3, axis=2).copy())), i
