@@ -110,3 +110,20 @@ def test_thinning_many_passes_on_a_multi_tile_page(prl, oracle, cuda_device, met
     want, passes = oracle.thin(img, method, return_passes=True)
     assert passes > 20
     assert np.array_equal(got, want), f"{int((got != want).sum())} mismatching pixels after {passes} passes"
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PRL_SWEEP_SEEDS", "12"))))
+def test_thinning_random_sweep(prl, oracle, cuda_device, seed):
+    """Seeded random shapes (word- and strip-ragged), densities and both methods, as a batch of two pages."""
+    import torch
+
+    rng = np.random.default_rng(9000 + seed)
+    h, w = int(rng.integers(1, 200)), int(rng.integers(1, 2300))
+    method = int(rng.integers(0, 2))
+    kinds = ["noise", "blobs", "doc", "full", "odd_values"]
+    imgs = [_mask((h, w), seed=seed * 3 + i, kind=kinds[int(rng.integers(0, len(kinds)))]) for i in range(2)]
+    fn = prl.thinZhangSuen if method == 0 else prl.thinGuoHall
+    got = fn(torch.from_numpy(np.stack(imgs)).to(cuda_device)).cpu().numpy()
+    for i in range(2):
+        want = oracle.thin(imgs[i], method)
+        assert np.array_equal(got[i], want), f"seed {seed} page {i}: {int((got[i] != want).sum())} mismatches ({h}x{w}, method {method})"
