@@ -125,13 +125,14 @@ __device__ __forceinline__ unsigned byte_of(uint2 v, int c)
 //   FENG     c0 = Z (1 + (1-alpha1)) f           T = c0 S + Z c3 (c3 folded into P2 per page)   (s > 0)
 //   WOLF     c0 = k, c1 = Z f, pk.c1 = f k/max(s), pk.imin = Z Imin
 //                                                T = c1 S + (pk.c1 sqrtK - c0)(c1 S - pk.imin)
-template <int METHOD>
+template <int METHOD, bool WIDE = false>
 __device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsigned Q, float P2, const PageK& pk,
                                         float* k_out)
 {
     // S arrives as 0x4B000000 + S (the horizontal sum carries that bias), whose bit pattern is the float 2^23 + S for
     // S < 2^23: one 2-cycle v_sub_f32 instead of the 4-cycle v_cvt_f32_u32 (profiles/r01/valu_issue_costs.txt)
-    const float Sf = __uint_as_float(S) - 8388608.0f, Qf = (float)Q;
+    // (WIDE: windows wider than 181, where S can reach 2^24: plain conversion, no bias)
+    const float Sf = WIDE ? (float)S : __uint_as_float(S) - 8388608.0f, Qf = (float)Q;
     const float K = fmaf(fp.w2f, Qf, -(Sf * Sf));
     *k_out = K;
     if (METHOD == PRL_SAUVOLA) {
@@ -267,7 +268,7 @@ __device__ __forceinline__ uint2 apply_edge(uint2 v, const EdgeFix& e)
 //   EDGE  : the strip touches the left/right page border (replicate clamp, partial stores)
 //   RING  : the last w-1 window rows of the strip live in a per-wavefront LDS ring (512 B per row), so
 //           the leaving row and the compared pixels are never re-read from memory
-template <int METHOD, int SH, bool EDGE, bool RING>
+template <int METHOD, int SH, bool EDGE, int MODE>
 __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, size_t ostep, unsigned char* ring,
                                            const FusedParams& fp, int page, int xs, int ys, int ye, int lane,
                                            const PageK& pk, unsigned wid, PageGlobals* __restrict__ g,
@@ -275,6 +276,8 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                                            unsigned* __restrict__ counters)
 {
     constexpr bool SWEEP = (METHOD == kWolfMax || METHOD == kWolfCollect);
+    constexpr bool RING = MODE == 1;   // LDS ring variant
+    constexpr bool WIDE = MODE == 2;   // w - 1 > 181: S does not fit the mantissa trick
     const ThrParams& tp = fp.tp;
     const int W = tp.width, H = tp.height, h = tp.half, w = tp.w;
     const int col0 = xs + 1 - h + CPL * lane;  // image column of this lane's sub-column 0
@@ -377,7 +380,8 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
         }
         }
 #undef PRL_W_STEP
-        const unsigned w0sb = w0s + kSBias, w1sb = w1s + kSBias;  // Ssum comes out as kSBias + S (see eval32)
+        const unsigned sbias = WIDE ? 0u : kSBias;
+        const unsigned w0sb = w0s + sbias, w1sb = w1s + sbias;  // Ssum comes out as kSBias + S (see eval32)
         // all exchanges first, then the integer arithmetic in one run (integer 2-cycle instructions issue at 4 cycles
         // next to 4-cycle ones, profiles/r01/valu_issue_costs.txt): 3.86 -> 3.82 ms
         unsigned Ssum[CPL], Qsum[CPL];
@@ -410,7 +414,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 float v32;
-                (void)eval32<METHOD>(fp, Ssum[c], Qsum[c], 0.0f, pk, &v32);
+                (void)eval32<METHOD, WIDE>(fp, Ssum[c], Qsum[c], 0.0f, pk, &v32);
                 if (lane_has_out && (x0 + c < tp.ow)) vmax_lane = fmaxf(vmax_lane, v32);
             }
         } else if (METHOD == kWolfCollect) {
@@ -419,7 +423,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             float vv[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
-                (void)eval32<METHOD>(fp, Ssum[c], Qsum[c], 0.0f, pk, &vv[c]);
+                (void)eval32<METHOD, WIDE>(fp, Ssum[c], Qsum[c], 0.0f, pk, &vv[c]);
                 if (lane_has_out && (x0 + c < tp.ow)) vm = fmaxf(vm, vv[c]);
             }
             if (__ballot(vm >= pk.c1) != 0ull) {
@@ -451,7 +455,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                 const unsigned p = byte_of(pv, c);
                 const float P2 = fmaf((float)p, kZ, pk.p0);
                 float v32;
-                const float ts = eval32<METHOD>(fp, Ssum[c], Qsum[c], P2, pk, &v32);
+                const float ts = eval32<METHOD, WIDE>(fp, Ssum[c], Qsum[c], P2, pk, &v32);
                 tmin = fminf(tmin, fabsf(ts));
                 vmin = fminf(vmin, v32);
                 if (c < 4) lo = __builtin_amdgcn_cvt_pk_u8_f32(ts, c, lo);
@@ -479,7 +483,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                         const unsigned Q = c == 0 ? Qsum[0] : c == 1 ? Qsum[1] : c == 2 ? Qsum[2] : c == 3 ? Qsum[3]
                                          : c == 4 ? Qsum[4] : c == 5 ? Qsum[5] : c == 6 ? Qsum[6] : Qsum[7];
                         float v32;
-                        const float t = eval32<METHOD>(fp, S, Q, fmaf((float)p, kZ, pk.p0), pk, &v32);
+                        const float t = eval32<METHOD, WIDE>(fp, S, Q, fmaf((float)p, kZ, pk.p0), pk, &v32);
                         if ((fabsf(t) > pk.eps1) && (v32 > fp.vthr32)) continue;
                         const unsigned idx = atomicAdd(&counters[0], 1u);
                         if (idx < fp.ref_cap) {
@@ -487,7 +491,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                             it.page = page;
                             it.y = y;
                             it.x = x0 + c;
-                            it.S = S - kSBias;
+                            it.S = S - sbias;
                             it.Q = Q;
                             it.p = p;
                             rl[idx] = it;
@@ -561,7 +565,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fused_ring_lds[];
 
-template <int METHOD, int SH, bool RING>
+template <int METHOD, int SH, int MODE>
 __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, FusedParams fp,
                                               PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
                                               WorkItem* __restrict__ cand, unsigned* __restrict__ counters)
@@ -613,16 +617,16 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
         if (!(fp.segmax[wid] >= pk.c1)) return;            // nothing in this wavefront's segment qualifies
     }
     // per-wavefront ring: ring_rows rows of SW bytes (+32 so the unaligned read of the last row stays inside)
-    unsigned char* ring = RING ? fused_ring_lds + (size_t)wv * ((size_t)fp.ring_rows * SW + 32) : nullptr;
+    unsigned char* ring = MODE == 1 ? fused_ring_lds + (size_t)wv * ((size_t)fp.ring_rows * SW + 32) : nullptr;
 
     // interior strip: every lane's 8-byte window fetch and the whole 512-column output span lie inside
     // the page, so no clamp, no partial store
     const int first_col = xs + 1 - tp.half;
     const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
     if (interior)
-        strip_loop<METHOD, SH, false, RING>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
+        strip_loop<METHOD, SH, false, MODE>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
     else
-        strip_loop<METHOD, SH, true, RING>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
+        strip_loop<METHOD, SH, true, MODE>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
 }
 
 // ---- second stage: float64 interval test of the queued pixels, one thread per pixel ----------------
@@ -808,7 +812,7 @@ template <int METHOD>
 int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
                  PageGlobals* g, RefItem* rl, WorkItem* cand, unsigned* cnt)
 {
-    const bool ring = fp.ring_rows > 0;
+    const bool ring = fp.ring_rows > 0 && fp.tp.w - 1 <= 181;
     // wavefronts are independent; one per workgroup schedules best (256 x 4K pages: 4 per workgroup 4.38 ms, 2: 4.18,
     // 1: 4.13 - a finished wavefront's slot is refilled at once instead of when its whole workgroup has drained)
     unsigned wpb = ring ? 2u : 1u;
@@ -818,12 +822,15 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     blocks = (blocks + 7) / 8 * 8;
     const dim3 grid(blocks), block(64 * wpb);
     const size_t lds = ring ? (size_t)wpb * ((size_t)fp.ring_rows * SW + 32) : 0;
+    const bool wide = fp.tp.w - 1 > 181;  // S no longer fits the mantissa of 2^23 (eval32)
 #define PRL_LAUNCH_FUSED(SHV)                                                                                    \
     do {                                                                                                         \
-        if (ring)                                                                                                \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, true>), grid, block, lds, stream, src, dst, fp, g, rl, cand, cnt);  \
+        if (wide)                                                                                                \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, 2>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);       \
+        else if (ring)                                                                                           \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, 1>), grid, block, lds, stream, src, dst, fp, g, rl, cand, cnt);     \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, false>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);   \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, 0>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);       \
     } while (0)
     switch (sh) {
     case 0: PRL_LAUNCH_FUSED(0); break;
@@ -957,7 +964,7 @@ extern "C" int prl_hip_internal_fused_bounds(const prl_binarize_params* p, int w
 bool fused_supports(const ThrParams& tp)
 {
     if (((tp.w - 1) & 1) != 0) return false;                 // even (clamped) window: rare, literal
-    if (tp.w - 1 > 181 || tp.w < 3) return false;            // 255 (w-1)^2 < 2^23: S rides in the mantissa of 2^23 (kSBias)
+    if (tp.w - 1 > 256 || tp.w < 3) return false;            // window sums must stay exact in u32 / float32
     if (tp.width < 16) return false;                         // the 8-byte row fetch needs a row to clamp into
     if (!std::isfinite(tp.k) || std::fabs(tp.k) > 1e3) return false;
     if (tp.method == PRL_FENG && !(tp.gamma > 0.0)) return false;

@@ -335,3 +335,11 @@ def test_random_sweep(prl, oracle, cuda_device, seed):
         bad = int((got[i, :, :g.out_w] != want).sum())
         assert bad == 0, f"seed {seed} page {i} ({kinds[i]}): {bad} mismatches, method {method} w {win} k {k} morph {morph} {h}x{w}"
     assert (got[:, :, g.out_w:] == 77).all()
+
+
+@pytest.mark.parametrize("method,win", [(SAUVOLA, 183), (NIBLACK, 201), (WOLFJOLION, 185), (NICK, 257), (FENG, 255), (SAUVOLA, 181)])
+def test_wide_windows_stay_on_the_fused_path(prl, oracle, cuda_device, method, win):
+    """Windows of 183..257 columns: S can exceed 2^23, so the kernel variant without the mantissa trick runs."""
+    pages = _pages((300, 340), ["doc", "noise", "white"], seed=win)
+    st = _check(prl, oracle, cuda_device, pages, method, win, 0.2 if method != NICK else -0.1, 0)
+    assert st.literal_pages == 0 or method == WOLFJOLION   # (a flat page makes every pixel a Wolf candidate)
