@@ -79,7 +79,6 @@ struct FusedParams {
     double Em, Eq;     // |m_literal - f*S| <= Em, |q_literal - f*Q| <= Eq
     unsigned ref_cap, wl_cap;
     int need_p0;       // T may be negative: mask bytes of p == 0 pixels must be cleared explicitly
-    int ring_rows;     // > 0: LDS ring variant with this many rows per wavefront
     float es_max;      // Wolf: bound on |s_literal - s*| for v* >= vthr (enters eps1 scaled by |k/devianceMax|)
     float rho;         // Wolf: relative error bound of the float32 variance v~
     float ev2;         // Wolf: 2 * Ev (literal variance noise)
@@ -266,18 +265,16 @@ __device__ __forceinline__ uint2 apply_edge(uint2 v, const EdgeFix& e)
 
 // One wavefront: a strip of SW padded columns x a segment of output rows.
 //   EDGE  : the strip touches the left/right page border (replicate clamp, partial stores)
-//   RING  : the last w-1 window rows of the strip live in a per-wavefront LDS ring (512 B per row), so
 //           the leaving row and the compared pixels are never re-read from memory
-template <int METHOD, int SH, bool EDGE, int MODE>
-__device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, size_t ostep, unsigned char* ring,
+template <int METHOD, int SH, bool EDGE, bool WIDE>
+__device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, size_t ostep,
                                            const FusedParams& fp, int page, int xs, int ys, int ye, int lane,
                                            const PageK& pk, unsigned wid, PageGlobals* __restrict__ g,
                                            RefItem* __restrict__ rl, WorkItem* __restrict__ cand,
                                            unsigned* __restrict__ counters)
 {
     constexpr bool SWEEP = (METHOD == kWolfMax || METHOD == kWolfCollect);
-    constexpr bool RING = MODE == 1;   // LDS ring variant
-    constexpr bool WIDE = MODE == 2;   // w - 1 > 181: S does not fit the mantissa trick
+    // WIDE: w - 1 > 181, S does not fit the mantissa trick (eval32)
     const ThrParams& tp = fp.tp;
     const int W = tp.width, H = tp.height, h = tp.half, w = tp.w;
     const int col0 = xs + 1 - h + CPL * lane;  // image column of this lane's sub-column 0
@@ -300,11 +297,10 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
 #pragma unroll
     for (int c = 0; c < CPL; ++c) VS[c] = VQ[c] = 0;
 
-    // warm-up: vertical sums over padded rows ys+1 .. ys+w-1 (ring slot r holds padded row ys+1+r)
+    // warm-up: vertical sums over padded rows ys+1 .. ys+w-1
 #pragma unroll 2
     for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
         const uint2 v = load_win(pr);
-        if (RING) *reinterpret_cast<uint2*>(ring + (size_t)(pr - ys - 1) * SW + CPL * lane) = v;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const unsigned b = byte_of(v, c);
@@ -313,31 +309,16 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
         }
     }
 
-    // ring slot of the leaving row y+1 / of the compared row y+h (both advance by one per iteration)
-    int slot_old = 0, slot_p = RING ? (h - 1) % (w - 1) : 0;
     float vmax_lane = 0.0f;  // Wolf sweep A
     uint2 vnew_n = load_win(ys + w);  // entering row of the first iteration, fetched one iteration ahead
 #pragma unroll 1
     for (int y = ys; y < ye; ++y) {
         uint2 pv, vold;
         const uint2 vnew = vnew_n;
-        if (RING) {
-            vnew_n = load_win(y + 1 + w);  // next iteration's entering row (row index clamps at the page end)
-            vold = *reinterpret_cast<const uint2*>(ring + (size_t)slot_old * SW + CPL * lane);
-            // compared pixels: strip columns 8*lane + h-1 .. +7 of padded row y+h (unaligned LDS read)
-            {   // aligned dwords + byte funnel (unaligned wide ds_read is several times slower)
-                const unsigned off = (unsigned)(CPL * lane + (h - 1));
-                const unsigned* q = reinterpret_cast<const unsigned*>(ring + (size_t)slot_p * SW + (off & ~3u));
-                const unsigned w0 = q[0], w1 = q[1], w2 = q[2];
-                pv.x = __builtin_amdgcn_alignbyte(w1, w0, off & 3u);
-                pv.y = __builtin_amdgcn_alignbyte(w2, w1, off & 3u);
-            }
-        } else {
-            if (!SWEEP) pv = gload8(img + (size_t)y * istep + ep.colc);
-            vnew_n = load_win(y + 1 + w);
-            vold = load_win(y + 1);
-            if (EDGE && !SWEEP) pv = apply_edge(pv, ep);
-        }
+        if (!SWEEP) pv = gload8(img + (size_t)y * istep + ep.colc);
+        vnew_n = load_win(y + 1 + w);
+        vold = load_win(y + 1);
+        if (EDGE && !SWEEP) pv = apply_edge(pv, ep);
 
         // horizontal window sums: S(j0) = E(j0+w-1) - E(j0) with E the exclusive prefix of the column sums.
         // No wavefront-wide scan is needed: with RAW in-lane prefixes the difference between this lane and the lane
@@ -547,11 +528,6 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             VS[c] += (unsigned)d;
             VQ[c] += (unsigned)(d * sm);
         }
-        if (RING) {
-            *reinterpret_cast<uint2*>(ring + (size_t)slot_old * SW + CPL * lane) = vnew;  // row y+w replaces row y+1
-            slot_old = (slot_old + 1 == w - 1) ? 0 : slot_old + 1;
-            slot_p = (slot_p + 1 == w - 1) ? 0 : slot_p + 1;
-        }
     }
     if (METHOD == kWolfMax) {
 #pragma unroll
@@ -563,9 +539,8 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     }
 }
 
-extern __shared__ __attribute__((aligned(16))) unsigned char fused_ring_lds[];
 
-template <int METHOD, int SH, int MODE>
+template <int METHOD, int SH, bool WIDE>
 __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, FusedParams fp,
                                               PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
                                               WorkItem* __restrict__ cand, unsigned* __restrict__ counters)
@@ -616,17 +591,15 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
         pk.c1 = (1.0f - fp.rho) * (vmax / (1.0f + fp.rho) - fp.ev2) * 0.999999f;
         if (!(fp.segmax[wid] >= pk.c1)) return;            // nothing in this wavefront's segment qualifies
     }
-    // per-wavefront ring: ring_rows rows of SW bytes (+32 so the unaligned read of the last row stays inside)
-    unsigned char* ring = MODE == 1 ? fused_ring_lds + (size_t)wv * ((size_t)fp.ring_rows * SW + 32) : nullptr;
 
     // interior strip: every lane's 8-byte window fetch and the whole 512-column output span lie inside
     // the page, so no clamp, no partial store
     const int first_col = xs + 1 - tp.half;
     const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
     if (interior)
-        strip_loop<METHOD, SH, false, MODE>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
+        strip_loop<METHOD, SH, false, WIDE>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
     else
-        strip_loop<METHOD, SH, true, MODE>(img, out, src.step, dst.step, ring, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
+        strip_loop<METHOD, SH, true, WIDE>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
 }
 
 // ---- second stage: float64 interval test of the queued pixels, one thread per pixel ----------------
@@ -812,25 +785,21 @@ template <int METHOD>
 int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
                  PageGlobals* g, RefItem* rl, WorkItem* cand, unsigned* cnt)
 {
-    const bool ring = fp.ring_rows > 0 && fp.tp.w - 1 <= 181;
     // wavefronts are independent; one per workgroup schedules best (256 x 4K pages: 4 per workgroup 4.38 ms, 2: 4.18,
     // 1: 4.13 - a finished wavefront's slot is refilled at once instead of when its whole workgroup has drained)
-    unsigned wpb = ring ? 2u : 1u;
+    unsigned wpb = 1u;
     if (const char* e = std::getenv("PRL_HIP_WPB")) wpb = (unsigned)std::max(1, std::min(4, std::atoi(e)));
     if (fp.total_waves > 0x7fffff00u) wpb = std::max(wpb, 4u);  // grid.x is limited to 2^31 - 1 workgroups
     unsigned blocks = (fp.total_waves + wpb - 1) / wpb;
     blocks = (blocks + 7) / 8 * 8;
     const dim3 grid(blocks), block(64 * wpb);
-    const size_t lds = ring ? (size_t)wpb * ((size_t)fp.ring_rows * SW + 32) : 0;
     const bool wide = fp.tp.w - 1 > 181;  // S no longer fits the mantissa of 2^23 (eval32)
 #define PRL_LAUNCH_FUSED(SHV)                                                                                    \
     do {                                                                                                         \
         if (wide)                                                                                                \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, 2>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);       \
-        else if (ring)                                                                                           \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, 1>), grid, block, lds, stream, src, dst, fp, g, rl, cand, cnt);     \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, true>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);    \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, 0>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);       \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, false>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);   \
     } while (0)
     switch (sh) {
     case 0: PRL_LAUNCH_FUSED(0); break;
@@ -1045,12 +1014,6 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         int st = page_min_run(tp, src, n_pages, d_globals, stream);
         if (st != PRL_OK) return st;
     }
-    // LDS ring variant (PRL_HIP_RING=1): a wavefront's w-1 rows of 512 B must fit a 16 KiB slice (w <= 33).
-    // Measured on MI355X (256 x 4K, w=31): 5.49 ms vs 4.58 ms without the ring — the kernel is bound by
-    // VALU issue, the ring caps occupancy at 2.5 waves/SIMD, and the re-reads it removes are served by the
-    // Infinity Cache anyway.  Kept for windows/pages where the L2/MALL working set no longer fits.
-    const char* ring_env = std::getenv("PRL_HIP_RING");
-    fp.ring_rows = ((size_t)(tp.w - 1) * SW <= 16384 && ring_env && ring_env[0] == '1') ? tp.w - 1 : 0;
     const int sh = (tp.w - 1) & 7;
     if (tp.method == PRL_WOLFJOLION) {
         // devianceMax first (binarizeWolfJolion.cpp:118-121): sweep A finds the float32 variance maximum,
