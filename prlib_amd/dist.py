@@ -29,17 +29,27 @@ def init(backend: str | None = None):
     import torch.distributed as dist
 
     world, rank, local_rank = env_world()
-    if world > 1 and not dist.is_initialized():
+    on_gpu = torch.cuda.is_available()
+    if on_gpu:
+        # one process per GPU: bind this process to its device BEFORE the first collective (RCCL communicators and
+        # barrier() are created on the current device; every rank left on device 0 is a "duplicate GPU" error)
+        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+    # (PRL_FORCE_DIST=1: join a process group even for a single rank - exercises the RCCL plumbing on one GPU)
+    if (world > 1 or os.environ.get("PRL_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+        dist.init_process_group(backend or ("nccl" if on_gpu else "gloo"))
     return world, rank, local_rank
 
 
 def barrier():
+    import torch
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value: float, device=None) -> float:
@@ -48,6 +58,8 @@ def max_over_ranks(value: float, device=None) -> float:
 
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
+    if device is None and dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -59,6 +71,8 @@ def sum_over_ranks(value: float, device=None) -> float:
 
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
+    if device is None and dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
@@ -68,5 +82,5 @@ def finish():
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
