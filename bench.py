@@ -163,7 +163,7 @@ def main():
             want = oc.binarize_batch(host.copy(), po, threads=os.cpu_count() or 1)
             got = out[:n_chk, :, : g.out_w].cpu().numpy()
             mismatches = int((want != got).sum())
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:   # the CPU baseline leg runs at N=1 only
             n_host = min(args.pages, 64)
             cpu = cpu_baseline(pages[:n_host].cpu().numpy().copy(), po, args.cpu_seconds)
 
