@@ -96,8 +96,7 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path in prlib_amd)")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cuda", torch.cuda.current_device())  # pdist.init() bound this process to its GPU
 
     import prlib_amd
     from prlib_amd import _capi, synth

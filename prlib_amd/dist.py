@@ -37,7 +37,8 @@ def init(backend: str | None = None):
     # (PRL_FORCE_DIST=1: join a process group even for a single rank - exercises the RCCL plumbing on one GPU)
     if (world > 1 or os.environ.get("PRL_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend or ("nccl" if on_gpu else "gloo"))
+        # PRL_DIST_BACKEND=gloo: several ranks on ONE GPU (testing the N>1 path on a single-GPU box; RCCL refuses that)
+        dist.init_process_group(backend or os.environ.get("PRL_DIST_BACKEND") or ("nccl" if on_gpu else "gloo"))
     return world, rank, local_rank
 
 
