@@ -113,6 +113,18 @@ __device__ __forceinline__ NbY<CH> y_nb(const uint2* p)
     return v;
 }
 
+// XL layout: element P is the 4 bytes starting at pixel P; a neighbourhood is elements P and P + 4 (1 channel) or
+// P, P + 2, P + 4, P + 6 (2 channels), read with ds_read2_b32.  Half the LDS footprint of the 8-byte elements - 4
+// workgroups per CU instead of 2 - for the same LDS bytes per neighbourhood.
+template <int CH>
+__device__ __forceinline__ NbY<CH> y_nb(const unsigned* p)
+{
+    NbY<CH> v;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) v.e[k] = make_uint2(p[(8 * k) / CH], p[(8 * k + 4) / CH]);
+    return v;
+}
+
 template <int CH>
 __device__ __forceinline__ NbY<CH> y_mask(NbY<CH> v)
 {
@@ -141,14 +153,18 @@ __device__ __forceinline__ unsigned sub_keep(unsigned a, unsigned b)
     return d;
 }
 
-template <int CH, bool LUT_LDS>
+constexpr int kLutMaxXL = 639;  // the 4-byte-element variant keeps a shorter LDS table (40 KB per workgroup in all)
+
+template <int CH, bool LUT_LDS, bool XL = false>
 __global__ void __launch_bounds__(256) k_nlm_y(PageSet src, PageSetOut dst, NlmParams np)
 {
     using G = YGeo<CH>;
-    constexpr int YP = G::YP, RAWP = G::RAWP;
-    __shared__ __attribute__((aligned(16))) uint2 ytile[EXT_H * YP];
+    using Elt = typename std::conditional<XL, unsigned, uint2>::type;
+    constexpr int YP = XL ? EXT_W : G::YP, RAWP = G::RAWP;  // XL: the last element read is 83 + 6
+    constexpr int kLutN = XL ? kLutMaxXL : kLutMax;
+    __shared__ __attribute__((aligned(16))) Elt ytile[EXT_H * YP];
     __shared__ __attribute__((aligned(16))) unsigned sbraw[G::SBRAW_WORDS];   // raw bytes while staging, then SB
-    __shared__ int lut_s[LUT_LDS ? kLutMax + 1 : 1];
+    __shared__ int lut_s[LUT_LDS ? kLutN + 1 : 1];
     unsigned char* raw = reinterpret_cast<unsigned char*>(sbraw);
     int* sb = reinterpret_cast<int*>(sbraw);
 
@@ -171,16 +187,18 @@ __global__ void __launch_bounds__(256) k_nlm_y(PageSet src, PageSetOut dst, NlmP
         raw[r * RAWP + EXT_W * CH + c] = 0;
     }
     if (LUT_LDS)
-        for (int i = threadIdx.x; i <= kLutMax; i += blockDim.x) lut_s[i] = (i < np.n_lut) ? np.lut[i] : 0;
+        for (int i = threadIdx.x; i <= kLutN; i += blockDim.x) lut_s[i] = (i < np.n_lut) ? np.lut[i] : 0;
     __syncthreads();
 
-    // expand: element (r, k) = raw bytes [k*CH, k*CH + 8) of row r
+    // expand: element (r, k) = raw bytes [k*CH, k*CH + 8) of row r (XL: 4 bytes)
     for (int i = threadIdx.x; i < EXT_H * YP; i += blockDim.x) {
         const int r = i / YP, k = i - r * YP;
         const unsigned P = (unsigned)(k * CH);
         const unsigned* q = reinterpret_cast<const unsigned*>(raw + r * RAWP + (P & ~3u));
         const unsigned w0 = q[0], w1 = q[1], w2 = q[2];
-        ytile[i] = make_uint2(__builtin_amdgcn_alignbyte(w1, w0, P & 3u), __builtin_amdgcn_alignbyte(w2, w1, P & 3u));
+        const uint2 e8 = make_uint2(__builtin_amdgcn_alignbyte(w1, w0, P & 3u), __builtin_amdgcn_alignbyte(w2, w1, P & 3u));
+        if constexpr (XL) ytile[i] = e8.x;
+        else ytile[i] = e8;
     }
     __syncthreads();
 
@@ -210,7 +228,7 @@ __global__ void __launch_bounds__(256) k_nlm_y(PageSet src, PageSetOut dst, NlmP
     const int oy0 = wv * ROWS;  // first output row of this wavefront inside the tile
     // staged coordinates: output (oy, lane) sits at staged (oy + 13, lane + 13); its template row ty starts at
     // staged column lane + 10 = element index lane + 10.
-    const uint2* abase = ytile + (oy0 + kSH) * YP + (lane + kSH);
+    const Elt* abase = ytile + (oy0 + kSH) * YP + (lane + kSH);
     const int* sa_base = sb + (oy0 + kSH) * SB_W + (lane + kSH);
 
     // own side, once: template energies and the 14 neighbourhood rows (padding bytes zeroed) stay in registers
@@ -234,7 +252,7 @@ __global__ void __launch_bounds__(256) k_nlm_y(PageSet src, PageSetOut dst, NlmP
     const unsigned dmax = (unsigned)np.n_lut * 64u;
     auto offsets = [&](int o, auto no_tag) {
         constexpr int NO = decltype(no_tag)::value;
-        const uint2* bbase[NO];
+        const Elt* bbase[NO];
         const int* sb_o[NO];
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
@@ -286,7 +304,10 @@ __global__ void __launch_bounds__(256) k_nlm_y(PageSet src, PageSetOut dst, NlmP
             }
         }
     };
-    constexpr int kPair = CH == 1 ? 3 : 2;  // measured: 1 -> 28.4 / 40.5 ms, 2 -> 18.2 / 27.2, 3 -> 17.8 / 27.6 (L / ab, 8 x 4K pages)
+    // offsets in flight per wavefront.  8-byte elements (2 wavefronts per SIMD): 3 / 2 measured best.  XL runs 4
+    // wavefronts per SIMD at <= 128 VGPRs: 1 and 2 measure the same (22.5 ms L-plane, 8 x 4K pages) - the kernel
+    // then sits at SQ_LDS_IDX_ACTIVE 88 % with the vector ALU saturated (profiles/r01/pmc_nlm_xl.txt)
+    constexpr int kPair = XL ? 1 : (CH == 1 ? 3 : 2);
 #pragma unroll 1
     for (int o = 0; o + kPair <= kS * kS; o += kPair) offsets(o, std::integral_constant<int, kPair>{});
 #pragma unroll 1
@@ -622,7 +643,10 @@ int launch_nlm(const PageSet& src_all, const PageSetOut& dst_all, int n_pages, c
         const dim3 grid((np.width + TILE_W - 1) / TILE_W, (np.height + TILE_H - 1) / TILE_H, cnt);
         if (CH <= 2) {
             constexpr int C = CH <= 2 ? CH : 1;
-            if (lds_lut) hipLaunchKernelGGL((k_nlm_y<C, true>), grid, dim3(256), 0, stream, src, dst, np);
+            static const int xl_env = [] { const char* e = std::getenv("PRL_NLM_XL"); return e ? std::atoi(e) : 3; }();
+            const bool xl = np.n_lut <= kLutMaxXL && ((xl_env >> (C - 1)) & 1);
+            if (xl) hipLaunchKernelGGL((k_nlm_y<C, true, true>), grid, dim3(256), 0, stream, src, dst, np);
+            else if (lds_lut) hipLaunchKernelGGL((k_nlm_y<C, true>), grid, dim3(256), 0, stream, src, dst, np);
             else hipLaunchKernelGGL((k_nlm_y<C, false>), grid, dim3(256), 0, stream, src, dst, np);
         } else {
             constexpr int C = CH > 2 ? CH : 3;
