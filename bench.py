@@ -144,6 +144,22 @@ def main():
     kernel_ms = sum(kms) / len(kms)
     stats = prlib_amd.last_stats()
 
+    # measured device-copy ceiling of this box (SURVEY.md §8d asks for it beside the 8 TB/s spec peak): a plain
+    # device-to-device copy of the page batch, bytes read + bytes written over the average of 5 copies
+    copy_gbs = None
+    if rank == 0:
+        flat = pages.view(-1)
+        scratch = torch.empty_like(flat)
+        scratch.copy_(flat)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            scratch.copy_(flat)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        copy_gbs = 2 * flat.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del scratch
+
     px_per_step_rank = args.pages * g.out_w * g.out_h
     bytes_per_px = 3 if method == prlib_amd.WOLFJOLION else 2
     alg_bytes = args.pages * (H * W * (bytes_per_px - 1) + g.out_w * g.out_h)
@@ -206,6 +222,7 @@ def main():
                 "kernel": "k_fused" if args.mode == "auto" else "literal chain",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
             },
             "cpu_baseline": cpu,
             "parity": {"checked_pages": min(args.check_pages, args.pages), "mismatching_pixels": mismatches,

@@ -85,6 +85,7 @@ struct FusedParams {
     float* segmax;     // Wolf: per-wavefront maximum of v~ (sweep A -> sweep B)
     int nt_store;      // non-temporal mask stores (on unless PRL_HIP_NT=0)
     int bit_out;       // the mask is written as a bit plane (1 bit per pixel) for the bit-domain morphology pass
+    int flt;           // interior strips run the float32 pipeline (typed loads, float sums): w - 1 <= 30, see strip_loop_f
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -124,14 +125,9 @@ __device__ __forceinline__ unsigned byte_of(uint2 v, int c)
 //   FENG     c0 = Z (1 + (1-alpha1)) f           T = c0 S + Z c3 (c3 folded into P2 per page)   (s > 0)
 //   WOLF     c0 = k, c1 = Z f, pk.c1 = f k/max(s), pk.imin = Z Imin
 //                                                T = c1 S + (pk.c1 sqrtK - c0)(c1 S - pk.imin)
-template <int METHOD, bool WIDE = false>
-__device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsigned Q, float P2, const PageK& pk,
-                                        float* k_out)
+template <int METHOD>
+__device__ __forceinline__ float eval32f(const FusedParams& fp, float Sf, float Qf, float P2, const PageK& pk, float* k_out)
 {
-    // S arrives as 0x4B000000 + S (the horizontal sum carries that bias), whose bit pattern is the float 2^23 + S for
-    // S < 2^23: one 2-cycle v_sub_f32 instead of the 4-cycle v_cvt_f32_u32 (profiles/r01/valu_issue_costs.txt)
-    // (WIDE: windows wider than 181, where S can reach 2^24: plain conversion, no bias)
-    const float Sf = WIDE ? (float)S : __uint_as_float(S) - 8388608.0f, Qf = (float)Q;
     const float K = fmaf(fp.w2f, Qf, -(Sf * Sf));
     *k_out = K;
     if (METHOD == PRL_SAUVOLA) {
@@ -150,6 +146,17 @@ __device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsig
     } else {  // Wolf sweeps: only K~ is used
         return 0.0f;
     }
+}
+
+template <int METHOD, bool WIDE = false>
+__device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsigned Q, float P2, const PageK& pk,
+                                        float* k_out)
+{
+    // S arrives as 0x4B000000 + S (the horizontal sum carries that bias), whose bit pattern is the float 2^23 + S for
+    // S < 2^23: one 2-cycle v_sub_f32 instead of the 4-cycle v_cvt_f32_u32 (profiles/r01/valu_issue_costs.txt)
+    // (WIDE: windows wider than 181, where S can reach 2^24: plain conversion, no bias)
+    const float Sf = WIDE ? (float)S : __uint_as_float(S) - 8388608.0f, Qf = (float)Q;
+    return eval32f<METHOD>(fp, Sf, Qf, P2, pk, k_out);
 }
 
 // ---- float64 interval evaluation: 255 / 0 when provably decided, 2 otherwise -----------------
@@ -540,6 +547,213 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
 }
 
 
+// ---- float32 strip loop: interior strips of the threshold sweeps, w - 1 <= 30 -------------------------------------
+// The vector ALU is what bounds k_fused, and a third of its instructions only unpack bytes (SDWA)
+// or convert integers to float.  gfx950's typed buffer loads do both in the texture-address unit:
+// buffer_load_format_xyzw with an 8_8_8_8 USCALED resource returns four pixels as four floats (any byte alignment,
+// 7.7 TB/s of pixels from L2 - tools/ubench/typed_load.hip).  With float pixels the column sums, their in-lane
+// prefixes and the exchange run on 2-cycle float instructions (v_fma_f32 instead of v_mad_i32_i24, no conversions).
+// Exactness: pixels, column sums (<= 30 * 65025), in-lane prefixes and lane totals (<= 8 * 30 * 65025 < 2^24) and
+// every S quantity are exact integers in float32.  Only the Q sums of several lanes (the W chain) and the final
+// Q = (E_far - E_own) + W can pass 2^24 and round: at most `flt_delta` units in all, and only when Q itself is at
+// least 2^24 - 8 (w-1) 65025 - which fused_bounds() turns into the relative error `cq u` of Q~ that widens eps1.
+// Queued pixels carry no sums: k_refine rebuilds S and Q exactly from the page when fp.flt is set.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wundefined-internal"
+__device__ f32x4 buf_load_fmt_xyzw(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
+#pragma clang diagnostic pop
+
+// gfx9 buffer resource over one page: raw (stride 0, byte offsets), no range limit, 8_8_8_8 USCALED -> x, y, z, w
+__device__ __forceinline__ i32x4 page_rsrc(gcptr page)
+{
+    const unsigned long long a = (unsigned long long)(const uint8_t*)page;
+    i32x4 r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((a >> 32) & 0xffffu);
+    r.z = (int)0xffffffffu;
+    r.w = (4 | (5 << 3) | (6 << 6) | (7 << 9)) | (2 << 12) | (10 << 15);
+    return r;
+}
+
+struct F8 {
+    float v[CPL];
+};
+
+// 8 consecutive pixels of a row as floats: lane byte offset in a VGPR, row byte offset wave-uniform (SGPR)
+__device__ __forceinline__ F8 tload8(const i32x4& rsrc, int col, int row_off)
+{
+    const f32x4 a = buf_load_fmt_xyzw(rsrc, col, row_off, 0), b = buf_load_fmt_xyzw(rsrc, col + 4, row_off, 0);
+    F8 r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+
+__device__ __forceinline__ float lane_up1f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float bpermf(int addr, float v)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
+}
+
+template <int METHOD, int SH>
+__device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, size_t ostep, const FusedParams& fp,
+                                             int page, int xs, int ys, int ye, int lane, const PageK& pk,
+                                             PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
+                                             unsigned* __restrict__ counters)
+{
+    const ThrParams& tp = fp.tp;
+    const int H = tp.height, h = tp.half, w = tp.w;
+    const int col0 = xs + 1 - h + CPL * lane;  // image column of this lane's sub-column 0 (interior: no clamp)
+    const int x0 = xs + CPL * lane;            // first output column of this lane
+    const bool lane_has_out = CPL * lane < fp.uo;  // interior strips: every output column exists
+    const int far_addr0 = (lane + fp.lane_off) * 4, far_addr1 = far_addr0 + 4;
+    const i32x4 rsrc = page_rsrc(img);
+    const int step = (int)istep;
+
+    auto load_win = [&](int padded_row) -> F8 { return tload8(rsrc, col0, clampi(padded_row - h, 0, H - 1) * step); };
+
+    float VS[CPL], VQ[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) VS[c] = VQ[c] = 0.0f;
+#pragma unroll 2
+    for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
+        const F8 v = load_win(pr);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            VS[c] += v.v[c];
+            VQ[c] = fmaf(v.v[c], v.v[c], VQ[c]);
+        }
+    }
+
+    // Loads are issued where their destination registers have just died, one iteration ahead of their use: the
+    // compared pixels of the next row right after this row's decision, the next entering and leaving rows right
+    // after the slide.  No second set of registers, a whole iteration of latency hiding.
+    F8 vnew = load_win(ys + w), vold = load_win(ys + 1);
+    F8 pv = tload8(rsrc, x0, ys * step);
+#pragma unroll 1
+    for (int y = ys; y < ye; ++y) {
+        float ES[CPL], EQ[CPL], tot_s, tot_q;
+        {
+            float accs = VS[0], accq = VQ[0];  // (not 0 + VS[0]: the compiler keeps a float add of +0)
+            ES[0] = EQ[0] = 0.0f;
+#pragma unroll
+            for (int c = 1; c < CPL; ++c) {
+                ES[c] = accs;
+                EQ[c] = accq;
+                accs += VS[c];
+                accq += VQ[c];
+            }
+            tot_s = accs;
+            tot_q = accq;
+        }
+        float w0s = 0.0f, w0q = 0.0f, w1s = tot_s, w1q = tot_q;
+#define PRL_W_STEP()                      \
+    do {                                  \
+        w0s = w1s;                        \
+        w0q = w1q;                        \
+        w1s = tot_s + lane_up1f(w1s);     \
+        w1q = tot_q + lane_up1f(w1q);     \
+    } while (0)
+        switch (fp.lane_off) {  // w - 1 <= 30: at most 3 steps
+        case 0: break;
+        case 1: PRL_W_STEP(); break;
+        case 2: PRL_W_STEP(); PRL_W_STEP(); break;
+        default: PRL_W_STEP(); PRL_W_STEP(); PRL_W_STEP(); break;
+        }
+#undef PRL_W_STEP
+        float Ssum[CPL], Qsum[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) Ssum[c] = bpermf((c + SH) >= 8 ? far_addr1 : far_addr0, ES[(c + SH) & 7]);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) Qsum[c] = bpermf((c + SH) >= 8 ? far_addr1 : far_addr0, EQ[(c + SH) & 7]);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) Ssum[c] = (Ssum[c] - ES[c]) + ((c + SH) >= 8 ? w1s : w0s);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) Qsum[c] = (Qsum[c] - EQ[c]) + ((c + SH) >= 8 ? w1q : w0q);
+
+        unsigned lo = 0, hi = 0;
+        float tmin = 3.0e38f, vmin = 3.0e38f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const float P2 = fmaf(pv.v[c], kZ, pk.p0);
+            float v32;
+            const float ts = eval32f<METHOD>(fp, Ssum[c], Qsum[c], P2, pk, &v32);
+            tmin = fminf(tmin, fabsf(ts));
+            vmin = fminf(vmin, v32);
+            if (c < 4) lo = __builtin_amdgcn_cvt_pk_u8_f32(ts, c, lo);
+            else hi = __builtin_amdgcn_cvt_pk_u8_f32(ts, c - 4, hi);
+        }
+
+        if (fp.need_p0) {  // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                if (c < 4) lo = (pv.v[c] == 0.0f) ? (lo & ~(0xffu << (8 * c))) : lo;
+                else hi = (pv.v[c] == 0.0f) ? (hi & ~(0xffu << (8 * (c - 4)))) : hi;
+            }
+        }
+        const F8 pv_cur = pv;
+
+        // rare: some pixel of this lane is not settled by the float32 test -> queue it (k_refine rebuilds its sums)
+        const bool unsure = lane_has_out && !((tmin > pk.eps1) && (vmin > fp.vthr32));
+        if (__ballot(unsure) != 0ull) {
+            if (unsure) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    if (pv_cur.v[c] == 0.0f) continue;  // 0 > T8 is false whatever T is
+                    float v32;
+                    const float t = eval32f<METHOD>(fp, Ssum[c], Qsum[c], fmaf(pv_cur.v[c], kZ, pk.p0), pk, &v32);
+                    if ((fabsf(t) > pk.eps1) && (v32 > fp.vthr32)) continue;
+                    const unsigned idx = atomicAdd(&counters[0], 1u);
+                    if (idx < fp.ref_cap) {
+                        RefItem it;
+                        it.page = page;
+                        it.y = y;
+                        it.x = x0 + c;
+                        it.S = 0;
+                        it.Q = 0;
+                        it.p = (unsigned)pv_cur.v[c];
+                        rl[idx] = it;
+                    } else {
+                        atomicOr(&g[page].worklist_overflow, 1u);
+                    }
+                }
+            }
+        }
+
+        if (lane_has_out) {
+            if (fp.bit_out) {
+                const unsigned b = (((lo & 0x01010101u) * 0x01020408u) >> 24) | ((((hi & 0x01010101u) * 0x01020408u) >> 20) & 0xf0u);
+                out[(size_t)y * ostep + (x0 >> 3)] = (uint8_t)b;
+            } else if (fp.nt_store) {
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                u2v o = {lo, hi};
+                __builtin_nontemporal_store(o, reinterpret_cast<u2v*>((uint8_t*)(out + (size_t)y * ostep + x0)));
+            } else {
+                uint2 o = make_uint2(lo, hi);
+                __builtin_memcpy((uint8_t*)(out + (size_t)y * ostep + x0), &o, 8);
+            }
+        }
+
+        pv = tload8(rsrc, x0, min(y + 1, H - 1) * step);
+
+        // slide the window one row down: new^2 - old^2 = (new - old)(new + old), one exact fma
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const float d = vnew.v[c] - vold.v[c], sm = vnew.v[c] + vold.v[c];
+            VS[c] += d;
+            VQ[c] = fmaf(d, sm, VQ[c]);
+        }
+        vnew = load_win(y + 1 + w);
+        vold = load_win(y + 2);
+    }
+}
+
 template <int METHOD, int SH, bool WIDE>
 __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, FusedParams fp,
                                               PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
@@ -596,21 +810,52 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     // the page, so no clamp, no partial store
     const int first_col = xs + 1 - tp.half;
     const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
-    if (interior)
+    constexpr bool kThreshold = !(METHOD == kWolfMax || METHOD == kWolfCollect);
+    if (interior && kThreshold && !WIDE && fp.flt)
+        strip_loop_f<METHOD, SH>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, g, rl, counters);
+    else if (interior)
         strip_loop<METHOD, SH, false, WIDE>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
     else
         strip_loop<METHOD, SH, true, WIDE>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
 }
 
-// ---- second stage: float64 interval test of the queued pixels, one thread per pixel ----------------
+// ---- second stage: float64 interval test of the queued pixels ------------------------------------------------------
+// One thread per pixel when the exact window sums travel with it (integer pipeline only); one wavefront per pixel when
+// they have to be rebuilt from the page (fp.flt: the float32 pipeline queues pixels without sums, and edge strips of
+// the same launch are simply recomputed too): lanes take the window's columns, 64-lane reduction, lane 0 decides.
 template <int METHOD>
-__global__ void __launch_bounds__(256) k_refine(PageSetOut dst, FusedParams fp, PageGlobals* __restrict__ g,
+__global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, FusedParams fp, PageGlobals* __restrict__ g,
                                                const RefItem* __restrict__ rl, WorkItem* __restrict__ wl,
                                                unsigned* __restrict__ counters)
 {
     const unsigned n = min(counters[0], fp.ref_cap);
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const RefItem it = rl[i];
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    const unsigned first = fp.flt ? tid >> 6 : tid, stride = fp.flt ? nthreads >> 6 : nthreads;
+    const int lane = threadIdx.x & 63;
+    for (unsigned i = first; i < n; i += stride) {
+        RefItem it = rl[i];
+        if (fp.flt) {
+            // padded rows y+1 .. y+w-1, columns x+1 .. x+w-1 of the replicate-padded page, exact in u32
+            const ThrParams& tp = fp.tp;
+            const uint8_t* pg = src.page(it.page);
+            unsigned S = 0, Q = 0;
+            for (int pc = it.x + 1 + lane; pc <= it.x + tp.w - 1; pc += 64) {
+                const uint8_t* col = pg + clampi(pc - tp.half, 0, tp.width - 1);
+                for (int pr = it.y + 1; pr <= it.y + tp.w - 1; ++pr) {
+                    const unsigned b = col[(size_t)clampi(pr - tp.half, 0, tp.height - 1) * src.step];
+                    S += b;
+                    Q += b * b;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                S += __shfl_xor(S, d, kWave);
+                Q += __shfl_xor(Q, d, kWave);
+            }
+            if (lane != 0) continue;
+            it.S = S;
+            it.Q = Q;
+        }
         const unsigned r = refine64<METHOD>(fp, it.S, it.Q, it.p, (double)g[it.page].imin, g[it.page].coeff);
         if (r != 2) {
             store_decision(dst, fp.bit_out, it.page, it.y, it.x, r);
@@ -822,7 +1067,7 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     int st = launch_sweep<METHOD>(sh, stream, src, dst, fp, g, rl, cand, cnt);
     if (st != PRL_OK) return st;
     if (ev_stop) PRL_HIP_CHECK(hipEventRecord(ev_stop, stream));
-    hipLaunchKernelGGL((k_refine<METHOD>), dim3(64), dim3(256), 0, stream, dst, fp, g, rl, wl, cnt);
+    hipLaunchKernelGGL((k_refine<METHOD>), dim3(fp.flt ? 1024 : 64), dim3(256), 0, stream, src, dst, fp, g, rl, wl, cnt);
     PRL_HIP_CHECK(hipGetLastError());
     PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, stream));
     hipLaunchKernelGGL(k_corner_partial, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc);
@@ -852,7 +1097,9 @@ struct FusedBounds {
     double rho;      // relative error bound of the float32 variance v~
 };
 
-static FusedBounds fused_bounds(const ThrParams& tp)
+// cq: |Q~ - Q| <= cq u Q for the float32 value of the window sum of squares (1 = one conversion of the exact integer;
+// the float32 pipeline's chain of lane sums is looser, see flt_cq)
+static FusedBounds fused_bounds(const ThrParams& tp, double cq = 1.0)
 {
     FusedBounds b{};
     const double u = std::ldexp(1.0, -24), e64 = std::ldexp(1.0, -53);
@@ -864,12 +1111,13 @@ static FusedBounds fused_bounds(const ThrParams& tp)
     const double Ev = b.Eq + 2.0 * M * b.Em + b.Em * b.Em;
     b.vthr = std::fmax(1e-2, 64.0 * Ev);
     const double Es = 1.01 * Ev / std::sqrt(b.vthr - Ev);
-    // K~ = fma(w^2, Q~, -S^2~): |K~ - K| <= u (w^2 Q + S^2) + u K, i.e. relative to v* = f^2 K at most
-    // rho = (2 + 2R) u; sqrt halves it and adds 2u (v_sqrt_f32 is 1 ulp): kappa = (3 + R) u.
-    b.kappa = (3.0 + R) * u * 1.1;
+    // K~ = fma(w^2, Q~, -S^2~): |K~ - K| <= u (cq w^2 Q + S^2) + u K, i.e. relative to v* = f^2 K at most
+    // rho = (cq + 1)(1 + R) u; sqrt halves it and adds 2u (v_sqrt_f32 is 1 ulp): kappa = ((cq + 1)(1 + R)/2 + 2) u
+    // (cq = 1: rho = (2 + 2R) u, kappa = (3 + R) u).
+    b.kappa = ((cq + 1.0) * (1.0 + R) * 0.5 + 2.0) * u * 1.1;
     b.Ev = Ev;
     b.Es = Es;
-    b.rho = (2.0 + 2.0 * R) * u * 1.1;
+    b.rho = (cq + 1.0) * (1.0 + R) * u * 1.1;
     const double k = std::fabs(tp.k);
     switch (tp.method) {
     case PRL_SAUVOLA: {
@@ -884,7 +1132,7 @@ static FusedBounds fused_bounds(const ThrParams& tp)
         break;
     case PRL_NICK: {
         const double Ec = 1.01 * (b.Eq + 1e-10) / std::sqrt(b.vthr - b.Eq - 1e-10);
-        b.E1 = k * SM * 3.5 * u + M * u + 2 * u * (256 + M + k * SM);
+        b.E1 = k * SM * (0.5 * cq + 3.0) * u + M * u + 2 * u * (256 + M + k * SM);  // sqrt(Q~): cq u / 2 + 2u, + 1u product
         b.Elit = b.Em + k * Ec;
         break;
     }
@@ -942,6 +1190,26 @@ bool fused_supports(const ThrParams& tp)
     return true;
 }
 
+// The float32 pipeline (strip_loop_f): is it usable for this call, and how loose is its Q~?  Sums of j+1 lane totals
+// (the W chain) and the final window sum round once each when they reach 2^24 (half an ulp of their largest
+// possible value); any such partial sum covers the window plus at most 8 columns outside it, so a rounding can
+// only happen when Q >= 2^24 - 8 (w-1) 65025 =: Qmin, which turns the absolute bound into a relative one.
+static bool flt_usable(const ThrParams& tp, size_t src_step, double* cq)
+{
+    if (const char* e = std::getenv("PRL_HIP_FLT")) if (e[0] == '0') return false;
+    const int n1 = tp.w - 1;
+    if (n1 > 30) return false;
+    if ((unsigned long long)src_step * (unsigned long long)tp.height >= 0x7fffffffull) return false;  // 32-bit buffer offsets
+    auto half_ulp = [](double x) { return x < 16777216.0 ? 0.0 : std::ldexp(1.0, (int)std::floor(std::log2(x)) - 24); };
+    const double col = (double)n1 * 65025.0;  // largest column sum of squares
+    double delta = half_ulp((double)n1 * col);  // the final sum
+    for (int j = 1; j <= n1 / 8; ++j) delta += half_ulp((j + 1) * 8.0 * col);
+    const double qmin = 16777216.0 - 8.0 * col;
+    if (delta > 0.0 && !(qmin > 0.0)) return false;
+    *cq = std::fmax(1.0, delta > 0.0 ? delta / (qmin * std::ldexp(1.0, -24)) : 1.0);
+    return true;
+}
+
 constexpr size_t kSegmaxCap = 1u << 20;  // wavefronts per call whose sweep-A maxima can be kept (Wolf)
 
 size_t fused_small_bytes(int)
@@ -975,7 +1243,10 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     const unsigned long long tw = (unsigned long long)n_pages * fp.n_strips * fp.n_segs;
     if (tw > 0xfffffff0ull) return PRL_ERR_BAD_ARG;
     fp.total_waves = (unsigned)tw;
-    const FusedBounds b = fused_bounds(tp);
+    double cq = 1.0;
+    fp.flt = flt_usable(tp, src.step, &cq) ? 1 : 0;
+    const FusedBounds b = fused_bounds(tp, fp.flt ? cq : 1.0);  // margins of the threshold sweep
+    const FusedBounds b1 = fused_bounds(tp);                    // Wolf-Jolion's maximum search always runs on integers
     const double Z = (double)kZ, f = tp.f;
     fp.w2f = (float)(tp.w * tp.w);
     fp.Em = b.Em;
@@ -998,8 +1269,8 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     default: return PRL_ERR_BAD_ARG;
     }
     fp.es_max = (float)(b.Es * 1.01);
-    fp.rho = (float)(b.rho * 1.01);
-    fp.ev2 = (float)(2.0 * b.Ev * 1.01 / (f * f));  // in K units
+    fp.rho = (float)(b1.rho * 1.01);
+    fp.ev2 = (float)(2.0 * b1.Ev * 1.01 / (f * f));  // in K units
 
     // [0] refine-list length, [1] fix-up-list length, [2] Wolf candidate-list length
     auto* cnt = static_cast<unsigned*>(small);

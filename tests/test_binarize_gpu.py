@@ -343,3 +343,34 @@ def test_wide_windows_stay_on_the_fused_path(prl, oracle, cuda_device, method, w
     pages = _pages((300, 340), ["doc", "noise", "white"], seed=win)
     st = _check(prl, oracle, cuda_device, pages, method, win, 0.2 if method != NICK else -0.1, 0)
     assert st.literal_pages == 0 or method == WOLFJOLION   # (a flat page makes every pixel a Wolf candidate)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PRL_SWEEP_SEEDS_WIDE", "16"))))
+def test_random_sweep_wide_pages(prl, oracle, cuda_device, seed):
+    """Pages wide enough for interior strips (>= 1100 columns), windows up to 31: those strips run the float32
+    pipeline (typed buffer loads, float column sums; k_refine rebuilds the window sums of queued pixels from the page).
+    Hard page kinds on purpose: binary and noise pages drive the sums of squares to their largest values, where the
+    float32 lane sums round."""
+    import torch
+
+    rng = np.random.default_rng(7000 + seed)
+    method = int(rng.integers(0, 5))
+    h, w = int(rng.integers(50, 260)), int(rng.integers(1100, 2300))
+    win = int(rng.choice([3, 5, 9, 15, 17, 23, 25, 29, 31]))
+    k = float(rng.choice([0.34, 0.2, 0.01, -0.01, -0.2, 0.5]))
+    morph = int(rng.choice([0, 0, 0, 2, -1, 4]))
+    kinds = [str(x) for x in rng.choice(["doc", "noise", "binary", "flat", "ramp", "dark_corner", "white", "black"], 3)]
+    pages = _pages((h, w), kinds, seed=seed + 900)
+    params = prl.make_params(method, win, k, morph)
+    g = prl.geometry(params, w, h)
+    dev_pages = torch.from_numpy(np.stack(pages)).to(cuda_device)
+    # an input view whose rows do not start on a multiple of 4 bytes (typed loads at every alignment)
+    off = int(rng.integers(0, 4))
+    big = torch.zeros((3, h, w + 8), dtype=torch.uint8, device=cuda_device)
+    big[:, :, off:off + w] = dev_pages
+    got = prl.binarize(big[:, :, off:off + w], params).cpu().numpy()
+    p = oracle.make_params(method, win, k, morph)
+    for i, pg in enumerate(pages):
+        want = oracle.binarize(pg, p)
+        bad = int((got[i] != want).sum())
+        assert bad == 0, f"seed {seed} page {i} ({kinds[i]}): {bad} mismatches, method {method} w {win} k {k} morph {morph} {h}x{w}"
