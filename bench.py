@@ -148,7 +148,7 @@ def main():
     # device-to-device copy of the page batch, bytes read + bytes written over the average of 5 copies
     copy_gbs = None
     if rank == 0:
-        flat = pages.view(-1)
+        flat = torch.empty(min(args.pages * H * W, 1 << 32), dtype=torch.uint8, device=dev)  # (pages may be a pitched view)
         scratch = torch.empty_like(flat)
         scratch.copy_(flat)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -158,7 +158,7 @@ def main():
         e1.record()
         torch.cuda.synchronize(dev)
         copy_gbs = 2 * flat.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del scratch
+        del scratch, flat
 
     px_per_step_rank = args.pages * g.out_w * g.out_h
     bytes_per_px = 3 if method == prlib_amd.WOLFJOLION else 2

@@ -34,6 +34,8 @@ DEFK(k_fma, "v_fma_f32 %0, %0, %1, %2")
 DEFK(k_dot4, "v_dot4_u32_u8 %0, %1, %2, %0")
 DEFK(k_lshl, "v_lshlrev_b32 %0, 1, %0")
 DEFK(k_min, "v_min_i32 %0, %0, %1")
+DEFK(k_fmamix, "v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]")
+DEFK(k_fmamix2, "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]")
 DEFK(k_mix, "v_dot4_u32_u8 %0, %1, %2, %0\n\tv_add_u32 %0, %0, %1\n\tv_lshlrev_b32 %0, 1, %0")
 
 template <typename K> void run(const char* name, K kern, int waves_per_simd, int ninst)
@@ -61,8 +63,9 @@ template <typename K> void run(const char* name, K kern, int waves_per_simd, int
 
 int main()
 {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {1, 4, 8}) {
         run("v_add_u32", k_add, w, 1); run("v_fma_f32", k_fma, w, 1); run("v_dot4", k_dot4, w, 1);
+        run("v_fma_mix(h,f,f)", k_fmamix, w, 1); run("v_fma_mix(hh,h,f)", k_fmamix2, w, 1);
         run("v_lshlrev", k_lshl, w, 1); run("v_min_i32", k_min, w, 1); run("dot+add+shl", k_mix, w, 3);
     }
     return 0;
