@@ -204,7 +204,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8 in/out; exact u32 window sums; f32 decision with f64/literal refinement",
+            "dtype": "u8 in/out; exact integer window sums (u32, f32 below 2^24 in interior strips); f32 decision with f64/literal refinement",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.pages} x {W}x{H} u8 pages per GPU, {args.method} k={args.k} w={args.window} "

@@ -116,7 +116,7 @@ __device__ __forceinline__ unsigned byte_of(uint2 v, int c)
     return (w >> (8 * (c & 3))) & 0xffu;
 }
 
-// ---- float32 evaluation: returns t2 = Z ((p - 0.5) - T~) and K~ = w^2 Q - S^2 (variance / f^2) ----------
+// ---- float32 evaluation: returns tn = Z (T~ - (p - 0.5)) and K~ = w^2 Q - S^2 (variance / f^2) ----------
 // With m = f S, v = f^2 K, s = f sqrt(K) every threshold is a polynomial in S and sqrt(K) (or sqrt(Q)); the
 // constants carry the powers of f and the scale Z = 2^30, so no multiply is spent on them (P2 = Z (p - 0.5)):
 //   SAUVOLA  c0 = Z a f^2, c1 = Z b f            T = S (c0 sqrtK + c1)            a = k/128, b = 1-k
@@ -128,24 +128,36 @@ __device__ __forceinline__ unsigned byte_of(uint2 v, int c)
 template <int METHOD>
 __device__ __forceinline__ float eval32f(const FusedParams& fp, float Sf, float Qf, float P2, const PageK& pk, float* k_out)
 {
+    // returns the NEGATED margin tn = Z (T~ - (p - 0.5)): white <=> tn < 0 <=> sign bit set, which pack_signs() turns
+    // into the 0xFF mask byte; the settled test only uses |tn|
     const float K = fmaf(fp.w2f, Qf, -(Sf * Sf));
     *k_out = K;
     if (METHOD == PRL_SAUVOLA) {
         const float d = fmaf(__builtin_amdgcn_sqrtf(K), fp.c0, fp.c1);
-        return fmaf(-Sf, d, P2);
+        return fmaf(Sf, d, -P2);
     } else if (METHOD == PRL_NIBLACK) {
-        return fmaf(-Sf, fp.c1, fmaf(-__builtin_amdgcn_sqrtf(K), fp.c0, P2));
+        return fmaf(Sf, fp.c1, fmaf(__builtin_amdgcn_sqrtf(K), fp.c0, -P2));
     } else if (METHOD == PRL_NICK) {
-        return fmaf(-Sf, fp.c1, fmaf(-__builtin_amdgcn_sqrtf(Qf), fp.c0, P2));
+        return fmaf(Sf, fp.c1, fmaf(__builtin_amdgcn_sqrtf(Qf), fp.c0, -P2));
     } else if (METHOD == PRL_WOLFJOLION) {
         const float d = fmaf(__builtin_amdgcn_sqrtf(K), pk.c1, -fp.c0);
         const float e = fmaf(Sf, fp.c1, -pk.imin);
-        return P2 - fmaf(d, e, Sf * fp.c1);
+        return fmaf(d, e, Sf * fp.c1) - P2;
     } else if (METHOD == PRL_FENG) {
-        return fmaf(-Sf, fp.c0, P2);
+        return fmaf(Sf, fp.c0, -P2);
     } else {  // Wolf sweeps: only K~ is used
         return 0.0f;
     }
+}
+
+// mask bytes of four pixels from the sign bits of their (negated) margins: v_perm_b32 selector 9 / 11 = the sign of
+// the low / high source replicated into a byte, 12 = 0x00.  Two permutes and an OR per four pixels instead of four
+// v_cvt_pk_u8_f32 (all 4-cycle instructions; the OR is a 2-cycle one).
+__device__ __forceinline__ unsigned pack_signs(float t0, float t1, float t2, float t3)
+{
+    const unsigned a = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x0c0c0b09u);
+    const unsigned b = __builtin_amdgcn_perm(__float_as_uint(t3), __float_as_uint(t2), 0x0b090c0cu);
+    return a | b;
 }
 
 template <int METHOD, bool WIDE = false>
@@ -434,21 +446,20 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             }
         } else {
             // float32 decision; tmin/vmin track the smallest margin / variance of the lane's 8 pixels.
-            // Mask bytes: every settled pixel has |t| > eps1 >= 1e-6, so t2 = Z t saturates the float->u8
-            // conversion to 255 (white, t > 0) or 0; unsettled pixels are overwritten by k_refine/k_fixup.
-            unsigned lo = 0, hi = 0;
+            // Mask bytes: the sign of the negated margin (pack_signs); unsettled pixels are overwritten by
+            // k_refine/k_fixup.
+            float tn[CPL];
             float tmin = 3.0e38f, vmin = 3.0e38f;
     #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const unsigned p = byte_of(pv, c);
                 const float P2 = fmaf((float)p, kZ, pk.p0);
                 float v32;
-                const float ts = eval32<METHOD, WIDE>(fp, Ssum[c], Qsum[c], P2, pk, &v32);
-                tmin = fminf(tmin, fabsf(ts));
+                tn[c] = eval32<METHOD, WIDE>(fp, Ssum[c], Qsum[c], P2, pk, &v32);
+                tmin = fminf(tmin, fabsf(tn[c]));
                 vmin = fminf(vmin, v32);
-                if (c < 4) lo = __builtin_amdgcn_cvt_pk_u8_f32(ts, c, lo);
-                else hi = __builtin_amdgcn_cvt_pk_u8_f32(ts, c - 4, hi);
             }
+            unsigned lo = pack_signs(tn[0], tn[1], tn[2], tn[3]), hi = pack_signs(tn[4], tn[5], tn[6], tn[7]);
             if (fp.need_p0) {
                 // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative)
                 const unsigned nzl = (((pv.x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | pv.x) & 0x80808080u;
@@ -634,8 +645,9 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     // Loads are issued where their destination registers have just died, one iteration ahead of their use: the
     // compared pixels of the next row right after this row's decision, the next entering and leaving rows right
     // after the slide.  No second set of registers, a whole iteration of latency hiding.
-    F8 vnew = load_win(ys + w), vold = load_win(ys + 1);
-    F8 pv = tload8(rsrc, x0, ys * step);
+    F8 vnew = load_win(ys + w);
+    F8 vold = load_win(ys + 1);
+    uint2 pvb = gload8(img + (size_t)ys * istep + x0);
 #pragma unroll 1
     for (int y = ys; y < ye; ++y) {
         float ES[CPL], EQ[CPL], tot_s, tot_q;
@@ -677,18 +689,23 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
 #pragma unroll
         for (int c = 0; c < CPL; ++c) Qsum[c] = (Qsum[c] - EQ[c]) + ((c + SH) >= 8 ? w1q : w0q);
 
-        unsigned lo = 0, hi = 0;
+        // the compared pixels come as packed bytes (one 8-byte load, 8 v_cvt_f32_ubyte): the kernel leans on the
+        // vector-memory pipe, and one load instruction less is worth more than eight conversions (3.48 -> 3.39 ms;
+        // fetching the leaving or both window rows this way too: 3.80 ms)
+        F8 pv;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) pv.v[c] = (float)byte_of(pvb, c);
+        float tn[CPL];
         float tmin = 3.0e38f, vmin = 3.0e38f;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const float P2 = fmaf(pv.v[c], kZ, pk.p0);
             float v32;
-            const float ts = eval32f<METHOD>(fp, Ssum[c], Qsum[c], P2, pk, &v32);
-            tmin = fminf(tmin, fabsf(ts));
+            tn[c] = eval32f<METHOD>(fp, Ssum[c], Qsum[c], P2, pk, &v32);
+            tmin = fminf(tmin, fabsf(tn[c]));
             vmin = fminf(vmin, v32);
-            if (c < 4) lo = __builtin_amdgcn_cvt_pk_u8_f32(ts, c, lo);
-            else hi = __builtin_amdgcn_cvt_pk_u8_f32(ts, c - 4, hi);
         }
+        unsigned lo = pack_signs(tn[0], tn[1], tn[2], tn[3]), hi = pack_signs(tn[4], tn[5], tn[6], tn[7]);
 
         if (fp.need_p0) {  // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative)
 #pragma unroll
@@ -740,7 +757,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             }
         }
 
-        pv = tload8(rsrc, x0, min(y + 1, H - 1) * step);
+        pvb = gload8(img + (size_t)min(y + 1, H - 1) * istep + x0);
 
         // slide the window one row down: new^2 - old^2 = (new - old)(new + old), one exact fma
 #pragma unroll
