@@ -374,3 +374,22 @@ def test_random_sweep_wide_pages(prl, oracle, cuda_device, seed):
         want = oracle.binarize(pg, p)
         bad = int((got[i] != want).sum())
         assert bad == 0, f"seed {seed} page {i} ({kinds[i]}): {bad} mismatches, method {method} w {win} k {k} morph {morph} {h}x{w}"
+
+
+@pytest.mark.parametrize("method", [SAUVOLA, NIBLACK, WOLFJOLION, NICK, FENG])
+@pytest.mark.parametrize("win", [23, 31])
+def test_float_pipeline_at_the_largest_sums(prl, oracle, cuda_device, method, win):
+    """Interior strips, saturated content: all-white and 0/255 patterns push the sums of squares of the lane chain past
+    2^24, where the float32 pipeline rounds (cq); black/white borders put nearly-black windows next
+    to saturated columns (the case that fixes Qmin)."""
+    h, w = 96, 1400
+    rng = np.random.default_rng(win * 10 + method)
+    white = np.full((h, w), 255, np.uint8)
+    checker = (((np.add.outer(np.arange(h), np.arange(w)) // 3) % 2) * 255).astype(np.uint8)
+    halves = np.zeros((h, w), np.uint8)
+    halves[:, : w // 2 + 5] = 255
+    halves[::7, w // 2 - 40: w // 2 + 60] = rng.integers(0, 256, halves[::7, w // 2 - 40: w // 2 + 60].shape, dtype=np.uint8)
+    stripes = np.where((np.arange(w) // 37) % 2 == 0, 255, rng.integers(0, 4, w)).astype(np.uint8)[None, :].repeat(h, 0)
+    stripes = (stripes.astype(np.int16) - rng.integers(0, 3, (h, w))).clip(0, 255).astype(np.uint8)
+    k = {SAUVOLA: 0.34, NIBLACK: -0.2, WOLFJOLION: 0.3, NICK: -0.1, FENG: 0.2}[method]
+    _check(prl, oracle, cuda_device, [white, checker, halves, stripes], method, win, k, 0)
