@@ -1211,7 +1211,7 @@ bool fused_supports(const ThrParams& tp)
 // (the W chain) and the final window sum round once each when they reach 2^24 (half an ulp of their largest
 // possible value); any such partial sum covers the window plus at most 8 columns outside it, so a rounding can
 // only happen when Q >= 2^24 - 8 (w-1) 65025 =: Qmin, which turns the absolute bound into a relative one.
-static bool flt_usable(const ThrParams& tp, size_t src_step, double* cq)
+static bool flt_usable(const ThrParams& tp, size_t src_step, double* cq, double* delta_out = nullptr, double* qmin_out = nullptr)
 {
     if (const char* e = std::getenv("PRL_HIP_FLT")) if (e[0] == '0') return false;
     const int n1 = tp.w - 1;
@@ -1224,7 +1224,19 @@ static bool flt_usable(const ThrParams& tp, size_t src_step, double* cq)
     const double qmin = 16777216.0 - 8.0 * col;
     if (delta > 0.0 && !(qmin > 0.0)) return false;
     *cq = std::fmax(1.0, delta > 0.0 ? delta / (qmin * std::ldexp(1.0, -24)) : 1.0);
+    if (delta_out) *delta_out = delta;
+    if (qmin_out) *qmin_out = qmin;
     return true;
+}
+
+extern "C" int prl_hip_internal_flt_q_error(int w, double* delta_qmin_cq)
+{
+    // test hook (not in the public header): the float32 pipeline's bound on |Q~ - Q| for window w -
+    // [0] = delta (absolute), [1] = Qmin (no rounding below it), [2] = cq; returns 0 when the pipeline is not used for w
+    ThrParams tp{};
+    tp.w = w;
+    tp.height = 1;
+    return flt_usable(tp, 1, &delta_qmin_cq[2], &delta_qmin_cq[0], &delta_qmin_cq[1]) ? 1 : 0;
 }
 
 constexpr size_t kSegmaxCap = 1u << 20;  // wavefronts per call whose sweep-A maxima can be kept (Wolf)

@@ -94,3 +94,60 @@ def test_margins_scale_with_page_and_stay_small(prl):
     assert b1k["Em"] < b4k["Em"] and b1k["Eq"] < b4k["Eq"]
     assert 1e-6 <= b4k["eps1"] < 5e-3          # the mask packing needs eps1 >= 1e-6; the band must stay narrow
     assert b4k["vthr"] >= 64 * (b4k["Eq"] + 510 * b4k["Em"]) or b4k["vthr"] == 1e-2
+
+
+@pytest.mark.parametrize("w", [9, 15, 21, 23, 25, 29, 31])
+def test_float32_pipeline_q_error_bound(prl, w):
+    """flt_usable()'s bound on the float32 pipeline's window sum of squares (cq): the lane chain of
+    strip_loop_f is emulated in numpy float32 on adversarial column sums (0 / maximal / random columns) and compared
+    with the exact integer window sums: |Q~ - Q| <= delta, and no error at all below Qmin."""
+    from prlib_amd import _capi
+
+    L = _capi.lib()
+    L.prl_hip_internal_flt_q_error.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    out = (C.c_double * 3)()
+    assert L.prl_hip_internal_flt_q_error(w, out) == 1
+    delta, qmin, cq = out[0], out[1], out[2]
+    n1, lane_off, sh = w - 1, (w - 1) // 8, (w - 1) % 8
+    colmax = n1 * 65025
+    rng = np.random.default_rng(w)
+    worst = 0.0
+    for trial in range(300):
+        kind = trial % 4
+        if kind == 0:
+            vq = np.full(512, colmax, np.int64)
+        elif kind == 1:
+            vq = rng.integers(0, colmax + 1, 512)
+        elif kind == 2:   # dark windows beside saturated columns
+            vq = np.where((np.arange(512) // int(rng.integers(5, 40))) % 2 == 0, colmax, rng.integers(0, 2000, 512))
+        else:
+            vq = np.where(rng.random(512) < rng.random(), colmax, rng.integers(0, colmax // 50 + 1, 512))
+        v = vq.reshape(64, 8)
+        f = v.astype(np.float32)
+        # in-lane exclusive prefixes and totals (float32, as the kernel forms them)
+        eq = np.zeros((64, 8), np.float32)
+        acc = f[:, 0].copy()
+        for c in range(1, 8):
+            eq[:, c] = acc
+            acc = (acc + f[:, c]).astype(np.float32)
+        tot = acc
+        up = lambda x: np.concatenate([x[1:], np.zeros(1, np.float32)])  # lane + 1 (0 beyond the wavefront)
+        w0, w1 = np.zeros(64, np.float32), tot.copy()
+        for _ in range(lane_off):
+            w0 = w1
+            w1 = (tot + up(w1)).astype(np.float32)
+        exact_prefix = np.concatenate([[0], np.cumsum(vq)])
+        for lane in range(0, 64 - lane_off - 1):
+            for c in range(8):
+                far1 = (c + sh) >= 8
+                fl = lane + lane_off + (1 if far1 else 0)
+                far = eq[fl, (c + sh) & 7]
+                q32 = np.float32(np.float32(far - eq[lane, c]) + (w1[lane] if far1 else w0[lane]))
+                col = lane * 8 + c
+                exact = int(exact_prefix[col + n1] - exact_prefix[col])   # columns col .. col + w - 2
+                err = abs(float(q32) - exact)
+                assert err <= delta, (w, trial, lane, c, err, delta)
+                if exact < qmin:
+                    assert err == 0.0, (w, trial, lane, c, exact, qmin, err)
+                worst = max(worst, err)
+    assert cq >= 1.0 and worst <= delta
