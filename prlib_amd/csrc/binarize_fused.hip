@@ -645,9 +645,17 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     // Loads are issued where their destination registers have just died, one iteration ahead of their use: the
     // compared pixels of the next row right after this row's decision, the next entering and leaving rows right
     // after the slide.  No second set of registers, a whole iteration of latency hiding.
-    F8 vnew = load_win(ys + w);
-    F8 vold = load_win(ys + 1);
-    uint2 pvb = gload8(img + (size_t)ys * istep + x0);
+    // Row byte offsets advance by one row step per iteration; the replicate clamp is a min / max on the offset itself
+    // (the entering row can only run past the last page row, the leaving row only start above the first): 5 scalar
+    // instructions per iteration instead of 13 - scalar instructions cost issue slots like vector ones here.
+    const int off_last = (H - 1) * step;
+    int off_new = min((ys + w - h) * step, off_last);   // padded row ys + w
+    int off_old = max((ys + 1 - h) * step, 0);          // padded row ys + 1
+    gcptr pv_ptr = img + (size_t)ys * istep + x0;
+    F8 vnew = tload8(rsrc, col0, off_new);
+    F8 vold = tload8(rsrc, col0, off_old);
+    int off_old_raw = (ys + 1 - h) * step;
+    uint2 pvb = gload8(pv_ptr);
 #pragma unroll 1
     for (int y = ys; y < ye; ++y) {
         float ES[CPL], EQ[CPL], tot_s, tot_q;
@@ -757,7 +765,8 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             }
         }
 
-        pvb = gload8(img + (size_t)min(y + 1, H - 1) * istep + x0);
+        pv_ptr += istep;  // row y + 1 <= H - 1 exists for every output row
+        pvb = gload8(pv_ptr);
 
         // slide the window one row down: new^2 - old^2 = (new - old)(new + old), one exact fma
 #pragma unroll
@@ -766,8 +775,11 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             VS[c] += d;
             VQ[c] = fmaf(d, sm, VQ[c]);
         }
-        vnew = load_win(y + 1 + w);
-        vold = load_win(y + 2);  // (a non-temporal hint on this last use of the row measured 2 % slower)
+        off_new = min(off_new + step, off_last);
+        off_old_raw += step;
+        off_old = max(off_old_raw, 0);
+        vnew = tload8(rsrc, col0, off_new);
+        vold = tload8(rsrc, col0, off_old);  // (a non-temporal hint on this last use of the row measured 2 % slower)
     }
 }
 

@@ -442,18 +442,31 @@ __device__ __forceinline__ void neighbours(unsigned c, int lane, unsigned* prev,
     *next = n;
 }
 
+// The two 16-bit halves of a word are independent chunks: packed 16-bit shifts (v_pk_lshlrev_b16 / v_pk_lshrrev_b16)
+// move both at once and nothing crosses between them, so a funnel shift against the neighbour chunk is two shifts and
+// an OR (the 32-bit shifts needed two masks on top).
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_shl(unsigned x, unsigned k)
+{
+    const us2 v = __builtin_bit_cast(us2, x) << (us2)((unsigned short)k);
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ unsigned pk_shr(unsigned x, unsigned k)
+{
+    const us2 v = __builtin_bit_cast(us2, x) >> (us2)((unsigned short)k);
+    return __builtin_bit_cast(unsigned, v);
+}
+
 // both 16-bit halves shifted towards higher x by k (pixel x takes pixel x - k), 0 <= k <= 15
 __device__ __forceinline__ unsigned shift_up(unsigned c, unsigned prev, unsigned k)
 {
-    const unsigned m = ((1u << k) - 1u) * 0x00010001u;  // low k bits of each half come from the previous chunk
-    return ((c << k) & ~m) | ((prev >> (16u - k)) & m);
+    return k == 0 ? c : (pk_shl(c, k) | pk_shr(prev, 16u - k));  // (a 16-bit shift by 16 would wrap to 0)
 }
 
 // both halves shifted towards lower x by k (pixel x takes pixel x + k), 1 <= k <= 15
 __device__ __forceinline__ unsigned shift_down(unsigned c, unsigned next, unsigned k)
 {
-    const unsigned m = ((0xffffu << (16u - k)) & 0xffffu) * 0x00010001u;  // top k bits of each half come from the next chunk
-    return ((c >> k) & ~m) | ((next << (16u - k)) & m);
+    return pk_shr(c, k) | pk_shl(next, 16u - k);
 }
 
 template <bool IS_OR, int N>
@@ -463,7 +476,15 @@ __device__ __forceinline__ unsigned hop_bits(unsigned c, int lane)
     neighbours(c, lane, &prev, &next);
     unsigned v = c;
 #pragma unroll
-    for (int k = 1; k <= N; ++k) v = comb<IS_OR>(v, comb<IS_OR>(shift_up(c, prev, k), shift_down(c, next, k)));
+    for (int k = 1; k <= N; ++k) {
+        if (IS_OR) {
+            v |= pk_shl(c, k) | pk_shr(prev, 16u - k);
+            v |= pk_shr(c, k) | pk_shl(next, 16u - k);
+        } else {
+            v &= pk_shl(c, k) | pk_shr(prev, 16u - k);
+            v &= pk_shr(c, k) | pk_shl(next, 16u - k);
+        }
+    }
     return v;
 }
 
@@ -482,8 +503,10 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
     const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
     const int seg = rem / n_strips, strip = rem - seg * n_strips;
 
-    const uint8_t* in = src.page(page);
-    uint8_t* out = dst.page(page);
+    typedef const uint8_t __attribute__((address_space(1)))* mgcptr;  // known-global pointers: global_load / global_store
+    typedef uint8_t __attribute__((address_space(1)))* mgptr;
+    mgcptr in = (mgcptr)src.page(page);
+    mgptr out = (mgptr)dst.page(page);
     const int base_px = strip * kBitsAdvance - 32;                 // source pixel of chunk 0
     const int gx0 = base_px + 16 * lane, gx1 = gx0 + 1024;         // first pixel of this lane's two chunks
     const int ys = seg * rows_per_seg, ye = min(ys + rows_per_seg, height);
@@ -501,17 +524,32 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
     // pipeline's own mask buffer), so an edge chunk is fetched whole and masked.
     auto fetch = [&](int r) -> unsigned {
         if (r < 0 || r >= height) return neutral1;
-        const uint8_t* row = in + (size_t)r * src.step;
+        mgcptr row = in + (size_t)r * src.step;
         unsigned v = 0;
         if (BITSRC) {
-            if (in0) v = *reinterpret_cast<const unsigned short*>(row + (gx0 >> 3));
-            if (in1) v |= (unsigned)*reinterpret_cast<const unsigned short*>(row + (gx1 >> 3)) << 16;
+            if (in0) v = *reinterpret_cast<const unsigned short*>((const uint8_t*)(row + (gx0 >> 3)));
+            if (in1) v |= (unsigned)*reinterpret_cast<const unsigned short*>((const uint8_t*)(row + (gx1 >> 3))) << 16;
         } else {
-            if (in0) v = pack16(*reinterpret_cast<const uint4*>(row + gx0));
-            if (in1) v |= pack16(*reinterpret_cast<const uint4*>(row + gx1)) << 16;
+            if (in0) v = pack16(*reinterpret_cast<const uint4*>((const uint8_t*)(row + gx0)));
+            if (in1) v |= pack16(*reinterpret_cast<const uint4*>((const uint8_t*)(row + gx1))) << 16;
         }
         return (v & inside) | (neutral1 & ~inside);
     };
+
+    // which of this lane's two output chunks are stored whole / partly: fixed for the wavefront when every row of the
+    // destination has the same address mod 16 (row step a multiple of 16: the usual case), else redone per row
+    const bool fixed_a = (dst.step & 15u) == 0;
+    unsigned A = (unsigned)((size_t)(uint8_t*)out & 15u);
+    bool full0 = false, full1 = false, rag0 = false, rag1 = false;
+    auto classify = [&](unsigned a) {
+        const int p0 = base_px + 16 * lane - (int)a, p1 = p0 + 1024;
+        const bool s0 = lane >= 2 && p0 + 16 > 0 && p0 < width, s1 = lane <= 62 && p1 + 16 > 0 && p1 < width;
+        full0 = s0 && p0 >= 0 && p0 + 16 <= width;
+        full1 = s1 && p1 >= 0 && p1 + 16 <= width;
+        rag0 = s0 && !full0;
+        rag1 = s1 && !full1;
+    };
+    classify(A);
 
     unsigned ring1[K], ring2[K];
 #pragma unroll
@@ -544,33 +582,36 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
         for (int k = 1; k < K; ++k) o = comb<!FIRST_OR>(o, ring2[k]);
 
         // destination-aligned chunks: chunk c covers pixels [base_px + 16 c - A, + 16)
-        uint8_t* orow = out + (size_t)ro * dst.step;
-        const unsigned A = (unsigned)((size_t)orow & 15u);  // wave-uniform
+        mgptr orow = out + (size_t)ro * dst.step;
+        if (!fixed_a) {
+            A = (unsigned)((size_t)(uint8_t*)orow & 15u);  // wave-uniform
+            classify(A);
+        }
         unsigned oprev, onext;
         neighbours(o, lane, &oprev, &onext);
         const unsigned bits = shift_up(o, oprev, A);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int c = half * 64 + lane;
-            const int px = base_px + 16 * c - (int)A;
-            if (c >= 2 && c <= 126 && px + 16 > 0 && px < width) {
-                const uint4 d = unpack16((bits >> (16 * half)) & 0xffffu);
-                if (px >= 0 && px + 16 <= width) {
-                    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-                    const u4v dv = {d.x, d.y, d.z, d.w};
-                    __builtin_nontemporal_store(dv, reinterpret_cast<u4v*>(orow + px));  // streamed out, never re-read
-                } else {  // ragged ends of the row: dwords that lie inside, then bytes
-                    const unsigned dw[4] = {d.x, d.y, d.z, d.w};
+            const bool full = half ? full1 : full0, ragged = half ? rag1 : rag0;
+            if (!(full || ragged)) continue;
+            const int px = base_px + 16 * (half * 64 + lane) - (int)A;
+            // (a 256-entry LDS table for this expansion - two ds_read_b64 instead of ~20 vector instructions - measured the same)
+            const uint4 d = unpack16((bits >> (16 * half)) & 0xffffu);
+            if (full) {
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                const u4v dv = {d.x, d.y, d.z, d.w};
+                __builtin_nontemporal_store(dv, reinterpret_cast<u4v*>((uint8_t*)(orow + px)));  // streamed out, never re-read
+            } else {  // ragged ends of the row: dwords that lie inside, then bytes
+                const unsigned dw[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int p4 = px + 4 * q;
-                        if (p4 >= 0 && p4 + 4 <= width) {
-                            *reinterpret_cast<unsigned*>(orow + p4) = dw[q];
-                        } else {
+                for (int q = 0; q < 4; ++q) {
+                    const int p4 = px + 4 * q;
+                    if (p4 >= 0 && p4 + 4 <= width) {
+                        *reinterpret_cast<unsigned*>((uint8_t*)(orow + p4)) = dw[q];
+                    } else {
 #pragma unroll
-                            for (int b = 0; b < 4; ++b)
-                                if (p4 + b >= 0 && p4 + b < width) orow[p4 + b] = (uint8_t)(dw[q] >> (8 * b));
-                        }
+                        for (int b = 0; b < 4; ++b)
+                            if (p4 + b >= 0 && p4 + b < width) orow[p4 + b] = (uint8_t)(dw[q] >> (8 * b));
                     }
                 }
             }
@@ -584,7 +625,7 @@ int launch_morph_bits(int iterations, bool bitsrc, const PageSet& src, int n_pag
 {
     const int n = iterations > 0 ? iterations : -iterations;
     const int n_strips = (width + 15 + kBitsAdvance - 1) / kBitsAdvance;
-    int rps = 128;
+    int rps = 64;  // 256 x 4K pages: 64 rows per segment 1.18 ms, 128: 1.23, 256: 1.24, 512: 1.31
     while (rps > 32 && (long long)n_pages * n_strips * ((height + rps - 1) / rps) < 16384) rps /= 2;
     if (const char* e = std::getenv("PRL_MORPH_RPS")) rps = std::max(8, std::atoi(e));  // tuning knob
     const int n_segs = (height + rps - 1) / rps;
