@@ -36,6 +36,32 @@ DEFK(k_lshl, "v_lshlrev_b32 %0, 1, %0")
 DEFK(k_min, "v_min_i32 %0, %0, %1")
 DEFK(k_fmamix, "v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]")
 DEFK(k_fmamix2, "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,0]")
+// packed float32: operates on register PAIRS; the harness variables are 32-bit, so pairs are formed from %0 and a copy
+__global__ void __launch_bounds__(256) k_pkfma(unsigned* out, unsigned long long* clk, unsigned a, unsigned b, int iters)
+{
+    if (a == 0xdeadbeefu) dyn_lds[threadIdx.x] = 1;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 r0 = {(float)threadIdx.x, 1.f}, r1 = r0 + 1.f, r2 = r0 + 2.f, r3 = r0 + 3.f, r4 = r0 + 4.f, r5 = r0 + 5.f, r6 = r0 + 6.f, r7 = r0 + 7.f;
+    const f2 fa = {(float)a, (float)a}, fb = {(float)b * 1e-3f, (float)b * 1e-3f};
+    const unsigned long long c0 = __builtin_readcyclecounter(), t0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r0) : "v"(fb), "v"(fa));
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r1) : "v"(fb), "v"(fa));
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r2) : "v"(fb), "v"(fa));
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r3) : "v"(fb), "v"(fa));
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r4) : "v"(fb), "v"(fa));
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r5) : "v"(fb), "v"(fa));
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r6) : "v"(fb), "v"(fa));
+            asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(r7) : "v"(fb), "v"(fa));
+        }
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), t1 = wall_clock64();
+    const f2 sum = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(sum.x + sum.y);
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = c1 - c0; clk[1] = t1 - t0; }
+}
 DEFK(k_mix, "v_dot4_u32_u8 %0, %1, %2, %0\n\tv_add_u32 %0, %0, %1\n\tv_lshlrev_b32 %0, 1, %0")
 
 template <typename K> void run(const char* name, K kern, int waves_per_simd, int ninst)
@@ -63,10 +89,10 @@ template <typename K> void run(const char* name, K kern, int waves_per_simd, int
 
 int main()
 {
-    for (int w : {1, 4, 8}) {
+    for (int w : {1, 2, 4, 5, 8}) {
         run("v_add_u32", k_add, w, 1); run("v_fma_f32", k_fma, w, 1); run("v_dot4", k_dot4, w, 1);
         run("v_fma_mix(h,f,f)", k_fmamix, w, 1); run("v_fma_mix(hh,h,f)", k_fmamix2, w, 1);
-        run("v_lshlrev", k_lshl, w, 1); run("v_min_i32", k_min, w, 1); run("dot+add+shl", k_mix, w, 3);
+        run("v_pk_fma_f32", k_pkfma, w, 1); run("v_lshlrev", k_lshl, w, 1); run("v_min_i32", k_min, w, 1); run("dot+add+shl", k_mix, w, 3);
     }
     return 0;
 }
