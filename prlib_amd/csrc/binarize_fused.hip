@@ -315,11 +315,24 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     unsigned VS[CPL], VQ[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) VS[c] = VQ[c] = 0;
+    // Wolf sweep A also carries cv::minMaxLoc's page minimum: bytewise running minimum of every window row this
+    // wavefront fetches (even and odd bytes as packed 16-bit lanes); the rows and columns no sweep fetches are
+    // covered by k_page_min_border
+    typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+    us2v pm_e = {255, 255}, pm_o = {255, 255};
+    auto track_min = [&](uint2 v) {
+        if (METHOD != kWolfMax) return;
+        pm_e = __builtin_elementwise_min(pm_e, __builtin_bit_cast(us2v, v.x & 0x00ff00ffu));
+        pm_o = __builtin_elementwise_min(pm_o, __builtin_bit_cast(us2v, (v.x >> 8) & 0x00ff00ffu));
+        pm_e = __builtin_elementwise_min(pm_e, __builtin_bit_cast(us2v, v.y & 0x00ff00ffu));
+        pm_o = __builtin_elementwise_min(pm_o, __builtin_bit_cast(us2v, (v.y >> 8) & 0x00ff00ffu));
+    };
 
     // warm-up: vertical sums over padded rows ys+1 .. ys+w-1
 #pragma unroll 2
     for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
         const uint2 v = load_win(pr);
+        track_min(v);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const unsigned b = byte_of(v, c);
@@ -334,6 +347,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     for (int y = ys; y < ye; ++y) {
         uint2 pv, vold;
         const uint2 vnew = vnew_n;
+        track_min(vnew);
         if (!SWEEP) pv = gload8(img + (size_t)y * istep + ep.colc);
         vnew_n = load_win(y + 1 + w);
         vold = load_win(y + 1);
@@ -550,9 +564,13 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     if (METHOD == kWolfMax) {
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) vmax_lane = fmaxf(vmax_lane, __shfl_xor(vmax_lane, d, kWave));
+        unsigned pm = min(min((unsigned)pm_e.x, (unsigned)pm_e.y), min((unsigned)pm_o.x, (unsigned)pm_o.y));
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) pm = min(pm, (unsigned)__shfl_xor((int)pm, d, kWave));
         if (lane == 0) {
             fp.segmax[wid] = vmax_lane;
             atomicMax(&g[page].v32max_bits, __float_as_uint(vmax_lane));  // v~ >= 0: bit order == value order
+            atomicMin(&g[page].imin, (int)pm);
         }
     }
 }
@@ -1055,6 +1073,42 @@ __global__ void __launch_bounds__(256) k_wolf_final(FusedParams fp, PageGlobals*
     }
 }
 
+// Page minimum of the part of the page no sweep-A wavefront fetches: the sweeps stop h rows above the bottom and may
+// stop short of the right border, so the last `band` rows and columns are reduced here (band = w is generous).
+__global__ void __launch_bounds__(256) k_page_min_border(PageSet src, int width, int height, int band, PageGlobals* g)
+{
+    // work items = 16-byte pieces: the bottom `band` rows over the whole width, then the right `band` columns of the
+    // rows above; a piece that would run past its region is pulled back inside (re-reading bytes does not change a minimum)
+    const int page = blockIdx.y;
+    const uint8_t* img = src.page(page);
+    const int y0 = max(0, height - band), x0 = max(0, width - band);
+    const int cpr_b = (width + 15) / 16, cpr_r = (width - x0 + 15) / 16;
+    const int n_bottom = (height - y0) * cpr_b, n_right = y0 * cpr_r;
+    unsigned mn = 255;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_bottom + n_right; i += gridDim.x * blockDim.x) {
+        int y, x;
+        if (i < n_bottom) {
+            y = y0 + i / cpr_b;
+            x = min((i % cpr_b) * 16, width - 16);
+        } else {
+            const int j = i - n_bottom;
+            y = j / cpr_r;
+            x = min(x0 + (j % cpr_r) * 16, width - 16);
+        }
+        uint4 q;
+        __builtin_memcpy(&q, img + (size_t)y * src.step + x, 16);
+        const unsigned d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mn = min(mn, min(d[k] & 0xffu, (d[k] >> 8) & 0xffu));
+            mn = min(mn, min((d[k] >> 16) & 0xffu, d[k] >> 24));
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, d, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0 && mn < 255u) atomicMin(&g[page].imin, (int)mn);
+}
+
 template <int METHOD>
 int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
                  PageGlobals* g, RefItem* rl, WorkItem* cand, unsigned* cnt)
@@ -1322,7 +1376,7 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.segmax = reinterpret_cast<float*>(acc + kWorkCap);
     PRL_HIP_CHECK(hipMemsetAsync(cnt, 0, 256, stream));
 
-    if (tp.method == PRL_FENG || tp.method == PRL_WOLFJOLION) {
+    if (tp.method == PRL_FENG) {
         int st = page_min_run(tp, src, n_pages, d_globals, stream);
         if (st != PRL_OK) return st;
     }
@@ -1332,8 +1386,21 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         // sweep B revisits only the wavefront segments that can hold the literal maximum and queues their
         // candidate pixels, k_wolf_exact evaluates those literally, k_wolf_coeff forms k / devianceMax.
         if (fp.total_waves > kSegmaxCap) return PRL_ERR_BAD_ARG;
+        // (cv::minMaxLoc(imageInput) rides on sweep A - every window row a wavefront fetches goes into a running
+        // minimum - plus a small kernel for the bottom rows / right columns the sweeps never fetch; Feng, which has no
+        // sweep, uses k_page_min)
         int st = launch_sweep<kWolfMax>(sh, stream, src, dst, fp, d_globals, rl, cand, cnt);
         if (st != PRL_OK) return st;
+        {
+            const int band = std::min(std::max(tp.w + 8, 16), std::max(tp.width, tp.height));
+            for (int first = 0; first < n_pages; first += 32768) {  // grid.y limit
+                PageSet part = src;
+                if (part.table) part.table += first; else part.base += (size_t)first * part.page_stride;
+                hipLaunchKernelGGL(k_page_min_border, dim3(16, std::min(32768, n_pages - first)), dim3(256), 0, stream, part,
+                                   tp.width, tp.height, band, d_globals + first);
+            }
+            PRL_HIP_CHECK(hipGetLastError());
+        }
         st = launch_sweep<kWolfCollect>(sh, stream, src, dst, fp, d_globals, rl, cand, cnt);
         if (st != PRL_OK) return st;
         PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, stream));
