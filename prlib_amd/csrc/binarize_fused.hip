@@ -958,16 +958,26 @@ __device__ __forceinline__ void row_range_sums(const uint8_t* row, int ca, int c
 {
     unsigned s = 0, q = 0;
     const int nbytes = cb - ca + 1;
-    for (int t = lane * 4; t < nbytes; t += kWave * 4) {
-        unsigned v;
-        if (t + 4 <= nbytes) {
-            __builtin_memcpy(&v, row + ca + t, 4);
-        } else {
-            v = 0;
-            for (int k = 0; t + k < nbytes; ++k) v |= (unsigned)row[ca + t + k] << (8 * k);
-        }
-        s = __builtin_amdgcn_udot4(v, 0x01010101u, s, false);
-        q = __builtin_amdgcn_udot4(v, v, q, false);
+    // 16 bytes per lane and step (the loop is a chain of dependent-latency loads: fewer, wider loads), dwords and
+    // single bytes for the tail
+    const int n16 = nbytes / 16;
+    for (int t = lane; t < n16; t += kWave) {
+        uint4 v;
+        __builtin_memcpy(&v, row + ca + 16 * t, 16);
+        s = __builtin_amdgcn_udot4(v.x, 0x01010101u, s, false);
+        q = __builtin_amdgcn_udot4(v.x, v.x, q, false);
+        s = __builtin_amdgcn_udot4(v.y, 0x01010101u, s, false);
+        q = __builtin_amdgcn_udot4(v.y, v.y, q, false);
+        s = __builtin_amdgcn_udot4(v.z, 0x01010101u, s, false);
+        q = __builtin_amdgcn_udot4(v.z, v.z, q, false);
+        s = __builtin_amdgcn_udot4(v.w, 0x01010101u, s, false);
+        q = __builtin_amdgcn_udot4(v.w, v.w, q, false);
+    }
+    const int rest = n16 * 16 + lane;  // the last nbytes % 16 (< 16) bytes, one per lane
+    if (rest < nbytes) {
+        const unsigned b = row[ca + rest];
+        s += b;
+        q += b * b;
     }
     *s_out = s;
     *q_out = q;
@@ -1014,13 +1024,21 @@ __global__ void __launch_bounds__(256) k_corner_partial(PageSet src, FusedParams
             a[0] += ct * sl;  a[1] += ct * sr;  a[2] += cb2 * sl;  a[3] += cb2 * sr;
             a[4] += ct * ql;  a[5] += ct * qr;  a[6] += cb2 * ql;  a[7] += cb2 * qr;
         }
+        // one atomic per workgroup and sum (256 wavefronts of a pixel adding to the same 8 words serialised)
+        __shared__ unsigned long long part[4][8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             unsigned long long v = a[k];
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
-            if (lane == 0 && v != 0) atomicAdd(&acc[it].a[k], v);
+            if (lane == 0) part[wv][k] = v;
         }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            const unsigned long long v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+            if (v != 0) atomicAdd(&acc[it].a[threadIdx.x], v);
+        }
+        __syncthreads();
     }
 }
 
