@@ -733,12 +733,12 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         }
         unsigned lo = pack_signs(tn[0], tn[1], tn[2], tn[3]), hi = pack_signs(tn[4], tn[5], tn[6], tn[7]);
 
-        if (fp.need_p0) {  // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative)
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                if (c < 4) lo = (pv.v[c] == 0.0f) ? (lo & ~(0xffu << (8 * c))) : lo;
-                else hi = (pv.v[c] == 0.0f) ? (hi & ~(0xffu << (8 * (c - 4)))) : hi;
-            }
+        if (fp.need_p0) {
+            // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative); on the packed bytes
+            const unsigned nzl = (((pvb.x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | pvb.x) & 0x80808080u;
+            const unsigned nzh = (((pvb.y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | pvb.y) & 0x80808080u;
+            lo &= (nzl >> 7) * 255u;
+            hi &= (nzh >> 7) * 255u;
         }
         const F8 pv_cur = pv;
 
