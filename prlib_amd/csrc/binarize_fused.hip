@@ -632,10 +632,11 @@ __device__ __forceinline__ float bpermf(int addr, float v)
 
 template <int METHOD, int SH>
 __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, size_t ostep, const FusedParams& fp,
-                                             int page, int xs, int ys, int ye, int lane, const PageK& pk,
+                                             int page, int xs, int ys, int ye, int lane, const PageK& pk, unsigned wid,
                                              PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
                                              unsigned* __restrict__ counters)
 {
+    constexpr bool SWEEP_A = METHOD == kWolfMax;  // Wolf-Jolion's variance-maximum sweep: sums and K~ only, no decision
     const ThrParams& tp = fp.tp;
     const int H = tp.height, h = tp.half, w = tp.w;
     const int col0 = xs + 1 - h + CPL * lane;  // image column of this lane's sub-column 0 (interior: no clamp)
@@ -650,9 +651,15 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     float VS[CPL], VQ[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) VS[c] = VQ[c] = 0.0f;
+    float pmin = 255.0f, vmax_lane = 0.0f;  // sweep A: running page minimum (see strip_loop) and variance maximum
+    auto track_min = [&](const F8& v) {
+        if (!SWEEP_A) return;
+        pmin = fminf(fminf(pmin, fminf(v.v[0], v.v[1])), fminf(fminf(v.v[2], v.v[3]), fminf(fminf(v.v[4], v.v[5]), fminf(v.v[6], v.v[7]))));
+    };
 #pragma unroll 2
     for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
         const F8 v = load_win(pr);
+        track_min(v);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             VS[c] += v.v[c];
@@ -673,9 +680,11 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     F8 vnew = tload8(rsrc, col0, off_new);
     F8 vold = tload8(rsrc, col0, off_old);
     int off_old_raw = (ys + 1 - h) * step;
-    uint2 pvb = gload8(pv_ptr);
+    uint2 pvb = make_uint2(0u, 0u);
+    if (!SWEEP_A) pvb = gload8(pv_ptr);
 #pragma unroll 1
     for (int y = ys; y < ye; ++y) {
+        track_min(vnew);
         float ES[CPL], EQ[CPL], tot_s, tot_q;
         {
             float accs = VS[0], accq = VQ[0];  // (not 0 + VS[0]: the compiler keeps a float add of +0)
@@ -715,6 +724,13 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
 #pragma unroll
         for (int c = 0; c < CPL; ++c) Qsum[c] = (Qsum[c] - EQ[c]) + ((c + SH) >= 8 ? w1q : w0q);
 
+        if constexpr (SWEEP_A) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const float K = fmaf(fp.w2f, Qsum[c], -(Ssum[c] * Ssum[c]));
+                if (lane_has_out) vmax_lane = fmaxf(vmax_lane, K);
+            }
+        } else {
         // the compared pixels come as packed bytes (one 8-byte load, 8 v_cvt_f32_ubyte): the kernel leans on the
         // vector-memory pipe, and one load instruction less is worth more than eight conversions (3.48 -> 3.39 ms;
         // fetching the leaving or both window rows this way too: 3.80 ms)
@@ -785,6 +801,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
 
         pv_ptr += istep;  // row y + 1 <= H - 1 exists for every output row
         pvb = gload8(pv_ptr);
+        }  // !SWEEP_A
 
         // slide the window one row down: new^2 - old^2 = (new - old)(new + old), one exact fma
 #pragma unroll
@@ -798,6 +815,18 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         off_old = max(off_old_raw, 0);
         vnew = tload8(rsrc, col0, off_new);
         vold = tload8(rsrc, col0, off_old);  // (a non-temporal hint on this last use of the row measured 2 % slower)
+    }
+    if (SWEEP_A) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            vmax_lane = fmaxf(vmax_lane, __shfl_xor(vmax_lane, d, kWave));
+            pmin = fminf(pmin, __shfl_xor(pmin, d, kWave));
+        }
+        if (lane == 0) {
+            fp.segmax[wid] = vmax_lane;
+            atomicMax(&g[page].v32max_bits, __float_as_uint(vmax_lane));  // v~ >= 0: bit order == value order
+            atomicMin(&g[page].imin, (int)pmin);
+        }
     }
 }
 
@@ -857,9 +886,9 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     // the page, so no clamp, no partial store
     const int first_col = xs + 1 - tp.half;
     const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
-    constexpr bool kThreshold = !(METHOD == kWolfMax || METHOD == kWolfCollect);
-    if (interior && kThreshold && !WIDE && fp.flt)
-        strip_loop_f<METHOD, SH>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, g, rl, counters);
+    constexpr bool kFloatOk = METHOD != kWolfCollect;  // (sweep B revisits few segments and queues exact candidates: integer)
+    if (interior && kFloatOk && !WIDE && fp.flt)
+        strip_loop_f<METHOD, SH>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
     else if (interior)
         strip_loop<METHOD, SH, false, WIDE>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
     else
@@ -1359,7 +1388,7 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     double cq = 1.0;
     fp.flt = flt_usable(tp, src.step, &cq) ? 1 : 0;
     const FusedBounds b = fused_bounds(tp, fp.flt ? cq : 1.0);  // margins of the threshold sweep
-    const FusedBounds b1 = fused_bounds(tp);                    // Wolf-Jolion's maximum search always runs on integers
+    const FusedBounds b1 = fused_bounds(tp);                    // integer-pipeline margins (Wolf-Jolion's sweep B, literal noise terms)
     const double Z = (double)kZ, f = tp.f;
     fp.w2f = (float)(tp.w * tp.w);
     fp.Em = b.Em;
@@ -1382,7 +1411,7 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     default: return PRL_ERR_BAD_ARG;
     }
     fp.es_max = (float)(b.Es * 1.01);
-    fp.rho = (float)(b1.rho * 1.01);
+    fp.rho = (float)(std::fmax(b1.rho, b.rho) * 1.01);  // sweep A runs the float32 pipeline on interior strips, sweep B the integer one
     fp.ev2 = (float)(2.0 * b1.Ev * 1.01 / (f * f));  // in K units
 
     // [0] refine-list length, [1] fix-up-list length, [2] Wolf candidate-list length
