@@ -520,22 +520,8 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
     const unsigned in0 = inside16(gx0), in1 = inside16(gx1);
     const unsigned inside = in0 | (in1 << 16);
 
-    // page row r as bits.  Source rows are 16-byte aligned and padded to whole chunks (checked by the host: the
-    // pipeline's own mask buffer), so an edge chunk is fetched whole and masked.
-    auto fetch = [&](int r) -> unsigned {
-        if (r < 0 || r >= height) return neutral1;
-        mgcptr row = in + (size_t)r * src.step;
-        unsigned v = 0;
-        if (BITSRC) {
-            if (in0) v = *reinterpret_cast<const unsigned short*>((const uint8_t*)(row + (gx0 >> 3)));
-            if (in1) v |= (unsigned)*reinterpret_cast<const unsigned short*>((const uint8_t*)(row + (gx1 >> 3))) << 16;
-        } else {
-            if (in0) v = pack16(*reinterpret_cast<const uint4*>((const uint8_t*)(row + gx0)));
-            if (in1) v |= pack16(*reinterpret_cast<const uint4*>((const uint8_t*)(row + gx1))) << 16;
-        }
-        return (v & inside) | (neutral1 & ~inside);
-    };
-
+    // (source rows are 16-byte aligned and padded to whole chunks - checked by the host: the pipeline's own mask
+    // buffer - so an edge chunk is fetched whole and masked)
     // which of this lane's two output chunks are stored whole / partly: fixed for the wavefront when every row of the
     // destination has the same address mod 16 (row step a multiple of 16: the usual case), else redone per row
     const bool fixed_a = (dst.step & 15u) == 0;
@@ -557,11 +543,43 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
         ring1[k] = neutral1;
         ring2[k] = neutral2;
     }
-    unsigned vnext = fetch(ys - 2 * N);
+    // Rows are taken four at a time: all their loads are issued back to back in straight-line code (clamped row and
+    // column addresses instead of branches, the fetched words masked afterwards), so a wavefront waits for memory once
+    // per four rows.  With one row per iteration the compiler had to put `s_waitcnt vmcnt(0)` right behind each load -
+    // the counter is shared with the (conditional) stores of the previous row, whose write acknowledgements then sat
+    // on every row's critical path.
+    constexpr int RB = 4;
+    const int boff0 = in0 ? (gx0 >> 3) : 0, boff1 = in1 ? (gx1 >> 3) : 0;   // BITSRC: byte offsets of the two 16-bit words
+    const int poff0 = in0 ? gx0 : 0, poff1 = in1 ? gx1 : 0;                 // byte masks: offsets of the two 16-byte chunks
 #pragma unroll 1
-    for (int r = ys - 2 * N; r < ye + 2 * N; ++r) {
-        const unsigned v = vnext;
-        vnext = fetch(r + 1);  // one row ahead; the rest of the latency is hidden by the other wavefronts
+    for (int r0 = ys - 2 * N; r0 < ye + 2 * N; r0 += RB) {
+        unsigned raw[RB];
+        if (BITSRC) {
+            unsigned lo[RB], hi[RB];
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                mgcptr row = in + (size_t)min(max(r0 + k, 0), height - 1) * src.step;
+                lo[k] = *reinterpret_cast<const unsigned short*>((const uint8_t*)(row + boff0));
+                hi[k] = *reinterpret_cast<const unsigned short*>((const uint8_t*)(row + boff1));
+            }
+#pragma unroll
+            for (int k = 0; k < RB; ++k) raw[k] = lo[k] | (hi[k] << 16);
+        } else {
+            uint4 qa[RB], qb[RB];
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                mgcptr row = in + (size_t)min(max(r0 + k, 0), height - 1) * src.step;
+                qa[k] = *reinterpret_cast<const uint4*>((const uint8_t*)(row + poff0));
+                qb[k] = *reinterpret_cast<const uint4*>((const uint8_t*)(row + poff1));
+            }
+#pragma unroll
+            for (int k = 0; k < RB; ++k) raw[k] = pack16(qa[k]) | (pack16(qb[k]) << 16);
+        }
+#pragma unroll
+      for (int kk = 0; kk < RB; ++kk) {
+        const int r = r0 + kk;
+        if (r >= ye + 2 * N) break;  // wave-uniform
+        const unsigned v = (r < 0 || r >= height) ? neutral1 : ((raw[kk] & inside) | (neutral1 & ~inside));
 #pragma unroll
         for (int k = K - 1; k > 0; --k) ring1[k] = ring1[k - 1];
         ring1[0] = hop_bits<FIRST_OR, N>(v, lane);
@@ -616,6 +634,7 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
                 }
             }
         }
+      }
     }
 }
 
