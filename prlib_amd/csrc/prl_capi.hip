@@ -9,6 +9,9 @@
 #include <map>
 #include <memory>
 #include <vector>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 
 #include "prl_internal.h"
 
@@ -146,10 +149,91 @@ int ensure_stage_pinned(DeviceCtx* ctx, size_t bytes)
     return PRL_OK;
 }
 
-// The copies run in bands of rows so that the CPU's memcpy of one band overlaps the DMA of the previous one.
+// The copies run in bands of rows so that the CPU's memcpy of one band overlaps the DMA of the previous one; the rows
+// of a band are split over a few persistent helper threads (one thread's memcpy moves ~12-15 GB/s, the DMA engine
+// several times that: the host entry was bound by the single-threaded bounce copy).
 namespace {
 constexpr size_t kStageBand = (size_t)2 << 20;  // ~2 MiB per band
 int rows_per_band(size_t row_bytes, int rows) { return (int)std::max<size_t>(1, std::min<size_t>((size_t)rows, kStageBand / std::max<size_t>(row_bytes, 1))); }
+
+class CopyPool {
+public:
+    static CopyPool& get()
+    {
+        static CopyPool* pool = new CopyPool();  // never destroyed: no joins during process teardown
+        return *pool;
+    }
+    // rows [0, n) of `row_bytes` bytes from src (row step src_step) to dst (row step dst_step)
+    void copy_rows(uint8_t* dst, size_t dst_step, const uint8_t* src, size_t src_step, size_t row_bytes, int n)
+    {
+        const int parts = (workers_.empty() || row_bytes * (size_t)n < ((size_t)256 << 10)) ? 1 : (int)workers_.size() + 1;
+        if (parts == 1) {
+            run(dst, dst_step, src, src_step, row_bytes, 0, n);
+            return;
+        }
+        std::unique_lock<std::mutex> call(call_mu_);  // one caller at a time posts jobs
+        const int per = (n + parts - 1) / parts;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (int t = 0; t + 1 < parts; ++t) {
+                Job j{dst, dst_step, src, src_step, row_bytes, std::min(n, (t + 1) * per), std::min(n, (t + 2) * per)};
+                if (j.r0 < j.r1) {
+                    jobs_.push_back(j);
+                    ++pending_;
+                }
+            }
+        }
+        cv_.notify_all();
+        run(dst, dst_step, src, src_step, row_bytes, 0, std::min(n, per));
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+    }
+
+private:
+    struct Job {
+        uint8_t* dst; size_t dst_step; const uint8_t* src; size_t src_step; size_t row_bytes; int r0, r1;
+    };
+    static void run(uint8_t* dst, size_t dst_step, const uint8_t* src, size_t src_step, size_t row_bytes, int r0, int r1)
+    {
+        if (r1 <= r0) return;
+        if (src_step == row_bytes && dst_step == row_bytes) {
+            std::memcpy(dst + (size_t)r0 * row_bytes, src + (size_t)r0 * row_bytes, row_bytes * (size_t)(r1 - r0));
+        } else {
+            for (int y = r0; y < r1; ++y) std::memcpy(dst + (size_t)y * dst_step, src + (size_t)y * src_step, row_bytes);
+        }
+    }
+    CopyPool()
+    {
+        int n = 3;
+        if (const char* e = std::getenv("PRL_HIP_COPY_THREADS")) n = std::max(0, std::min(15, std::atoi(e) - 1));
+        const unsigned hc = std::thread::hardware_concurrency();
+        if (hc > 0 && (unsigned)n + 1 > hc) n = (int)hc - 1;
+        for (int i = 0; i < n; ++i) {
+            workers_.emplace_back([this] {
+                for (;;) {
+                    Job j;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_.wait(lk, [&] { return !jobs_.empty(); });
+                        j = jobs_.back();
+                        jobs_.pop_back();
+                    }
+                    run(j.dst, j.dst_step, j.src, j.src_step, j.row_bytes, j.r0, j.r1);
+                    {
+                        std::lock_guard<std::mutex> lk(mu_);
+                        if (--pending_ == 0) done_.notify_all();
+                    }
+                }
+            });
+            workers_.back().detach();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::vector<Job> jobs_;
+    std::mutex mu_, call_mu_;
+    std::condition_variable cv_, done_;
+    int pending_ = 0;
+};
 }  // namespace
 
 int stage_upload(DeviceCtx* ctx, size_t pin_off, const uint8_t* src, size_t src_step, size_t row_bytes, int rows,
@@ -160,11 +244,7 @@ int stage_upload(DeviceCtx* ctx, size_t pin_off, const uint8_t* src, size_t src_
     for (int y0 = 0; y0 < rows; y0 += band) {
         const int n = std::min(band, rows - y0);
         uint8_t* p = pin + (size_t)y0 * row_bytes;
-        if (src_step == row_bytes) {
-            std::memcpy(p, src + (size_t)y0 * src_step, row_bytes * (size_t)n);
-        } else {
-            for (int y = 0; y < n; ++y) std::memcpy(p + (size_t)y * row_bytes, src + (size_t)(y0 + y) * src_step, row_bytes);
-        }
+        CopyPool::get().copy_rows(p, row_bytes, src + (size_t)y0 * src_step, src_step, row_bytes, n);
         PRL_HIP_CHECK(hipMemcpyAsync(d_dst + (size_t)y0 * row_bytes, p, row_bytes * (size_t)n, hipMemcpyHostToDevice, stream));
     }
     return PRL_OK;
@@ -192,11 +272,7 @@ int stage_download(DeviceCtx* ctx, size_t pin_off, const uint8_t* d_src, size_t 
         const int y0 = k * band, n = std::min(band, rows - y0);
         PRL_HIP_CHECK(hipEventSynchronize(ctx->stage_events[(size_t)k]));
         const uint8_t* p = pin + (size_t)y0 * row_bytes;
-        if (dst_step == row_bytes) {
-            std::memcpy(dst + (size_t)y0 * dst_step, p, row_bytes * (size_t)n);
-        } else {
-            for (int y = 0; y < n; ++y) std::memcpy(dst + (size_t)(y0 + y) * dst_step, p + (size_t)y * row_bytes, row_bytes);
-        }
+        CopyPool::get().copy_rows(dst + (size_t)y0 * dst_step, dst_step, p, row_bytes, row_bytes, n);
     }
     return PRL_OK;
 }
