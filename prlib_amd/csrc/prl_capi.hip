@@ -9,6 +9,7 @@
 #include <map>
 #include <memory>
 #include <vector>
+#include <unistd.h>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -166,7 +167,9 @@ public:
     // rows [0, n) of `row_bytes` bytes from src (row step src_step) to dst (row step dst_step)
     void copy_rows(uint8_t* dst, size_t dst_step, const uint8_t* src, size_t src_step, size_t row_bytes, int n)
     {
-        const int parts = (workers_.empty() || row_bytes * (size_t)n < ((size_t)256 << 10)) ? 1 : (int)workers_.size() + 1;
+        // (after a fork() the child has the pool object but not its threads: copy on the calling thread then)
+        const bool usable = !workers_.empty() && getpid() == owner_pid_;
+        const int parts = (!usable || row_bytes * (size_t)n < ((size_t)256 << 10)) ? 1 : (int)workers_.size() + 1;
         if (parts == 1) {
             run(dst, dst_step, src, src_step, row_bytes, 0, n);
             return;
@@ -204,6 +207,7 @@ private:
     }
     CopyPool()
     {
+        owner_pid_ = getpid();
         int n = 3;
         if (const char* e = std::getenv("PRL_HIP_COPY_THREADS")) n = std::max(0, std::min(15, std::atoi(e) - 1));
         const unsigned hc = std::thread::hardware_concurrency();
@@ -233,6 +237,7 @@ private:
     std::mutex mu_, call_mu_;
     std::condition_variable cv_, done_;
     int pending_ = 0;
+    pid_t owner_pid_ = 0;
 };
 }  // namespace
 
