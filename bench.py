@@ -63,15 +63,19 @@ def cpu_baseline(pages_host, params_oracle, budget_s):
     # pages for roughly budget_s seconds with `cores` threads (assume ~linear up to memory bandwidth)
     n = int(max(cores, min(n_avail, (budget_s / max(t1, 1e-3)) * max(1, cores // 2))))
     n = min(n, n_avail)
-    t0 = time.perf_counter()
-    oc.binarize_batch(pages_host[:n], params_oracle, threads=cores)
-    tn = time.perf_counter() - t0
+    # the sample is passed over as many times as fit the budget (about 10 s of wall time on a many-core host)
+    reps, tn = 0, 0.0
+    while reps == 0 or (tn < min(budget_s, 10.0) and reps < 8):
+        t0 = time.perf_counter()
+        oc.binarize_batch(pages_host[:n], params_oracle, threads=cores)
+        tn += time.perf_counter() - t0
+        reps += 1
     return {
-        "value": round(n * px_page / tn / 1e6, 2),
+        "value": round(reps * n * px_page / tn / 1e6, 2),
         "unit": "Mpixels/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{n} of the benchmark's pages ({w}x{h}), oracle/prl_oracle.c with {cores} OpenMP threads, "
+        "sample": f"{n} of the benchmark's pages ({w}x{h}) x {reps} passes, oracle/prl_oracle.c with {cores} OpenMP threads, "
                   f"{tn:.1f} s; single-thread 1 page: {px_page / t1 / 1e6:.2f} Mpixels/s",
     }
 
