@@ -1191,7 +1191,7 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
 template <int METHOD>
 int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
                  PageGlobals* g, RefItem* rl, WorkItem* wl, WorkItem* cand, CornerAcc* acc, unsigned* cnt,
-                 hipEvent_t ev_start, hipEvent_t ev_stop)
+                 hipEvent_t ev_start, hipEvent_t ev_stop, bool with_fixup)
 {
     if (ev_start) PRL_HIP_CHECK(hipEventRecord(ev_start, stream));
     int st = launch_sweep<METHOD>(sh, stream, src, dst, fp, g, rl, cand, cnt);
@@ -1199,6 +1199,7 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     if (ev_stop) PRL_HIP_CHECK(hipEventRecord(ev_stop, stream));
     hipLaunchKernelGGL((k_refine<METHOD>), dim3(fp.flt ? 1024 : 64), dim3(256), 0, stream, src, dst, fp, g, rl, wl, cnt);
     PRL_HIP_CHECK(hipGetLastError());
+    if (!with_fixup) return PRL_OK;  // the caller runs the literal fix-up (phase 2) only if k_refine left pixels for it
     PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, stream));
     hipLaunchKernelGGL(k_corner_partial, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc);
     PRL_HIP_CHECK(hipGetLastError());
@@ -1361,8 +1362,11 @@ size_t fused_small_bytes(int)
            sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(float) * kSegmaxCap;
 }
 
+// phase 0: the whole pipeline; 1: everything up to and including k_refine; 2: only the literal fix-up of the pixels
+// k_refine queued in an earlier phase-1 call with the same arguments (the caller reads PageGlobals::n_exact in between
+// and skips phase 2 - two launches and a 1 MB memset - when nothing was queued, the usual case)
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst, void* small,
-              PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool bit_out)
+              PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool bit_out, int phase)
 {
     FusedParams fp{};
     fp.tp = tp;
@@ -1421,6 +1425,15 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     auto* cand = wl + kWorkCap;
     auto* acc = reinterpret_cast<CornerAcc*>(cand + kWorkCap);
     fp.segmax = reinterpret_cast<float*>(acc + kWorkCap);
+    if (phase == 2) {
+        PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, stream));
+        hipLaunchKernelGGL(k_corner_partial, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc);
+        PRL_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(k_fixup_final, dim3(16), dim3(256), 0, stream, src, dst, fp, d_globals, wl, acc, cnt);
+        PRL_HIP_CHECK(hipGetLastError());
+        return PRL_OK;
+    }
+    const bool with_fixup = phase == 0;
     PRL_HIP_CHECK(hipMemsetAsync(cnt, 0, 256, stream));
 
     if (tp.method == PRL_FENG) {
@@ -1463,13 +1476,13 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         }
         st = wolf_coeff_run(tp, d_globals, 0, n_pages, stream);
         if (st != PRL_OK) return st;
-        return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop);
+        return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);
     }
     switch (tp.method) {
-    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop);
-    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop);
-    case PRL_NICK: return launch_fused<PRL_NICK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop);
-    case PRL_FENG: return launch_fused<PRL_FENG>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop);
+    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);
+    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);
+    case PRL_NICK: return launch_fused<PRL_NICK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);
+    case PRL_FENG: return launch_fused<PRL_FENG>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);
     default: return PRL_ERR_BAD_ARG;
     }
 }

@@ -477,7 +477,7 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         ev1 = ctx->prof_stop;
     }
     if (use_fused) {
-        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask);
+        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask, 1);
         if (st != PRL_OK) return st;
         // Pages whose fix-up list overflowed (pathological: a large share of their pixels sits within
         // ~1e-6 of the decision boundary) are redone by the literal pipeline.  Knowing that needs the
@@ -489,6 +489,13 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         PRL_HIP_CHECK(hipMemcpyAsync(const_cast<PageGlobals*>(hg), d_globals, sizeof(PageGlobals) * (size_t)n_pages,
                                      hipMemcpyDeviceToHost, stream));
         PRL_HIP_CHECK(hipStreamSynchronize(stream));
+        // literal fix-up of what the float64 interval test left open: launched only when there is something to fix
+        unsigned long long n_open = 0;
+        for (int i = 0; i < n_pages; ++i) n_open += hg[(size_t)i].n_exact;
+        if (n_open > 0) {
+            st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, nullptr, nullptr, bit_mask, 2);
+            if (st != PRL_OK) return st;
+        }
         for (int i = 0; i < n_pages; ++i) {
             if (!hg[(size_t)i].worklist_overflow) continue;
             st = ensure_scratch(ctx, literal_per_page);
