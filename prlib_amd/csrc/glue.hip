@@ -296,11 +296,9 @@ int prl_hip_chain_batch_device(const prl_chain_params* cp, int n_pages, int chan
             st = prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, w, r256(mpx),
                                                (size_t)g.out_w, stream);
             if (st != PRL_OK) return st;
-            st = prl_hip_invert_batch_device(cnt, w, r256(mpx), (size_t)g.out_w, g.out_w, g.out_h, w, r256(mpx), (size_t)g.out_w,
-                                             stream);
-            if (st != PRL_OK) return st;
-            st = prl_hip_thin_batch_device(cp->thin, cnt, w, r256(mpx), (size_t)g.out_w, g.out_w, g.out_h, out, dst_page_stride,
-                                           dst_step, stream);
+            // cv::bitwise_not between the two stages happens inside the thinning's bit packing (no pass of its own)
+            st = prl_hip::thin_batch_device(cp->thin, cnt, w, r256(mpx), (size_t)g.out_w, g.out_w, g.out_h, out, dst_page_stride,
+                                            dst_step, stream, true);
             if (st != PRL_OK) return st;
         }
     }

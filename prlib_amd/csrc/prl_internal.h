@@ -131,6 +131,10 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
               hipEvent_t ev_stop, bool bit_out = false, int phase = 0);
 bool fused_supports(const ThrParams& tp);
 
+// ---- thinning (thin.hip): the C entry plus the option to thin cv::bitwise_not of the source (chain glue) ------
+int thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step, int width,
+                      int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream, bool invert_input);
+
 // ---- morphology (morph.hip) ------------------------------------------------------------------
 int morph_run(int iterations, const PageSet& src, int n_pages, int width, int height,
               const PageSetOut& dst, hipStream_t stream);

@@ -27,8 +27,10 @@ namespace {
 // (W-1)-wide binarizer output are rarely 8-byte aligned, so the thread reads the (up to five) ALIGNED u64 that cover
 // its 32 bytes and funnel-shifts them; an aligned u64 that holds at least one byte of the row never leaves the
 // row's memory page, so the over-read is safe, and bytes past the row end are masked off.
+// flip = 0xffffffff: pack cv::bitwise_not of the source (the chain feeds the binarizer's mask, white = background,
+// into thinning, which thins white: binarizeSauvola -> bitwise_not -> thinZhangSuen without a separate inversion pass)
 __global__ void __launch_bounds__(256) k_thin_pack(PageSet src, int width, int height, int wpr, unsigned* __restrict__ bits,
-                                                  size_t plane_words)
+                                                  size_t plane_words, unsigned flip)
 {
     const int page = blockIdx.y;
     const unsigned gid = blockIdx.x * 256u + threadIdx.x;
@@ -49,6 +51,7 @@ __global__ void __launch_bounds__(256) k_thin_pack(PageSet src, int width, int h
         // bit 0 of each of the 8 bytes -> 8 adjacent bits (byte j lands on bit j)
         w |= (unsigned)(((u & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * i);
     }
+    w ^= flip;
     if (nb < 32) w &= (1u << nb) - 1u;
     bits[(size_t)page * plane_words + gid] = w;
 }
@@ -274,16 +277,26 @@ extern "C" {
 int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step,
                               int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream)
 {
+    return prl_hip::thin_batch_device(method, n_pages, d_src, src_page_stride, src_step, width, height, d_dst, dst_page_stride,
+                                      dst_step, stream, false);
+}
+
+}  // extern "C"
+
+namespace prl_hip {
+int thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step, int width,
+                      int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream, bool invert_input)
+{
     if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;  // "Input image for thinning is empty" (thinZhangSuen.cpp:59-62)
     if (method != PRL_THIN_ZHANGSUEN && method != PRL_THIN_GUOHALL) return PRL_ERR_BAD_ARG;
     if (n_pages < 0 || !d_src || !d_dst || src_step < (size_t)width || dst_step < (size_t)width) return PRL_ERR_BAD_ARG;
     if (n_pages == 0) return PRL_OK;
     if (n_pages > 32768) {  // the page index sits in a grid dimension limited to 65535
         for (int first = 0; first < n_pages; first += 32768) {
-            const int st2 = prl_hip_thin_batch_device(method, std::min(32768, n_pages - first),
-                                                      d_src + (size_t)first * src_page_stride, src_page_stride, src_step, width,
-                                                      height, d_dst + (size_t)first * dst_page_stride, dst_page_stride, dst_step,
-                                                      stream);
+            const int st2 = thin_batch_device(method, std::min(32768, n_pages - first),
+                                              d_src + (size_t)first * src_page_stride, src_page_stride, src_step, width,
+                                              height, d_dst + (size_t)first * dst_page_stride, dst_page_stride, dst_step,
+                                              stream, invert_input);
             if (st2 != PRL_OK) return st2;
         }
         return PRL_OK;
@@ -331,7 +344,7 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
     pd.page_stride = dst_page_stride;
     pd.step = dst_step;
     const dim3 gw((unsigned)((plane_words + 255) / 256), n_pages);  // one thread per 32-pixel word
-    hipLaunchKernelGGL(k_thin_pack, gw, dim3(256), 0, s, ps, width, height, wpr, A, plane_words);
+    hipLaunchKernelGGL(k_thin_pack, gw, dim3(256), 0, s, ps, width, height, wpr, A, plane_words, invert_input ? 0xffffffffu : 0u);
     PRL_HIP_CHECK(hipGetLastError());
 
     st = ensure_pinned(ctx, sizeof(unsigned) * (size_t)n_pages);  // flag readback through pinned memory
@@ -370,6 +383,9 @@ int prl_hip_thin_batch_device(int method, int n_pages, const uint8_t* d_src, siz
     PRL_HIP_CHECK(hipEventRecord(ctx->last_use, s));
     return PRL_OK;
 }
+}  // namespace prl_hip
+
+extern "C" {
 
 int prl_hip_thin_host(int method, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst, size_t dst_step)
 {
