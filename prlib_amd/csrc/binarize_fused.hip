@@ -1377,11 +1377,18 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.uo = ((SW - (tp.w - 1)) / 8) * 8;
     fp.n_strips = (tp.ow + fp.uo - 1) / fp.uo;
     // rows per segment: long segments amortise the (w-1)-row warm-up, short ones fill the chip
-    int rps = 128;  // measured on MI355X (256 x 4K): 128 rows/segment 4.34 ms, 256: 4.46, 512: 4.95, 64: 4.41
-    const long long waves_at = (long long)n_pages * fp.n_strips * ((tp.oh + rps - 1) / rps);
-    if (waves_at < 8192) rps = 128;
-    if ((long long)n_pages * fp.n_strips * ((tp.oh + rps - 1) / rps) < 8192) rps = 64;
-    if (rps < tp.w) rps = ((tp.w + 63) / 64) * 64;
+    // measured on MI355X, 4K pages, w=31: 256 pages - 64..192 rows per segment within 1 %, 256: +1 %, 512: +14 %;
+    // 32 pages - 128: 0.54 ms, 64: 0.48, 32: 0.49, 16: 0.55; 8 pages - 0.168 / 0.125 / 0.127 / 0.131; one page -
+    // 0.120 / 0.066 / 0.044 / 0.031 (a single page has 9 x 32 wavefronts at 128 rows for 5120 wavefront slots)
+    auto waves_at = [&](int r) { return (long long)n_pages * fp.n_strips * ((tp.oh + r - 1) / r); };
+    int rps = 128;
+    if (waves_at(128) < 40000 && tp.w - 1 <= 64) rps = 64;   // (64 A4 pages, w=101: 128 rows 0.78 ms, 64 rows 0.80)
+    {   // small batches: halve while the chip is far from full, but keep the (w-1)-row warm-up (a warm-up row costs
+        // about a quarter of a full one) below ~the segment's own work
+        int min_rps = 16;
+        while (min_rps < (tp.w - 1) / 4) min_rps *= 2;
+        while (rps > min_rps && waves_at(rps) < 4096) rps /= 2;
+    }
     if (const char* e = std::getenv("PRL_HIP_ROWS_PER_SEG")) rps = std::max(16, std::atoi(e));  // tuning knob
     fp.rows_per_seg = rps;
     fp.n_segs = (tp.oh + rps - 1) / rps;
