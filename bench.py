@@ -46,8 +46,29 @@ def parse():
     ap.add_argument("--morph", type=int, default=0)
     ap.add_argument("--mode", default="auto", choices=["auto", "literal"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--check-pages", type=int, default=1, help="pages verified against the oracle after timing")
+    ap.add_argument("--check-pages", type=int, default=8,
+                    help="pages verified against the oracle after timing (spread over the batch: first, last, evenly between)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --pages per GPU; strong: --pages in total, split over the ranks by dist.page_range")
     return ap.parse_args()
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process and hand
+    its exit code back.  Runs before this process has imported torch or touched a GPU (a process that has initialised
+    the GPU must never exec another program; children are fresh processes)."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(pages_host, params_oracle, budget_s):
@@ -82,20 +103,27 @@ def cpu_baseline(pages_host, params_oracle, budget_s):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     import torch
 
     from prlib_amd import dist as pdist
 
     world, rank, local_rank = pdist.init()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if os.environ.get("PRL_BENCH_DRYRUN") == "1":
         # launcher/collective plumbing only (CPU test of the N>1 path): no kernels, no number
-        mine = pdist.page_range(world * args.pages, world, rank)
+        total_pages = args.pages if args.scaling == "strong" else world * args.pages
+        mine = pdist.page_range(total_pages, world, rank)
         pdist.barrier()
         slowest = pdist.max_over_ranks(float(rank + 1))
         total = pdist.sum_over_ranks(float(len(mine)))
         if rank == 0:
             print(json.dumps({"dryrun": True, "n_gpus": world, "pages_total": int(total), "max_rank_plus_1": slowest,
-                              "first_block": [mine.start, mine.stop]}), flush=True)
+                              "first_block": [mine.start, mine.stop], "scaling": args.scaling}), flush=True)
         pdist.finish()
         return
     if not torch.cuda.is_available():
@@ -114,10 +142,15 @@ def main():
 
     # synthetic pages, resident in HBM before the timed region.  The job's page list has
     # world * pages_per_gpu pages (weak scaling); this rank owns a contiguous block of it.
-    mine = pdist.page_range(world * args.pages, world, rank)
+    # (--scaling strong: the list has args.pages pages in all and the ranks split it)
+    total_pages = args.pages if args.scaling == "strong" else world * args.pages
+    mine = pdist.page_range(total_pages, world, rank)
+    n_mine = len(mine)
+    if n_mine == 0:
+        raise SystemExit(f"rank {rank}: no pages to process ({total_pages} pages over {world} ranks)")
     pitch = (W + 255) // 256 * 256
-    pages = synth.pages_torch(len(mine), H, W, dev, seed=1000 + mine.start, pitch=pitch)
-    out, out_pitch = prlib_amd.binarizations.alloc_output(args.pages, g.out_w, g.out_h, dev)
+    pages = synth.pages_torch(n_mine, H, W, dev, seed=1000 + mine.start, pitch=pitch)
+    out, out_pitch = prlib_amd.binarizations.alloc_output(n_mine, g.out_w, g.out_h, dev)
     L = _capi.lib()
 
     def step():
@@ -152,7 +185,7 @@ def main():
     # device-to-device copy of the page batch, bytes read + bytes written over the average of 5 copies
     copy_gbs = None
     if rank == 0:
-        flat = torch.empty(min(args.pages * H * W, 1 << 32), dtype=torch.uint8, device=dev)  # (pages may be a pitched view)
+        flat = torch.empty(min(n_mine * H * W, 1 << 32), dtype=torch.uint8, device=dev)  # (pages may be a pitched view)
         scratch = torch.empty_like(flat)
         scratch.copy_(flat)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -164,33 +197,38 @@ def main():
         copy_gbs = 2 * flat.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del scratch, flat
 
-    px_per_step_rank = args.pages * g.out_w * g.out_h
+    px_per_step_total = total_pages * g.out_w * g.out_h
     bytes_per_px = 3 if method == prlib_amd.WOLFJOLION else 2
-    alg_bytes = args.pages * (H * W * (bytes_per_px - 1) + g.out_w * g.out_h)
+    alg_bytes = n_mine * (H * W * (bytes_per_px - 1) + g.out_w * g.out_h)   # rank 0's launch
     achieved_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
     # parity spot check (outside the timed region): first pages against the CPU oracle
     mismatches = None
+    checked = []
     cpu = None
     if rank == 0:
         from oracle import capi as oc
 
         po = oc.make_params(method, args.window, args.k, args.morph)
-        n_chk = min(args.check_pages, args.pages)
+        n_chk = min(args.check_pages, n_mine)
         if n_chk > 0:
-            host = pages[:n_chk].cpu().numpy()
+            # first, last and evenly spaced pages of this rank's block
+            idx = sorted({round(i * (n_mine - 1) / max(1, n_chk - 1)) for i in range(n_chk)})
+            sel = torch.tensor(idx, device=dev)
+            host = pages.index_select(0, sel).cpu().numpy()
             want = oc.binarize_batch(host.copy(), po, threads=os.cpu_count() or 1)
-            got = out[:n_chk, :, : g.out_w].cpu().numpy()
+            got = out.index_select(0, sel)[:, :, : g.out_w].cpu().numpy()
             mismatches = int((want != got).sum())
+            checked = idx
         if args.cpu_seconds > 0 and world == 1:   # the CPU baseline leg runs at N=1 only
-            n_host = min(args.pages, 64)
+            n_host = min(n_mine, 64)
             cpu = cpu_baseline(pages[:n_host].cpu().numpy().copy(), po, args.cpu_seconds)
 
     if rank == 0:
-        value = world * px_per_step_rank * args.steps / elapsed / 1e6
+        value = px_per_step_total * args.steps / elapsed / 1e6
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        key = f"{args.method}_w{args.window}_{args.pages}x{W}x{H}_{args.mode}"
+        key = f"{args.method}_w{args.window}_{n_mine}x{W}x{H}_{args.mode}"
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(key)
@@ -206,14 +244,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8 in/out; exact integer window sums (u32, f32 below 2^24 in interior strips); f32 decision with f64/literal refinement",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.pages} x {W}x{H} u8 pages per GPU, {args.method} k={args.k} w={args.window} "
-                            f"morph={args.morph}, mode={args.mode}",
-                "pages_per_gpu": args.pages,
+                "workload": f"{args.pages} x {W}x{H} u8 pages {'per GPU' if args.scaling == 'weak' else 'in total'}, "
+                            f"{args.method} k={args.k} w={args.window} morph={args.morph}, mode={args.mode}",
+                "pages_per_gpu": n_mine,
+                "pages_total": total_pages,
                 "parallelism": f"pages sharded over {world} GPU(s), no collectives",
             },
             "roofline": {
@@ -229,7 +268,7 @@ def main():
                 "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
             },
             "cpu_baseline": cpu,
-            "parity": {"checked_pages": min(args.check_pages, args.pages), "mismatching_pixels": mismatches,
+            "parity": {"checked_pages": checked, "mismatching_pixels": mismatches,
                        "refined_pixels": int(stats.refined_pixels), "exact_pixels": int(stats.exact_pixels),
                        "literal_pages": int(stats.literal_pages)},
         }

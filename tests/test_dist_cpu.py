@@ -94,4 +94,35 @@ def test_bench_launcher_path_two_ranks_dryrun():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d == {"dryrun": True, "n_gpus": 2, "pages_total": 10, "max_rank_plus_1": 2.0, "first_block": [0, 5]}
+    assert d == {"dryrun": True, "n_gpus": 2, "pages_total": 10, "max_rank_plus_1": 2.0, "first_block": [0, 5],
+                 "scaling": "weak"}
+
+
+def _run_bench(argv, extra_env=None):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PRL_BENCH_DRYRUN="1", **(extra_env or {}))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True,
+                          timeout=300, env=env, cwd=root)
+
+
+def test_bench_gpus_flag_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (child torch.distributed.run, before
+    anything touches a GPU) - round 1's --gpus was parsed and ignored."""
+    import json
+
+    r = _run_bench(["--gpus", "2", "--pages", "7", "--scaling", "strong"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d == {"dryrun": True, "n_gpus": 2, "pages_total": 7, "max_rank_plus_1": 2.0, "first_block": [0, 4],
+                 "scaling": "strong"}
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    r = _run_bench(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 2" in (r.stdout + r.stderr)
