@@ -257,6 +257,50 @@ int prl_hip_chain_batch_device(const prl_chain_params* params, int n_pages, int 
                                size_t src_page_stride, size_t src_step, int width, int height, uint8_t* d_dst,
                                size_t dst_page_stride, size_t dst_step, void* stream);
 
+/* ---- background normalisation (prl::backgroundNormalization) ------------------------------ */
+
+/*
+ * prl::backgroundNormalization(const cv::Mat&, cv::Mat&) (src/backgroundNormalization.cpp:36-61) =
+ * Leptonica's pixBackgroundNormSimple(pixs, NULL, NULL) between prl::opencvToLeptonica / prl::leptonicaToOpenCV
+ * (src/formatConvert.cpp:38-218): channels 1 -> 1-channel result, 3 or 4 -> 3-channel result (the fourth byte is
+ * dropped by the reference's converter).  d_dst rows hold width * prl_hip_bgnorm_out_channels(channels) bytes.
+ * Enqueues on `stream`, no synchronisation.
+ */
+int prl_hip_bgnorm_out_channels(int channels);
+int prl_hip_bgnorm_batch_device(int n_pages, int channels, const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                                int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream);
+int prl_hip_bgnorm_host(int channels, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst,
+                        size_t dst_step);
+
+/* ---- deskew / rotate (prl::deskew, prl::rotate) ----------------------------------------------- */
+
+/* Size of prl::rotate's result (src/rotate.cpp:35-72): transposed for 90 / 270 degrees, unchanged for 180, else a square
+ * of side max(width, height). */
+int prl_hip_rotate_out_size(int width, int height, double angle, int* out_w, int* out_h);
+
+/* prl::rotate(input, output, angles[i]) per page; d_dst pages need room for the largest result, rows of dst_step bytes.
+ * 1..4 channels.  In place is not allowed. */
+int prl_hip_rotate_batch_device(int n_pages, int channels, const double* angles, const uint8_t* d_src, size_t src_page_stride,
+                                size_t src_step, int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                                void* stream);
+
+/* cv::HoughLinesP(image, lines, 1, CV_PI/180, threshold, line_length, line_gap) on one 1-channel device page, the call
+ * of prl::findAngle (src/deskew/deskew.cpp:148); segments as (x0, y0, x1, y1) into the host array `lines` (4*cap ints),
+ * *n_lines = number found (may exceed cap).  Synchronises. */
+int prl_hip_houghp_device(const uint8_t* d_image, size_t step, int width, int height, int threshold, int line_length,
+                          int line_gap, int32_t* lines, int cap, int* n_lines, void* stream);
+
+/*
+ * prl::deskew (src/deskew/deskew.cpp:208-251) on n_pages device pages of 1, 3 or 4 channels: gray -> Otsu -> findAngle
+ * (HoughLinesP + angle vote) -> prl::rotate.  Page i's result is out_wh[2i] x out_wh[2i+1] pixels (host array):
+ * max(width,height)^2 when an angle was found, width x height otherwise.  d_dst pages need room for max(width,height)
+ * rows of dst_step >= max(width,height) * channels bytes.  angles (host, optional) receives findAngle's degrees.
+ * The orientation step (:238, Leptonica) is a no-op for the page the reference hands it; see DESIGN.md.  Synchronises.
+ */
+int prl_hip_deskew_batch_device(int n_pages, int channels, const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                                int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                                int32_t* out_wh, double* angles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

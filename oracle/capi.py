@@ -107,6 +107,28 @@ def lib() -> C.CDLL:
             L.prl_oracle_denoise.argtypes = [C.c_int, C.c_float, u8p, C.c_size_t, C.c_int, C.c_int,
                                              u8p, C.c_size_t, C.c_int]
         L.prl_oracle_thin.argtypes = [C.c_int, u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_int)]
+        L.prl_oracle_bgnorm_map_size.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.prl_oracle_bgnorm_map_size.restype = None
+        L.prl_oracle_bgnorm_fgmask.argtypes = [C.c_int, u8p, C.c_size_t, C.c_int, C.c_int, u8p]
+        L.prl_oracle_bgnorm_fgmask.restype = None
+        L.prl_oracle_bgnorm_bgmap.argtypes = [C.c_int, C.c_int, u8p, C.c_size_t, C.c_int, C.c_int, u8p, u8p]
+        L.prl_oracle_bgnorm_blockconv.argtypes = [u8p, C.c_int, C.c_int, u8p]
+        L.prl_oracle_bgnorm_blockconv.restype = None
+        L.prl_oracle_bgnorm_invmap.argtypes = [u8p, C.c_int, C.c_int, C.c_void_p]
+        L.prl_oracle_bgnorm.argtypes = [C.c_int, u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t]
+        L.prl_oracle_houghp.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.prl_oracle_vote_angle.argtypes = [C.c_void_p, C.c_int]
+        L.prl_oracle_vote_angle.restype = C.c_double
+        L.prl_oracle_find_angle.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.prl_oracle_find_angle.restype = C.c_double
+        L.prl_oracle_rotate_kind.argtypes = [C.c_double]
+        L.prl_oracle_rotate_size.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.prl_oracle_rotate_size.restype = None
+        L.prl_oracle_rotate_matrix.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double * 6)]
+        L.prl_oracle_rotate_matrix.restype = None
+        L.prl_oracle_rotate.argtypes = [C.c_int, u8p, C.c_size_t, C.c_int, C.c_int, C.c_double, u8p, C.c_size_t]
+        L.prl_oracle_deskew.argtypes = [C.c_int, u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -275,3 +297,129 @@ def thin(img: np.ndarray, method: int = ZHANGSUEN, return_passes: bool = False):
     if st != PRL_OK:
         raise OracleError(st)
     return (out, passes.value) if return_passes else out
+
+
+# ---- background normalisation (prl_oracle_bgnorm.c) ---------------------------------------------
+
+def _as3(img: np.ndarray) -> np.ndarray:
+    a = img if img.ndim == 3 else img[:, :, None]
+    assert a.dtype == np.uint8 and (a.shape[2] == 1 or a.strides[2] == 1) and a.strides[1] == a.shape[2]
+    return a
+
+
+def bgnorm_map_size(width: int, height: int):
+    mw, mh = C.c_int(0), C.c_int(0)
+    lib().prl_oracle_bgnorm_map_size(width, height, C.byref(mw), C.byref(mh))
+    return mw.value, mh.value
+
+
+def bgnorm_fgmask(img: np.ndarray) -> np.ndarray:
+    a = _as3(img)
+    h, w, c = a.shape
+    fg = np.empty((h, w), dtype=np.uint8)
+    lib().prl_oracle_bgnorm_fgmask(c, _ptr(a), a.strides[0], w, h, _ptr(fg))
+    return fg
+
+
+def bgnorm_bgmap(img: np.ndarray, channel: int = 0):
+    """(failed, map) for one channel: tile averages + pixFillMapHoles."""
+    a = _as3(img)
+    h, w, c = a.shape
+    fg = bgnorm_fgmask(img)
+    mw, mh = bgnorm_map_size(w, h)
+    m = np.empty((mh, mw), dtype=np.uint8)
+    failed = lib().prl_oracle_bgnorm_bgmap(c, channel, _ptr(a), a.strides[0], w, h, _ptr(fg), _ptr(m))
+    return bool(failed), m
+
+
+def bgnorm_blockconv(m: np.ndarray) -> np.ndarray:
+    m = np.ascontiguousarray(m)
+    out = np.empty_like(m)
+    lib().prl_oracle_bgnorm_blockconv(_ptr(m), m.shape[1], m.shape[0], _ptr(out))
+    return out
+
+
+def bgnorm_invmap(m: np.ndarray):
+    m = np.ascontiguousarray(m)
+    inv = np.empty(m.shape, dtype=np.uint16)
+    failed = lib().prl_oracle_bgnorm_invmap(_ptr(m), m.shape[1], m.shape[0], _ptr(inv))
+    return bool(failed), inv
+
+
+def bgnorm(img: np.ndarray) -> np.ndarray:
+    """prl::backgroundNormalization: H x W (1 channel) or H x W x {3,4} uint8; 4 channels come back as 3."""
+    a = _as3(img)
+    h, w, c = a.shape
+    och = 1 if c == 1 else 3
+    out = np.empty((h, w, och), dtype=np.uint8)
+    st = lib().prl_oracle_bgnorm(c, _ptr(a), a.strides[0], w, h, _ptr(out), out.strides[0])
+    if st != PRL_OK:
+        raise OracleError(st)
+    return out if img.ndim == 3 else out[:, :, 0]
+
+
+# ---- deskew / rotate (prl_oracle_deskew.c) --------------------------------------------------------
+
+def houghp(img: np.ndarray, threshold: int, line_length: int, line_gap: int) -> np.ndarray:
+    """cv::HoughLinesP(img, lines, 1, CV_PI/180, threshold, line_length, line_gap) -> n x 4 int32."""
+    assert img.dtype == np.uint8 and img.ndim == 2 and img.strides[1] == 1
+    h, w = img.shape
+    cap = 4096
+    while True:
+        lines = np.empty((cap, 4), dtype=np.int32)
+        n = lib().prl_oracle_houghp(_ptr(img), img.strides[0], w, h, threshold, line_length, line_gap, _ptr(lines), cap)
+        if n <= cap:
+            return lines[:n].copy()
+        cap = n
+
+
+def vote_angle(lines: np.ndarray) -> float:
+    lines = np.ascontiguousarray(lines, dtype=np.int32)
+    return float(lib().prl_oracle_vote_angle(_ptr(lines), len(lines)))
+
+
+def find_angle(binary: np.ndarray):
+    assert binary.dtype == np.uint8 and binary.ndim == 2 and binary.strides[1] == 1
+    h, w = binary.shape
+    n = C.c_int(0)
+    ang = lib().prl_oracle_find_angle(_ptr(binary), binary.strides[0], w, h, C.byref(n))
+    return float(ang), n.value
+
+
+def rotate_size(width: int, height: int, angle: float):
+    ow, oh = C.c_int(0), C.c_int(0)
+    lib().prl_oracle_rotate_size(width, height, angle, C.byref(ow), C.byref(oh))
+    return ow.value, oh.value
+
+
+def rotate_matrix(width: int, height: int, angle: float) -> np.ndarray:
+    m = (C.c_double * 6)()
+    lib().prl_oracle_rotate_matrix(width, height, angle, C.byref(m))
+    return np.array(list(m), dtype=np.float64)
+
+
+def rotate(img: np.ndarray, angle: float) -> np.ndarray:
+    a = _as3(img)
+    h, w, c = a.shape
+    ow, oh = rotate_size(w, h, angle)
+    out = np.empty((oh, ow, c), dtype=np.uint8)
+    st = lib().prl_oracle_rotate(c, _ptr(a), a.strides[0], w, h, angle, _ptr(out), out.strides[0])
+    if st != PRL_OK:
+        raise OracleError(st)
+    return out if img.ndim == 3 else out[:, :, 0]
+
+
+def deskew(img: np.ndarray):
+    """prl::deskew -> (image, info) with info = dict(angle, otsu, n_lines)."""
+    a = _as3(img)
+    h, w, c = a.shape
+    ln = max(w, h)
+    buf = np.empty((ln, ln, c), dtype=np.uint8)
+    ow, oh, ang, thr, nl = C.c_int(0), C.c_int(0), C.c_double(0), C.c_int(0), C.c_int(0)
+    st = lib().prl_oracle_deskew(c, _ptr(a), a.strides[0], w, h, _ptr(buf), buf.strides[0], C.byref(ow), C.byref(oh),
+                                 C.byref(ang), C.byref(thr), C.byref(nl))
+    if st != PRL_OK:
+        raise OracleError(st)
+    out = buf[: oh.value, : ow.value].copy()
+    info = dict(angle=ang.value, otsu=thr.value, n_lines=nl.value)
+    return (out if img.ndim == 3 else out[:, :, 0]), info

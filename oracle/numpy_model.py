@@ -153,3 +153,70 @@ def binarize(img: np.ndarray, method: int, window: int, k: float = 0.0, morph_it
     pix = padded[half:half + oh, half:half + ow]
     out = np.where(pix > t8, 255, 0).astype(np.uint8)
     return morph(out, morph_iterations)
+
+
+# ---- backgroundNormalization: an independently written whole-plane model of pixBackgroundNormSimple -------------------
+# (same published algorithm as prl_oracle_bgnorm.c, different code: scipy morphology, reshape/sum tiles, pandas-free
+# forward fill, integral-image box sums in float32 numpy).  Used by tests/test_oracle_stages.py to catch slips in the C.
+
+def bgnorm_model(img: np.ndarray) -> np.ndarray:
+    from scipy import ndimage
+
+    a = img if img.ndim == 3 else img[:, :, None]
+    h, w, c = a.shape
+    och = 1 if c == 1 else 3
+    sx, sy = 10, 15
+    gray = a[:, :, 0 if c == 1 else 1]
+    fg = ndimage.binary_dilation(gray < 60, structure=np.ones((7, 7), bool))  # zero beyond the border
+    mw, mh, nx, ny = -(-w // sx), -(-h // sy), w // sx, h // sy
+    inv = np.zeros((och, mh, mw), np.int64)
+    ok = nx > 0 and ny > 0 and mw >= 5 and mh >= 5
+    for ch in range(och):
+        if not ok:
+            break
+        m = np.zeros((mh, mw), np.int64)
+        keep = ~fg[: ny * sy, : nx * sx]
+        vals = a[: ny * sy, : nx * sx, ch].astype(np.int64) * keep
+        cnt = keep.reshape(ny, sy, nx, sx).sum(axis=(1, 3))
+        sm = vals.reshape(ny, sy, nx, sx).sum(axis=(1, 3))
+        m[:ny, :nx] = np.where(cnt >= 40, sm // np.maximum(cnt, 1), 0)
+        has = (m[:ny, :nx] != 0).any(axis=0)
+        if not has.any():
+            ok = False
+            break
+        for j in np.nonzero(has)[0]:          # column fill: first value upwards, then carry downwards to the last row
+            col = m[:, j]
+            first = np.nonzero(col[:ny])[0][0]
+            col[:first] = col[first]
+            for i in range(1, mh):
+                if col[i] == 0:
+                    col[i] = col[i - 1]
+        good = np.nonzero(has)[0]
+        for j in range(mw):                   # columns without data (incl. the column of incomplete tiles)
+            if j < nx and has[j]:
+                continue
+            left = good[good < j]
+            m[:, j] = m[:, left[-1]] if len(left) else m[:, good[0]]
+        if mw > nx:
+            m[:, mw - 1] = m[:, mw - 2]
+        # blockconv(2, 1): Leptonica's accumulator differences drop row / column 0 from windows clamped at the top / left
+        acc = m.cumsum(0).cumsum(1)
+        ii, jj = np.mgrid[0:mh, 0:mw]
+        imin, imax = np.maximum(ii - 2, 0), np.minimum(ii + 1, mh - 1)
+        jmin, jmax = np.maximum(jj - 3, 0), np.minimum(jj + 2, mw - 1)
+        box = acc[imax, jmax] - acc[imax, jmin] - acc[imin, jmax] + acc[imin, jmin]
+        norm = np.float32(1.0 / (np.float32(5) * np.float32(3)))
+        val = ((norm * box.astype(np.float32)).astype(np.float64) + 0.5).astype(np.int64) & 255
+        hn = np.where(ii <= 1, np.maximum(1, 1 + ii), np.where(ii >= mh - 1, 1 + mh - ii, 0))
+        wn = np.where(jj <= 2, np.maximum(1, 2 + jj), np.where(jj >= mw - 2, 2 + mw - jj, 0))
+        t = val.astype(np.float32)
+        t = np.where(hn > 0, t * (np.float32(3) / np.maximum(hn, 1).astype(np.float32)), t).astype(np.float32)
+        t = np.where(wn > 0, t * (np.float32(5) / np.maximum(wn, 1).astype(np.float32)), t).astype(np.float32)
+        val = np.where((hn > 0) | (wn > 0), np.minimum(t, np.float32(255)).astype(np.int64), val)
+        inv[ch] = np.where(val > 0, 51200 // np.maximum(val, 1), 100)
+    out = a[:, :, :och].copy()
+    if ok:
+        ty, tx = np.arange(h) // sy, np.arange(w) // sx
+        for ch in range(och):
+            out[:, :, ch] = np.minimum(255, (a[:, :, ch].astype(np.int64) * inv[ch][np.ix_(ty, tx)]) >> 8).astype(np.uint8)
+    return out if img.ndim == 3 else out[:, :, 0]

@@ -99,6 +99,33 @@ int prl_oracle_denoise(int channels, float strength, const uint8_t* src, size_t 
 int prl_oracle_thin(int method, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst,
                     size_t dst_step, int* passes_out);
 
+/* ---- backgroundNormalization (src/backgroundNormalization.cpp:36-61; prl_oracle_bgnorm.c) ---- */
+/* channels 1 -> 1-channel result; 3 or 4 -> 3-channel result (src/formatConvert.cpp:111-218). */
+int  prl_oracle_bgnorm_out_channels(int channels);
+void prl_oracle_bgnorm_map_size(int width, int height, int* map_w, int* map_h);
+void prl_oracle_bgnorm_fgmask(int channels, const uint8_t* src, size_t src_step, int width, int height, uint8_t* fg);
+int  prl_oracle_bgnorm_bgmap(int channels, int c, const uint8_t* src, size_t src_step, int width, int height,
+                             const uint8_t* fg, uint8_t* map);
+void prl_oracle_bgnorm_blockconv(const uint8_t* map, int w, int h, uint8_t* out);
+int  prl_oracle_bgnorm_invmap(const uint8_t* map, int w, int h, uint16_t* inv);
+int  prl_oracle_bgnorm(int channels, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst,
+                       size_t dst_step);
+
+/* ---- deskew / rotate (src/deskew/deskew.cpp:139-251, src/rotate.cpp:35-72; prl_oracle_deskew.c) ---- */
+/* cv::HoughLinesP(image, lines, 1, CV_PI/180, threshold, lineLength, lineGap): returns the number of segments found,
+ * the first `cap` of them as (x0, y0, x1, y1). */
+int    prl_oracle_houghp(const uint8_t* image, size_t step, int width, int height, int threshold, int lineLength,
+                         int lineGap, int32_t* lines, int cap);
+double prl_oracle_vote_angle(const int32_t* lines, int nb_lines);
+double prl_oracle_find_angle(const uint8_t* bin, size_t step, int width, int height, int* n_lines_out);
+int    prl_oracle_rotate_kind(double angle);
+void   prl_oracle_rotate_size(int width, int height, double angle, int* out_w, int* out_h);
+void   prl_oracle_rotate_matrix(int width, int height, double angle, double M[6]);
+int    prl_oracle_rotate(int channels, const uint8_t* src, size_t src_step, int width, int height, double angle,
+                         uint8_t* dst, size_t dst_step);
+int    prl_oracle_deskew(int channels, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst,
+                         size_t dst_step, int* out_w, int* out_h, double* angle_out, int* thr_out, int* n_lines_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,8 @@ with the reference's prl::binarize*(cv::Mat&, cv::Mat&, ...) signatures lives in
 from . import _capi, binarizations  # noqa: F401
 from .denoise import denoise, nlm_planes  # noqa: F401
 from .thinning import thinGuoHall, thinZhangSuen  # noqa: F401
+from .background import backgroundNormalization  # noqa: F401
+from .deskew import deskew, houghp, rotate  # noqa: F401
 from .chain import bitwise_not, cvtColorBGR2GRAY, cvtColorGRAY2BGR, process_pages  # noqa: F401
 from .binarizations import (  # noqa: F401
     FENG, NICK, NIBLACK, SAUVOLA, WOLFJOLION, binarize, binarizeFeng, binarizeNICK, binarizeNiblack,
@@ -16,6 +18,6 @@ from .binarizations import (  # noqa: F401
 
 __all__ = [
     "binarize", "binarizeSauvola", "binarizeNiblack", "binarizeWolfJolion", "binarizeNICK", "binarizeFeng",
-    "denoise", "nlm_planes", "thinZhangSuen", "thinGuoHall", "cvtColorBGR2GRAY", "cvtColorGRAY2BGR", "bitwise_not", "process_pages", "make_params", "default_params", "geometry", "last_stats", "morph", "set_exec_mode",
+    "denoise", "nlm_planes", "backgroundNormalization", "deskew", "rotate", "houghp", "thinZhangSuen", "thinGuoHall", "cvtColorBGR2GRAY", "cvtColorGRAY2BGR", "bitwise_not", "process_pages", "make_params", "default_params", "geometry", "last_stats", "morph", "set_exec_mode",
     "SAUVOLA", "NIBLACK", "WOLFJOLION", "NICK", "FENG",
 ]

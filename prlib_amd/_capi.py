@@ -36,6 +36,8 @@ EXPORTED_SYMBOLS = [
     "prl_hip_denoise_host", "prl_hip_thin_batch_device", "prl_hip_thin_host",
     "prl_hip_bgr2gray_batch_device", "prl_hip_gray2bgr_batch_device", "prl_hip_invert_batch_device",
     "prl_hip_default_chain_params", "prl_hip_chain_batch_device",
+    "prl_hip_bgnorm_out_channels", "prl_hip_bgnorm_batch_device", "prl_hip_bgnorm_host",
+    "prl_hip_rotate_out_size", "prl_hip_rotate_batch_device", "prl_hip_houghp_device", "prl_hip_deskew_batch_device",
 ]
 
 
@@ -127,6 +129,13 @@ def lib() -> C.CDLL:
         L.prl_hip_default_chain_params.argtypes = [P(ChainParams)]
         L.prl_hip_default_chain_params.restype = None
         L.prl_hip_chain_batch_device.argtypes = [P(ChainParams), i, i, vp, sz, sz, i, i, vp, sz, sz, vp]
+        L.prl_hip_bgnorm_out_channels.argtypes = [i]
+        L.prl_hip_bgnorm_batch_device.argtypes = [i, i, vp, sz, sz, i, i, vp, sz, sz, vp]
+        L.prl_hip_bgnorm_host.argtypes = [i, vp, sz, i, i, vp, sz]
+        L.prl_hip_rotate_out_size.argtypes = [i, i, C.c_double, P(C.c_int), P(C.c_int)]
+        L.prl_hip_rotate_batch_device.argtypes = [i, i, vp, vp, sz, sz, i, i, vp, sz, sz, vp]
+        L.prl_hip_houghp_device.argtypes = [vp, sz, i, i, i, i, i, vp, i, P(C.c_int), vp]
+        L.prl_hip_deskew_batch_device.argtypes = [i, i, vp, sz, sz, i, i, vp, sz, sz, vp, vp, vp]
         _lib = L
     return _lib
 

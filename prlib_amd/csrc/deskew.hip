@@ -1,0 +1,723 @@
+// deskew.hip — prl::deskew and prl::rotate for pages resident in device memory.
+//
+// Reference: src/deskew/deskew.cpp:208-251 (gray -> Otsu -> findAngle -> rotate), :139-205 (findAngle = bitwise_not,
+// cv::HoughLinesP(1, CV_PI/180, 100, width/8.f, 20), angle vote), src/rotate.cpp:35-72.  OpenCV's arithmetic
+// [upstream] is restated with citations in oracle/prl_oracle_deskew.c; the kernels below reproduce it bit for bit:
+//
+//   k_hist / k_otsu      256-bin histogram (LDS-privatised) and getThreshVal_Otsu_8u's float64 scan, one thread per page
+//   k_dark_mask          mask = (p <= thr) (the bitwise_not of the thresholded page, as 0/1 bytes = HoughLinesP's own
+//                        `mask` matrix) + the number of set pixels per row
+//   k_row_offsets        exclusive scan of the row counts (one workgroup per page) -> where each row's points start
+//   k_collect            HoughLinesP stage 1: the non-zero points in raster order, packed x | y << 16
+//   k_ppht               HoughLinesP stage 2, ONE WAVEFRONT PER PAGE.  The progressive probabilistic Hough transform is
+//                        sequential by construction (every random point votes into the accumulator the previous points
+//                        left, and a detected line erases points and takes their votes back), so a page cannot be split;
+//                        the batch dimension supplies the parallelism (1024 pages = one wavefront per SIMD).  Inside a
+//                        page the 180 angles of a vote are spread over the lanes (3 per lane, `global_atomic_add` with
+//                        return, owner-lane rows), the maximum is a wavefront reduction, and the two line walks test 64
+//                        steps per memory round trip (ballot + scalar run-length scan) instead of one.  cv::RNG's
+//                        multiply-with-carry sequence is reproduced exactly, so the segments - and therefore the angle -
+//                        are those OpenCV finds.  Latency-bound by design: ~3 dependent L2/HBM round trips per point.
+//   host                 atan2 + first-fit clustering of deskew.cpp:158-201 (host libm, as in the reference), matrices of
+//                        getRotationMatrix2D / warpAffine's inversion
+//   k_warp<CH>           warpAffine(INTER_LINEAR, BORDER_CONSTANT 0) between the two bitwise_not of rotate.cpp:61-70: 10-bit
+//                        fixed-point coordinates from float64 (one rounding per operation), 5-bit bilinear weights,
+//                        (sum + 2^14) >> 15.  k_rot90<CH>: the transpose/flip branches (:38-58).
+// findOrientation (deskew.cpp:238, Leptonica pixOrientDetectDwa) is a no-op for the 1-channel page prl::deskew hands it
+// (oracle header); it is not built.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+#include "prl_internal.h"
+
+namespace prl_hip {
+namespace {
+
+constexpr int kNumAngle = 180;
+
+// ---- Otsu --------------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) k_hist(PageSet src, int width, int height, unsigned* __restrict__ hist)
+{
+    __shared__ unsigned h[256];
+    const int page = blockIdx.z, t = threadIdx.x;
+    h[t] = 0;
+    __syncthreads();
+    const uint8_t* base = src.page(page);
+    for (int y = blockIdx.y; y < height; y += gridDim.y) {
+        const uint8_t* row = base + (size_t)y * src.step;
+        for (int x = (blockIdx.x * 256 + t) * 4; x < width; x += gridDim.x * 1024) {
+            const int n = min(4, width - x);
+            for (int i = 0; i < n; ++i) atomicAdd(&h[row[x + i]], 1u);
+        }
+    }
+    __syncthreads();
+    if (h[t]) atomicAdd(&hist[(size_t)page * 256 + t], h[t]);
+}
+
+// getThreshVal_Otsu_8u [upstream]: the float64 sequence of oracle/prl_oracle.c:prl_oracle_otsu, one thread per page.
+__global__ void k_otsu(const unsigned* __restrict__ hist, int width, int height, int n_pages, int* __restrict__ thr)
+{
+    const int page = blockIdx.x * blockDim.x + threadIdx.x;
+    if (page >= n_pages) return;
+    const unsigned* h = hist + (size_t)page * 256;
+    double mu = 0;
+    const double scale = 1. / ((double)width * height);
+    for (int i = 0; i < 256; ++i) mu += i * (double)h[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+    for (int i = 0; i < 256; ++i) {
+        const double p_i = h[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        const double q2 = 1. - q1;
+        if (fmin(q1, q2) < (double)FLT_EPSILON || fmax(q1, q2) > 1. - (double)FLT_EPSILON) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        const double mu2 = (mu - q1 * mu1) / q2;
+        const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) {
+            max_sigma = sigma;
+            max_val = i;
+        }
+    }
+    thr[page] = (int)max_val;
+}
+
+// ---- HoughLinesP stage 1 -------------------------------------------------------------------------------------------
+
+// one wavefront per row: mask byte = (p <= thr), row_count = number of set pixels
+__global__ void __launch_bounds__(64) k_dark_mask(PageSet src, int width, int height, const int* __restrict__ thr,
+                                                  uint8_t* __restrict__ mask, size_t mask_page, unsigned* __restrict__ row_count)
+{
+    const int page = blockIdx.y, y = blockIdx.x, lane = threadIdx.x;
+    const uint8_t* row = src.page(page) + (size_t)y * src.step;
+    uint8_t* m = mask + (size_t)page * mask_page + (size_t)y * width;
+    const int t = thr[page];
+    unsigned cnt = 0;
+    for (int x = lane; x < width; x += 64) {
+        const uint8_t v = row[x] <= t;
+        m[x] = v;
+        cnt += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) row_count[(size_t)page * height + y] = cnt;
+}
+
+// one workgroup per page: row_off[y] = sum of row_count[0..y), count[page] = total
+__global__ void __launch_bounds__(256) k_row_offsets(int height, const unsigned* __restrict__ row_count,
+                                                     unsigned* __restrict__ row_off, unsigned* __restrict__ count)
+{
+    __shared__ unsigned part[256];
+    const int page = blockIdx.x, t = threadIdx.x;
+    const unsigned* rc = row_count + (size_t)page * height;
+    unsigned* ro = row_off + (size_t)page * height;
+    const int per = (height + 255) / 256, y0 = t * per, y1 = min(height, y0 + per);
+    unsigned s = 0;
+    for (int y = y0; y < y1; ++y) s += rc[y];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        unsigned run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const unsigned v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        count[page] = run;
+    }
+    __syncthreads();
+    unsigned run = part[t];
+    for (int y = y0; y < y1; ++y) {
+        ro[y] = run;
+        run += rc[y];
+    }
+}
+
+// one wavefront per row: the row's set pixels, in x order, to nz[nz_off[page] + row_off[y] ...]
+__global__ void __launch_bounds__(64) k_collect(int width, int height, const uint8_t* __restrict__ mask, size_t mask_page,
+                                                const unsigned* __restrict__ row_off, const unsigned long long* __restrict__ nz_off,
+                                                unsigned* __restrict__ nz)
+{
+    const int page = blockIdx.y, y = blockIdx.x, lane = threadIdx.x;
+    const uint8_t* m = mask + (size_t)page * mask_page + (size_t)y * width;
+    unsigned* out = nz + nz_off[page] + row_off[(size_t)page * height + y];
+    unsigned base = 0;
+    for (int x0 = 0; x0 < width; x0 += 64) {
+        const int x = x0 + lane;
+        const bool set = x < width && m[x] != 0;
+        const unsigned long long b = __ballot(set);
+        if (set) out[base + __popcll(b & ((1ull << lane) - 1))] = (unsigned)x | ((unsigned)y << 16);
+        base += __popcll(b);
+    }
+}
+
+// ---- HoughLinesP stage 2 -------------------------------------------------------------------------------------------
+
+struct PphtArgs {
+    int width, height, numrho, threshold, line_length, line_gap;
+    uint8_t* mask; size_t mask_page;
+    unsigned* nz; const unsigned long long* nz_off; const unsigned* count;
+    int* accum;                 // per page kNumAngle * numrho, zeroed
+    const float* ttab;          // kNumAngle x {cos, sin}
+    int* lines; const unsigned long long* lines_off; const unsigned* lines_cap; unsigned* n_lines;
+};
+
+__device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }
+
+__device__ __forceinline__ unsigned uni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Steps [0, ...) of a walk x += dx, y += dy from (x0, y0): pixel of step s.
+__device__ __forceinline__ void step_pixel(int xflag, unsigned x0, unsigned y0, int dx, int dy, unsigned s, int* j1, int* i1)
+{
+    const int x = (int)(x0 + s * (unsigned)dx), y = (int)(y0 + s * (unsigned)dy);  // wraps like the reference's repeated adds
+    if (xflag) { *j1 = x; *i1 = y >> 16; }
+    else { *j1 = x >> 16; *i1 = y; }
+}
+
+__global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
+{
+    const int page = blockIdx.x, lane = threadIdx.x;
+    const int W = a.width, H = a.height, numrho = a.numrho;
+    volatile uint8_t* mask = a.mask + (size_t)page * a.mask_page;
+    volatile unsigned* nz = a.nz + a.nz_off[page];
+    int* accum = a.accum + (size_t)page * kNumAngle * numrho;
+    int* lines = a.lines + a.lines_off[page] * 4;
+    const unsigned cap = a.lines_cap[page];
+    float tc[3], ts[3];
+    int* arow[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int n = min(lane + 64 * q, kNumAngle - 1);
+        tc[q] = a.ttab[2 * n];
+        ts[q] = a.ttab[2 * n + 1];
+        arow[q] = accum + (size_t)n * numrho + (numrho - 1) / 2;
+    }
+    const bool has2 = lane + 128 < kNumAngle;
+    unsigned long long rng = ~0ull;
+    unsigned n_lines = 0;
+    for (unsigned count = a.count[page]; count > 0; --count) {
+        rng = (unsigned long long)(unsigned)rng * 4164903690ull + (rng >> 32);
+        const unsigned idx = uni((unsigned)rng % count);
+        const unsigned pt = nz[idx];
+        const unsigned last = nz[count - 1];
+        if (lane == 0) nz[idx] = last;
+        const int j = (int)(uni(pt) & 0xffffu), i = (int)(uni(pt) >> 16);
+        if (!uni(mask[(size_t)i * W + j])) continue;
+        // vote; key = count << 8 | (255 - angle): the largest count, the first angle among equals
+        unsigned key = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (q < 2 || has2) {
+                const int r = cv_round_f((float)j * tc[q] + (float)i * ts[q]);
+                const int val = atomicAdd(arow[q] + r, 1) + 1;
+                key = max(key, ((unsigned)val << 8) | (unsigned)(255 - (lane + 64 * q)));
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, o));
+        key = uni(key);
+        if ((int)(key >> 8) < a.threshold) continue;
+        const int max_n = 255 - (int)(key & 255u);
+        const float fa = -a.ttab[2 * max_n + 1], fb = a.ttab[2 * max_n];
+        unsigned x0 = (unsigned)j, y0 = (unsigned)i;
+        int dx0, dy0, xflag;
+        if (fabs((double)fa) > fabs((double)fb)) {
+            xflag = 1;
+            dx0 = fa > 0 ? 1 : -1;
+            dy0 = __double2int_rn((double)(fb * 65536.f) / fabs((double)fa));
+            y0 = (y0 << 16) + (1u << 15);
+        } else {
+            xflag = 0;
+            dy0 = fb > 0 ? 1 : -1;
+            dx0 = __double2int_rn((double)(fa * 65536.f) / fabs((double)fb));
+            x0 = (x0 << 16) + (1u << 15);
+        }
+        // first walk, both directions: the step of the last set pixel before the border or a gap above line_gap
+        unsigned end_step[2];
+        for (int k = 0; k < 2; ++k) {
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            unsigned endk = 0;
+            int gap = 0;  // consecutive cleared pixels so far
+            bool stop = false;
+            for (unsigned base = 0; !stop; base += 64) {
+                int j1, i1;
+                step_pixel(xflag, x0, y0, dx, dy, base + lane, &j1, &i1);
+                const bool inb = j1 >= 0 && j1 < W && i1 >= 0 && i1 < H;
+                const bool set = inb && mask[(size_t)i1 * W + j1] != 0;
+                const unsigned long long oob = __ballot(!inb);
+                unsigned long long nzb = __ballot(set);
+                const int limit = oob ? __ffsll((long long)oob) - 1 : 64;  // steps [0, limit) are inside the image
+                int prev = -1 - gap;                                        // position of the last set pixel (virtual)
+                while (nzb) {
+                    const int q = __ffsll((long long)nzb) - 1;
+                    nzb &= nzb - 1;
+                    if (q >= limit || q - prev - 1 > a.line_gap) { stop = true; break; }
+                    endk = base + (unsigned)q;
+                    prev = q;
+                }
+                if (!stop) {
+                    if (limit - 1 - prev > a.line_gap || limit < 64) stop = true;
+                    else gap = 63 - prev;
+                }
+            }
+            end_step[k] = endk;
+        }
+        int ex[2], ey[2];
+        step_pixel(xflag, x0, y0, dx0, dy0, end_step[0], &ex[0], &ey[0]);
+        step_pixel(xflag, x0, y0, -dx0, -dy0, end_step[1], &ex[1], &ey[1]);
+        const bool good_line = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
+        // second walk: clear the set pixels up to the line ends; a good line takes their votes back
+        for (int k = 0; k < 2; ++k) {
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            for (unsigned base = (unsigned)k; base <= end_step[k]; base += 64) {  // (step 0 was cleared by k = 0)
+                const unsigned s = base + lane;
+                int j1, i1;
+                step_pixel(xflag, x0, y0, dx, dy, s, &j1, &i1);
+                bool set = false;
+                if (s <= end_step[k]) {
+                    set = mask[(size_t)i1 * W + j1] != 0;
+                    if (set) mask[(size_t)i1 * W + j1] = 0;
+                }
+                unsigned long long nzb = __ballot(set);
+                if (good_line) {
+                    while (nzb) {
+                        const int q = __ffsll((long long)nzb) - 1;
+                        nzb &= nzb - 1;
+                        int jq, iq;
+                        step_pixel(xflag, x0, y0, dx, dy, base + (unsigned)q, &jq, &iq);
+#pragma unroll
+                        for (int qq = 0; qq < 3; ++qq)
+                            if (qq < 2 || has2) atomicAdd(arow[qq] + cv_round_f((float)jq * tc[qq] + (float)iq * ts[qq]), -1);
+                    }
+                }
+            }
+        }
+        if (good_line) {
+            if (lane == 0 && n_lines < cap) {
+                lines[4 * n_lines] = ex[0];
+                lines[4 * n_lines + 1] = ey[0];
+                lines[4 * n_lines + 2] = ex[1];
+                lines[4 * n_lines + 3] = ey[1];
+            }
+            ++n_lines;
+        }
+    }
+    if (lane == 0) a.n_lines[page] = n_lines;
+}
+
+// ---- rotate --------------------------------------------------------------------------------------------------------
+
+struct WarpPage {
+    double M[6];   // the inverted matrix warpAffine works with
+    int kind;      // 0 warp, 1/2/3 = 90/180/270, 4 = copy (deskew without an angle)
+    int ow, oh;
+};
+
+template <int CH>
+__global__ void __launch_bounds__(256) k_warp(PageSet src, PageSetOut dst, int width, int height, const WarpPage* __restrict__ wp)
+{
+    const int page = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    const WarpPage& p = wp[page];
+    if (x >= p.ow || y >= p.oh) return;
+    const uint8_t* s = src.page(page);
+    uint8_t* d = dst.page(page) + (size_t)y * dst.step + (size_t)x * CH;
+    if (p.kind != 0) {
+        int sx = x, sy = y;
+        if (p.kind == 1) { sx = y; sy = height - 1 - x; }
+        else if (p.kind == 2) { sx = width - 1 - x; sy = height - 1 - y; }
+        else if (p.kind == 3) { sx = width - 1 - y; sy = x; }
+        const uint8_t* q = s + (size_t)sy * src.step + (size_t)sx * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) d[c] = q[c];
+        return;
+    }
+    const int X0 = __double2int_rn((p.M[1] * y + p.M[2]) * 1024) + 16, Y0 = __double2int_rn((p.M[4] * y + p.M[5]) * 1024) + 16;
+    const int X = (X0 + __double2int_rn(p.M[0] * x * 1024)) >> 5, Y = (Y0 + __double2int_rn(p.M[3] * x * 1024)) >> 5;
+    const int sx = max(-32768, min(32767, X >> 5)), sy = max(-32768, min(32767, Y >> 5));
+    const int fx = X & 31, fy = Y & 31;
+    const int w00 = 32 * (32 - fx) * (32 - fy), w01 = 32 * fx * (32 - fy), w10 = 32 * (32 - fx) * fy, w11 = 32 * fx * fy;
+    const bool x0in = sx >= 0 && sx < width, x1in = sx + 1 >= 0 && sx + 1 < width;
+    const bool y0in = sy >= 0 && sy < height, y1in = sy + 1 >= 0 && sy + 1 < height;
+    const uint8_t* r0 = s + (size_t)sy * src.step + (size_t)sx * CH;  // only dereferenced where the flags allow
+    const uint8_t* r1 = r0 + src.step;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        // the source is cv::bitwise_not(input); outside it the border value 0
+        const int v00 = (x0in && y0in) ? 255 - r0[c] : 0, v01 = (x1in && y0in) ? 255 - r0[CH + c] : 0;
+        const int v10 = (x0in && y1in) ? 255 - r1[c] : 0, v11 = (x1in && y1in) ? 255 - r1[CH + c] : 0;
+        d[c] = (uint8_t)(255 - ((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15));
+    }
+}
+
+bool eq_d(double a, double b, double delta) { return std::fabs(a - b) <= delta; }
+
+// rotate.cpp:37-58
+int rotate_kind(double angle)
+{
+    angle = std::fmod(angle, 360.0);
+    if (eq_d(angle, 90.0, 1e-7)) return 1;
+    if (eq_d(angle, 180.0, 1e-7)) return 2;
+    if (eq_d(angle, 270.0, 1e-7)) return 3;
+    return 0;
+}
+
+// getRotationMatrix2D((len/2, len/2), angle, 1.0) then warpAffine's inversion [upstream, see the oracle]
+void rotate_matrix(int width, int height, double angle, double M[6])
+{
+    const int len = std::max(width, height);
+    const float cx = static_cast<float>(len / 2.0), cy = static_cast<float>(len / 2.0);
+    angle = std::fmod(angle, 360.0);
+    angle *= 3.1415926535897932384626433832795 / 180;
+    const double alpha = std::cos(angle) * 1.0, beta = std::sin(angle) * 1.0;
+    M[0] = alpha; M[1] = beta; M[2] = (1 - alpha) * cx - beta * cy;
+    M[3] = -beta; M[4] = alpha; M[5] = beta * cx + (1 - alpha) * cy;
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5];
+    const double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+}
+
+void fill_warp_page(int width, int height, double angle, bool copy, WarpPage* wp)
+{
+    wp->kind = copy ? 4 : rotate_kind(angle);
+    if (wp->kind == 1 || wp->kind == 3) { wp->ow = height; wp->oh = width; }
+    else if (wp->kind == 2 || wp->kind == 4) { wp->ow = width; wp->oh = height; }
+    else { wp->ow = wp->oh = std::max(width, height); rotate_matrix(width, height, angle, wp->M); }
+}
+
+// deskew.cpp:158-201 over the segments of one page
+double vote_angle(const int* lines, int nb_lines)
+{
+    if (!nb_lines) return 0.0;
+    std::vector<std::pair<double, int>> t_diff;
+    const double delta = 0.01;
+    for (int l = 0; l < nb_lines; ++l) {
+        const double ang = std::atan2((double)lines[4 * l + 3] - lines[4 * l + 1], (double)lines[4 * l + 2] - lines[4 * l]);
+        bool found = false;
+        for (auto& e : t_diff)
+            if (eq_d(ang, e.first, delta)) {
+                e.second++;
+                found = true;
+                break;
+            }
+        if (!found) t_diff.emplace_back(ang, 0);
+    }
+    size_t best = 0;
+    for (size_t e = 1; e < t_diff.size(); ++e)
+        if (t_diff[best].second < t_diff[e].second) best = e;
+    return t_diff[best].first * 180 / 3.14159265358979323846;
+}
+
+int launch_warp(int channels, const PageSet& s, const PageSetOut& d, int width, int height, int n_pages, int max_ow, int max_oh,
+                const WarpPage* d_wp, hipStream_t stream)
+{
+    const dim3 grid((unsigned)((max_ow + 255) / 256), (unsigned)max_oh, (unsigned)n_pages);
+    switch (channels) {
+    case 1: hipLaunchKernelGGL(k_warp<1>, grid, dim3(256), 0, stream, s, d, width, height, d_wp); break;
+    case 2: hipLaunchKernelGGL(k_warp<2>, grid, dim3(256), 0, stream, s, d, width, height, d_wp); break;
+    case 3: hipLaunchKernelGGL(k_warp<3>, grid, dim3(256), 0, stream, s, d, width, height, d_wp); break;
+    default: hipLaunchKernelGGL(k_warp<4>, grid, dim3(256), 0, stream, s, d, width, height, d_wp); break;
+    }
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
+size_t r256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+// Segments of cv::HoughLinesP(~binarized, 1, CV_PI/180, threshold, line_length, line_gap) for `n_pages` 1-channel pages
+// whose dark mask (p <= thr[page]) is the non-zero image.  `gray` pages are device resident.  Returns the segments
+// per page in `lines_out` (host).  Synchronises the stream.
+static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int width, int height, int threshold, int line_length,
+                      int line_gap, bool otsu, int fixed_thr, std::vector<std::vector<int>>* lines_out, std::vector<int>* thr_out,
+                      hipStream_t stream)
+{
+    const int numrho = (int)std::lrint((double)(float)((width + height) * 2 + 1));
+    const size_t mask_page = r256((size_t)width * height);
+    // fixed part of the workspace: hist, thr, row counts / offsets, counts, offsets, trig table
+    const size_t b_hist = r256((size_t)n_pages * 256 * 4), b_thr = r256((size_t)n_pages * 4);
+    const size_t b_rows = r256((size_t)n_pages * height * 4), b_cnt = r256((size_t)n_pages * 4), b_off = r256((size_t)n_pages * 8);
+    const size_t b_ttab = r256(kNumAngle * 2 * 4);
+    const size_t b_mask = mask_page * (size_t)n_pages;
+    const size_t b_accum = r256((size_t)n_pages * kNumAngle * numrho * 4);
+    const size_t fixed = b_hist + b_thr + 2 * b_rows + 3 * b_cnt + 2 * b_off + b_ttab + b_mask + b_accum;
+    int st = ensure_scratch(ctx, fixed);
+    if (st != PRL_OK) return st;
+    uint8_t* w = static_cast<uint8_t*>(ctx->scratch);
+    auto take = [&](size_t bytes) { uint8_t* p = w; w += bytes; return p; };
+    unsigned* d_hist = reinterpret_cast<unsigned*>(take(b_hist));
+    int* d_thr = reinterpret_cast<int*>(take(b_thr));
+    unsigned* d_rowcnt = reinterpret_cast<unsigned*>(take(b_rows));
+    unsigned* d_rowoff = reinterpret_cast<unsigned*>(take(b_rows));
+    unsigned* d_count = reinterpret_cast<unsigned*>(take(b_cnt));
+    unsigned* d_nlines = reinterpret_cast<unsigned*>(take(b_cnt));
+    unsigned* d_cap = reinterpret_cast<unsigned*>(take(b_cnt));
+    unsigned long long* d_nzoff = reinterpret_cast<unsigned long long*>(take(b_off));
+    unsigned long long* d_lnoff = reinterpret_cast<unsigned long long*>(take(b_off));
+    float* d_ttab = reinterpret_cast<float*>(take(b_ttab));
+    uint8_t* d_mask = take(b_mask);
+    int* d_accum = reinterpret_cast<int*>(take(b_accum));
+
+    std::vector<int> h_thr((size_t)n_pages, fixed_thr);
+    if (otsu) {
+        PRL_HIP_CHECK(hipMemsetAsync(d_hist, 0, (size_t)n_pages * 256 * 4, stream));
+        const dim3 hg((unsigned)std::min(4, (width + 1023) / 1024), (unsigned)std::min(height, 64), (unsigned)n_pages);
+        hipLaunchKernelGGL(k_hist, hg, dim3(256), 0, stream, gray, width, height, d_hist);
+        hipLaunchKernelGGL(k_otsu, dim3((unsigned)((n_pages + 63) / 64)), dim3(64), 0, stream, d_hist, width, height, n_pages, d_thr);
+        PRL_HIP_CHECK(hipGetLastError());
+    } else {
+        PRL_HIP_CHECK(hipMemcpyAsync(d_thr, h_thr.data(), (size_t)n_pages * 4, hipMemcpyHostToDevice, stream));
+    }
+    hipLaunchKernelGGL(k_dark_mask, dim3((unsigned)height, (unsigned)n_pages), dim3(64), 0, stream, gray, width, height, d_thr, d_mask,
+                       mask_page, d_rowcnt);
+    hipLaunchKernelGGL(k_row_offsets, dim3((unsigned)n_pages), dim3(256), 0, stream, height, d_rowcnt, d_rowoff, d_count);
+    PRL_HIP_CHECK(hipGetLastError());
+    std::vector<unsigned> h_count((size_t)n_pages);
+    PRL_HIP_CHECK(hipMemcpyAsync(h_count.data(), d_count, (size_t)n_pages * 4, hipMemcpyDeviceToHost, stream));
+    if (otsu) PRL_HIP_CHECK(hipMemcpyAsync(h_thr.data(), d_thr, (size_t)n_pages * 4, hipMemcpyDeviceToHost, stream));
+    PRL_HIP_CHECK(hipStreamSynchronize(stream));
+    if (thr_out) *thr_out = h_thr;
+
+    // point lists and segment lists sized from the counts.  A good line clears at least line_length / (line_gap + 1)
+    // points, which bounds the number of segments a page can produce.
+    std::vector<unsigned long long> h_nzoff((size_t)n_pages), h_lnoff((size_t)n_pages);
+    std::vector<unsigned> h_cap((size_t)n_pages);
+    unsigned long long nz_total = 0, ln_total = 0;
+    const unsigned per_line = (unsigned)std::max(1, line_length / (line_gap + 1));
+    for (int i = 0; i < n_pages; ++i) {
+        h_nzoff[(size_t)i] = nz_total;
+        nz_total += (h_count[(size_t)i] + 63) / 64 * 64;
+        h_cap[(size_t)i] = h_count[(size_t)i] / per_line + 16;
+        h_lnoff[(size_t)i] = ln_total;
+        ln_total += h_cap[(size_t)i];
+    }
+    const size_t b_nz = r256(nz_total * 4 + 256), b_lines = r256(ln_total * 16 + 256);
+    st = ensure_mask(ctx, b_nz + b_lines);
+    if (st != PRL_OK) return st;
+    unsigned* d_nz = reinterpret_cast<unsigned*>(ctx->mask);
+    int* d_lines = reinterpret_cast<int*>(static_cast<uint8_t*>(ctx->mask) + b_nz);
+    PRL_HIP_CHECK(hipMemcpyAsync(d_nzoff, h_nzoff.data(), (size_t)n_pages * 8, hipMemcpyHostToDevice, stream));
+    PRL_HIP_CHECK(hipMemcpyAsync(d_lnoff, h_lnoff.data(), (size_t)n_pages * 8, hipMemcpyHostToDevice, stream));
+    PRL_HIP_CHECK(hipMemcpyAsync(d_cap, h_cap.data(), (size_t)n_pages * 4, hipMemcpyHostToDevice, stream));
+    // the trig table of HoughLinesProbabilistic: (float)(cos((double)n * theta) * irho), host libm as in the reference
+    float h_ttab[kNumAngle * 2];
+    const float theta = (float)(3.1415926535897932384626433832795 / 180), irho = 1.f;
+    for (int n = 0; n < kNumAngle; ++n) {
+        h_ttab[2 * n] = (float)(std::cos((double)n * theta) * irho);
+        h_ttab[2 * n + 1] = (float)(std::sin((double)n * theta) * irho);
+    }
+    PRL_HIP_CHECK(hipMemcpyAsync(d_ttab, h_ttab, sizeof(h_ttab), hipMemcpyHostToDevice, stream));
+    PRL_HIP_CHECK(hipMemsetAsync(d_accum, 0, (size_t)n_pages * kNumAngle * numrho * 4, stream));
+    hipLaunchKernelGGL(k_collect, dim3((unsigned)height, (unsigned)n_pages), dim3(64), 0, stream, width, height, d_mask, mask_page,
+                       d_rowoff, d_nzoff, d_nz);
+    PphtArgs a{};
+    a.width = width; a.height = height; a.numrho = numrho; a.threshold = threshold; a.line_length = line_length; a.line_gap = line_gap;
+    a.mask = d_mask; a.mask_page = mask_page; a.nz = d_nz; a.nz_off = d_nzoff; a.count = d_count; a.accum = d_accum; a.ttab = d_ttab;
+    a.lines = d_lines; a.lines_off = d_lnoff; a.lines_cap = d_cap; a.n_lines = d_nlines;
+    hipLaunchKernelGGL(k_ppht, dim3((unsigned)n_pages), dim3(64), 0, stream, a);
+    PRL_HIP_CHECK(hipGetLastError());
+    std::vector<unsigned> h_nl((size_t)n_pages);
+    std::vector<int> h_lines((size_t)ln_total * 4 + 4);
+    PRL_HIP_CHECK(hipMemcpyAsync(h_nl.data(), d_nlines, (size_t)n_pages * 4, hipMemcpyDeviceToHost, stream));
+    PRL_HIP_CHECK(hipMemcpyAsync(h_lines.data(), d_lines, (size_t)ln_total * 16, hipMemcpyDeviceToHost, stream));
+    PRL_HIP_CHECK(hipStreamSynchronize(stream));
+    lines_out->assign((size_t)n_pages, {});
+    for (int i = 0; i < n_pages; ++i) {
+        if (h_nl[(size_t)i] > h_cap[(size_t)i]) {
+            set_error_detail("HoughLinesP: segment list overflow");
+            return PRL_ERR_NOMEM;
+        }
+        const int* p = h_lines.data() + h_lnoff[(size_t)i] * 4;
+        (*lines_out)[(size_t)i].assign(p, p + (size_t)h_nl[(size_t)i] * 4);
+    }
+    return PRL_OK;
+}
+
+static size_t ppht_bytes_per_page(int width, int height)
+{
+    const size_t numrho = (size_t)(width + height) * 2 + 1;
+    return r256((size_t)width * height) + kNumAngle * numrho * 4 + (size_t)height * 8 + 2048 + (size_t)width * height / 2;
+}
+
+}  // namespace prl_hip
+
+using namespace prl_hip;
+
+extern "C" {
+
+int prl_hip_rotate_out_size(int width, int height, double angle, int* out_w, int* out_h)
+{
+    if (!out_w || !out_h) return PRL_ERR_BAD_ARG;
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    WarpPage wp{};
+    fill_warp_page(width, height, angle, false, &wp);
+    *out_w = wp.ow;
+    *out_h = wp.oh;
+    return PRL_OK;
+}
+
+// prl::rotate on device pages, one angle per page (angles == NULL: not allowed).
+int prl_hip_rotate_batch_device(int n_pages, int channels, const double* angles, const uint8_t* d_src, size_t src_page_stride,
+                                size_t src_step, int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                                void* stream)
+{
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    if (channels < 1 || channels > 4) return PRL_ERR_BAD_CHANNELS;
+    if (n_pages < 0 || !angles || !d_src || !d_dst || d_src == d_dst || src_step < (size_t)width * channels) return PRL_ERR_BAD_ARG;
+    if (std::max(width, height) > 32767) return PRL_ERR_BAD_ARG;
+    if (n_pages == 0) return PRL_OK;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const int chunk = std::min(n_pages, 32768);
+    st = ensure_small(ctx, sizeof(WarpPage) * (size_t)chunk);
+    if (st != PRL_OK) return st;
+    ctx->lut_small[0] = ctx->lut_small[1] = nullptr;
+    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(hs, ctx->last_use, 0));
+    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+    std::vector<WarpPage> wp((size_t)chunk);
+    for (int first = 0; first < n_pages; first += chunk) {
+        const int cnt = std::min(chunk, n_pages - first);
+        int max_ow = 0, max_oh = 0;
+        for (int i = 0; i < cnt; ++i) {
+            fill_warp_page(width, height, angles[first + i], false, &wp[(size_t)i]);
+            max_ow = std::max(max_ow, wp[(size_t)i].ow);
+            max_oh = std::max(max_oh, wp[(size_t)i].oh);
+            if (dst_step < (size_t)wp[(size_t)i].ow * channels) return PRL_ERR_BAD_ARG;
+        }
+        PRL_HIP_CHECK(hipMemcpyAsync(ctx->small, wp.data(), sizeof(WarpPage) * (size_t)cnt, hipMemcpyHostToDevice, hs));
+        PRL_HIP_CHECK(hipStreamSynchronize(hs));  // `wp` is pageable host memory reused by the next chunk
+        PageSet s{};
+        s.base = d_src + (size_t)first * src_page_stride; s.page_stride = src_page_stride; s.step = src_step;
+        PageSetOut d{};
+        d.base = d_dst + (size_t)first * dst_page_stride; d.page_stride = dst_page_stride; d.step = dst_step;
+        st = launch_warp(channels, s, d, width, height, cnt, max_ow, max_oh, static_cast<const WarpPage*>(ctx->small), hs);
+        if (st != PRL_OK) return st;
+    }
+    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, hs));
+    return PRL_OK;
+}
+
+// cv::HoughLinesP(image, lines, 1, CV_PI/180, threshold, line_length, line_gap) on ONE 1-channel device page whose
+// non-zero pixels are the points (test / building-block entry).  lines: host buffer of 4*cap ints; *n_lines = segments found.
+int prl_hip_houghp_device(const uint8_t* d_image, size_t step, int width, int height, int threshold, int line_length, int line_gap,
+                          int32_t* lines, int cap, int* n_lines, void* stream)
+{
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    if (!d_image || !n_lines || (cap > 0 && !lines) || step < (size_t)width || std::max(width, height) > 32767) return PRL_ERR_BAD_ARG;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> slk(ctx->stage_mu);  // lock order: stage_mu, then mu
+    // HoughLinesP's points are the NON-ZERO pixels; the point stage selects "p <= thr", so it runs on the complement:
+    // p != 0  <=>  (255 - p) <= 254
+    const size_t bytes = (size_t)width * height;
+    st = ensure_stage(ctx, bytes);
+    if (st != PRL_OK) return st;
+    st = prl_hip_invert_batch_device(1, d_image, 0, step, width, height, static_cast<uint8_t*>(ctx->stage), bytes, (size_t)width, stream);
+    if (st != PRL_OK) return st;
+    PageSet g{};
+    g.base = static_cast<uint8_t*>(ctx->stage); g.page_stride = 0; g.step = (size_t)width;
+    std::vector<std::vector<int>> out;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(hs, ctx->last_use, 0));
+    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+    st = ppht_pages(ctx, 1, g, width, height, threshold, line_length, line_gap, false, 254, &out, nullptr, hs);
+    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, hs));
+    if (st != PRL_OK) return st;
+    *n_lines = (int)(out[0].size() / 4);
+    for (int i = 0; i < std::min(cap, *n_lines) * 4; ++i) lines[i] = out[0][(size_t)i];
+    return PRL_OK;
+}
+
+/*
+ * prl::deskew on n_pages device pages (channels 1, 3 or 4).  Every page's result has its own size: len x len
+ * (len = max(width, height)) when an angle was found, width x height otherwise (and transposed / same size for exactly
+ * +-90 / 180 degrees); out_wh (host, 2 ints per page) receives it, angles (host, optional) findAngle's result in degrees.
+ * d_dst pages must have room for len rows of dst_step >= len * channels bytes.  Synchronises the stream.
+ */
+int prl_hip_deskew_batch_device(int n_pages, int channels, const uint8_t* d_src, size_t src_page_stride, size_t src_step,
+                                int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                                int32_t* out_wh, double* angles, void* stream)
+{
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;  // CV_Assert(!inputImage.empty()), deskew.cpp:210
+    if (channels != 1 && channels != 3 && channels != 4) return PRL_ERR_BAD_CHANNELS;
+    const int len = std::max(width, height);
+    if (n_pages < 0 || !d_src || !d_dst || d_src == d_dst || !out_wh || src_step < (size_t)width * channels ||
+        dst_step < (size_t)len * channels || len > 32767)
+        return PRL_ERR_BAD_ARG;
+    if (n_pages == 0) return PRL_OK;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> slk(ctx->stage_mu);  // gray pages live in the staging area
+    // pages per pass: bounded by a workspace budget (mask + accumulator + lists per page)
+    size_t budget = (size_t)24 << 30;
+    if (const char* e = std::getenv("PRL_HIP_DESKEW_WORK_MB")) budget = (size_t)std::max(64ll, std::atoll(e)) << 20;
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n_pages, (size_t)16384, budget / ppht_bytes_per_page(width, height)}));
+    const size_t gray_page = r256((size_t)width * height);
+    if (channels != 1) {
+        st = ensure_stage(ctx, gray_page * (size_t)chunk);
+        if (st != PRL_OK) return st;
+    }
+    std::vector<WarpPage> wp((size_t)chunk);
+    for (int first = 0; first < n_pages; first += chunk) {
+        const int cnt = std::min(chunk, n_pages - first);
+        const uint8_t* src = d_src + (size_t)first * src_page_stride;
+        PageSet g{};
+        if (channels != 1) {  // deskew.cpp:214-217
+            st = prl_hip_bgr2gray_batch_device(cnt, channels, src, src_page_stride, src_step, width, height,
+                                               static_cast<uint8_t*>(ctx->stage), gray_page, (size_t)width, stream);
+            if (st != PRL_OK) return st;
+            g.base = static_cast<uint8_t*>(ctx->stage); g.page_stride = gray_page; g.step = (size_t)width;
+        } else {
+            g.base = src; g.page_stride = src_page_stride; g.step = src_step;
+        }
+        std::vector<std::vector<int>> lines;
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(hs, ctx->last_use, 0));
+        else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+        // cv::threshold(..., THRESH_BINARY | THRESH_OTSU) (:224) + findAngle's bitwise_not (:146): points = (p <= otsu)
+        st = ppht_pages(ctx, cnt, g, width, height, 100, (int)std::lrint((double)(width / 8.f)), (int)std::lrint(20.0), true, 0,
+                        &lines, nullptr, hs);
+        if (st != PRL_OK) return st;
+        int max_ow = 0, max_oh = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const double angle = vote_angle(lines[(size_t)i].data(), (int)(lines[(size_t)i].size() / 4));
+            if (angles) angles[first + i] = angle;
+            const bool rot = (angle != 0) && (angle <= DBL_MAX && angle >= -DBL_MAX);  // deskew.cpp:228
+            fill_warp_page(width, height, angle, !rot, &wp[(size_t)i]);
+            out_wh[2 * (first + i)] = wp[(size_t)i].ow;
+            out_wh[2 * (first + i) + 1] = wp[(size_t)i].oh;
+            max_ow = std::max(max_ow, wp[(size_t)i].ow);
+            max_oh = std::max(max_oh, wp[(size_t)i].oh);
+        }
+        st = ensure_small(ctx, sizeof(WarpPage) * (size_t)cnt);
+        if (st != PRL_OK) return st;
+        ctx->lut_small[0] = ctx->lut_small[1] = nullptr;
+        PRL_HIP_CHECK(hipMemcpyAsync(ctx->small, wp.data(), sizeof(WarpPage) * (size_t)cnt, hipMemcpyHostToDevice, hs));
+        PRL_HIP_CHECK(hipStreamSynchronize(hs));
+        PageSet s{};
+        s.base = src; s.page_stride = src_page_stride; s.step = src_step;
+        PageSetOut d{};
+        d.base = d_dst + (size_t)first * dst_page_stride; d.page_stride = dst_page_stride; d.step = dst_step;
+        st = launch_warp(channels, s, d, width, height, cnt, max_ow, max_oh, static_cast<const WarpPage*>(ctx->small), hs);
+        if (st != PRL_OK) return st;
+        PRL_HIP_CHECK(hipEventRecord(ctx->last_use, hs));
+    }
+    return PRL_OK;
+}
+
+}  // extern "C"

@@ -52,3 +52,32 @@ def pages_torch(n_pages: int, height: int, width: int, device, seed: int = 1000,
         page = (page - dark).round_().clamp_(0, 255)
         buf[i, :, :width] = page.to(torch.uint8)
     return buf[:, :, :width]
+
+
+def text_page_numpy(height: int, width: int, index: int = 0, skew_deg: float = 0.0, shading: float = 0.0) -> np.ndarray:
+    """A page of "text lines" (rows of word-like dark runs) drawn at `skew_deg`, on paper whose brightness falls off by
+    `shading` (0..1) towards one corner - the input deskew and backgroundNormalization are written for.  Seeded."""
+    rng = np.random.Generator(np.random.PCG64(5000 + index))
+    a = np.deg2rad(skew_deg)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    u = xx * np.cos(a) + yy * np.sin(a)
+    v = -xx * np.sin(a) + yy * np.cos(a)
+    pitch, line_h = 34.0, 9.0
+    margin = 0.06 * min(height, width)
+    span = int(np.hypot(height, width)) + 64
+    # word pattern along a line: 1 = ink; words of 20-90 px separated by 10-22 px, different on every line
+    n_lines = int(np.hypot(height, width) // pitch) + 4
+    pat = np.zeros((2 * n_lines, 2 * span), dtype=bool)
+    for ln in range(2 * n_lines):
+        x = int(rng.integers(0, 30))
+        while x < 2 * span:
+            wl = int(rng.integers(20, 90))
+            pat[ln, x:x + wl] = True
+            x += wl + int(rng.integers(10, 22))
+    li = np.floor(v / pitch).astype(np.int64)
+    inside = (np.mod(v, pitch) < line_h) & (xx > margin) & (xx < width - margin) & (yy > margin) & (yy < height - margin)
+    ink = inside & pat[np.clip(li + n_lines, 0, 2 * n_lines - 1), np.clip(u.astype(np.int64) + span, 0, 2 * span - 1)]
+    paper = rng.normal(225.0, 6.0, size=(height, width))
+    light = 1.0 - shading * (0.6 * xx / max(1, width - 1) + 0.4 * yy / max(1, height - 1))
+    page = np.where(ink, rng.normal(45.0, 10.0, size=(height, width)), paper) * light
+    return np.clip(np.rint(page), 0, 255).astype(np.uint8)

@@ -1,0 +1,90 @@
+"""GPU parity of prl::deskew / prl::rotate / HoughLinesP against the CPU oracle: the segments,
+the angle and every output byte are identical."""
+import numpy as np
+import pytest
+
+from prlib_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_houghp_segments_equal_oracle(prl, oracle, cuda_device):
+    import torch
+
+    img = np.zeros((200, 300), np.uint8)
+    img[50, 20:280] = 255
+    img[20:190, 150] = 255
+    rng = np.random.default_rng(1)
+    img[rng.integers(0, 200, 900), rng.integers(0, 300, 900)] = 128       # clutter: any non-zero value is a point
+    for thr, ll, gap in ((100, 100, 5), (60, 40, 3), (1000, 10, 2)):
+        got = prl.houghp(torch.from_numpy(img).to(cuda_device), thr, ll, gap)
+        want = oracle.houghp(img, thr, ll, gap)
+        assert np.array_equal(got, want), (thr, ll, gap, len(got), len(want))
+    # a text page the way findAngle sees it
+    p = synth.text_page_numpy(300, 420, 5, skew_deg=2.0)
+    thr, binary = oracle.otsu(p)
+    inv = 255 - binary
+    got = prl.houghp(torch.from_numpy(inv).to(cuda_device), 100, 52, 20)
+    want = oracle.houghp(inv, 100, 52, 20)
+    assert len(want) > 20 and np.array_equal(got, want)
+    assert len(prl.houghp(torch.zeros((40, 50), dtype=torch.uint8, device=cuda_device), 10, 10, 2)) == 0
+
+
+@pytest.mark.parametrize("c", [1, 3, 4])
+@pytest.mark.parametrize("angle", [0.0, 3.0, -7.25, 45.0, 90.0, 180.0, 270.0, 450.0, 359.999, 1e-9, 123.456])
+def test_rotate_matches_oracle(prl, oracle, cuda_device, c, angle):
+    import torch
+
+    rng = np.random.default_rng(int(abs(angle) * 10) + c)
+    g = synth.text_page_numpy(97, 141, 2, skew_deg=1.0)
+    img = g if c == 1 else np.stack([g] + [rng.integers(0, 256, g.shape, dtype=np.uint8) for _ in range(c - 1)], axis=-1)
+    t = torch.from_numpy(np.stack([img, img[::-1].copy()])).to(cuda_device)
+    outs = prl.rotate(t, angle)
+    for i, src in enumerate((img, img[::-1].copy())):
+        want = oracle.rotate(src, angle)
+        got = outs[i].cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), f"{(got != want).sum()} bytes differ"
+
+
+def test_rotate_tall_page_and_per_page_angles(prl, oracle, cuda_device):
+    import torch
+
+    g = synth.text_page_numpy(180, 75, 4)
+    t = torch.from_numpy(np.stack([g, g, g])).to(cuda_device)
+    angles = [2.0, 90.0, -33.0]
+    outs = prl.rotate(t, angles)
+    for i, a in enumerate(angles):
+        assert np.array_equal(outs[i].cpu().numpy(), oracle.rotate(g, a))
+
+
+@pytest.mark.parametrize("c", [1, 3])
+def test_deskew_matches_oracle(prl, oracle, cuda_device, c):
+    import torch
+
+    pages = []
+    for i, skew in enumerate((2.5, -4.0, 0.0, 1.0)):
+        g = synth.text_page_numpy(390, 300, 20 + i, skew_deg=skew, shading=0.2)
+        pages.append(g if c == 1 else np.stack([g, np.clip(g.astype(int) + 8, 0, 255).astype(np.uint8), g], axis=-1))
+    blank = np.full_like(pages[0], 230)          # no segments -> angle 0 -> clone
+    pages.append(blank)
+    batch = np.stack(pages)
+    outs, angles = prl.deskew(torch.from_numpy(batch).to(cuda_device))
+    for i in range(len(pages)):
+        want, info = oracle.deskew(batch[i])
+        assert angles[i] == info["angle"], (i, angles[i], info)
+        got = outs[i].cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), f"page {i}: {(got != want).sum()} bytes differ"
+    assert angles[-1] == 0.0 and outs[-1].shape[:2] == (390, 300)
+
+
+def test_deskew_argument_errors(prl, cuda_device):
+    import torch
+
+    from prlib_amd import _capi
+    L = _capi.lib()
+    t = torch.zeros((64, 64), dtype=torch.uint8, device=cuda_device)
+    o = torch.zeros((64, 64), dtype=torch.uint8, device=cuda_device)
+    wh = np.zeros(2, np.int32)
+    assert L.prl_hip_deskew_batch_device(1, 1, t.data_ptr(), 4096, 64, 0, 64, o.data_ptr(), 4096, 64, wh.ctypes.data, None, None) == _capi.PRL_ERR_EMPTY
+    assert L.prl_hip_deskew_batch_device(1, 2, t.data_ptr(), 4096, 128, 64, 64, o.data_ptr(), 4096, 128, wh.ctypes.data, None, None) == _capi.PRL_ERR_BAD_CHANNELS
+    assert L.prl_hip_deskew_batch_device(1, 1, t.data_ptr(), 4096, 64, 64, 64, o.data_ptr(), 4096, 32, wh.ctypes.data, None, None) == _capi.PRL_ERR_BAD_ARG
