@@ -301,6 +301,14 @@ int prl_hip_deskew_batch_device(int n_pages, int channels, const uint8_t* d_src,
                                 int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
                                 int32_t* out_wh, double* angles, void* stream);
 
+/* Host-image forms of the two (what the cv::Mat wrappers call): prl_hip_rotate_host's dst holds the size
+ * prl_hip_rotate_out_size reports; prl_hip_deskew_host's dst has room for max(width,height)^2 pixels and *out_w x *out_h
+ * tells which part was written. */
+int prl_hip_rotate_host(int channels, double angle, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst,
+                        size_t dst_step);
+int prl_hip_deskew_host(int channels, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst, size_t dst_step,
+                        int* out_w, int* out_h, double* angle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "prl_hip_default_chain_params", "prl_hip_chain_batch_device",
     "prl_hip_bgnorm_out_channels", "prl_hip_bgnorm_batch_device", "prl_hip_bgnorm_host",
     "prl_hip_rotate_out_size", "prl_hip_rotate_batch_device", "prl_hip_houghp_device", "prl_hip_deskew_batch_device",
+    "prl_hip_rotate_host", "prl_hip_deskew_host",
 ]
 
 
@@ -136,6 +137,8 @@ def lib() -> C.CDLL:
         L.prl_hip_rotate_batch_device.argtypes = [i, i, vp, vp, sz, sz, i, i, vp, sz, sz, vp]
         L.prl_hip_houghp_device.argtypes = [vp, sz, i, i, i, i, i, vp, i, P(C.c_int), vp]
         L.prl_hip_deskew_batch_device.argtypes = [i, i, vp, sz, sz, i, i, vp, sz, sz, vp, vp, vp]
+        L.prl_hip_rotate_host.argtypes = [i, C.c_double, vp, sz, i, i, vp, sz]
+        L.prl_hip_deskew_host.argtypes = [i, vp, sz, i, i, vp, sz, P(C.c_int), P(C.c_int), P(C.c_double)]
         _lib = L
     return _lib
 

@@ -27,7 +27,9 @@
 // (oracle header); it is not built.
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
+#include <cstdio>
 #include <vector>
 
 #include "prl_internal.h"
@@ -162,6 +164,9 @@ struct PphtArgs {
     int* accum;                 // per page kNumAngle * numrho, zeroed
     const float* ttab;          // kNumAngle x {cos, sin}
     int* lines; const unsigned long long* lines_off; const unsigned* lines_cap; unsigned* n_lines;
+#ifdef PRL_PPHT_TRACE
+    int* trace;  // 8 ints per trigger of page 0: j, i, max_n, max_val, end0, end1, good, count
+#endif
 };
 
 __device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }
@@ -205,20 +210,21 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
         if (lane == 0) nz[idx] = last;
         const int j = (int)(uni(pt) & 0xffffu), i = (int)(uni(pt) >> 16);
         if (!uni(mask[(size_t)i * W + j])) continue;
-        // vote; key = count << 8 | (255 - angle): the largest count, the first angle among equals
-        unsigned key = 0;
+        // vote; key = count * 256 + (255 - angle), signed: the largest count, the first angle among equals.  Counts can be
+        // negative (a good line takes back the votes of points that have not voted yet, as in the reference).
+        int key = INT_MIN;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             if (q < 2 || has2) {
                 const int r = cv_round_f((float)j * tc[q] + (float)i * ts[q]);
                 const int val = atomicAdd(arow[q] + r, 1) + 1;
-                key = max(key, ((unsigned)val << 8) | (unsigned)(255 - (lane + 64 * q)));
+                key = max(key, val * 256 + (255 - (lane + 64 * q)));
             }
         }
-        for (int o = 32; o > 0; o >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, o));
-        key = uni(key);
-        if ((int)(key >> 8) < a.threshold) continue;
-        const int max_n = 255 - (int)(key & 255u);
+        for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o));
+        key = (int)uni((unsigned)key);
+        if ((key >> 8) < a.threshold) continue;
+        const int max_n = 255 - (key & 255);
         const float fa = -a.ttab[2 * max_n + 1], fb = a.ttab[2 * max_n];
         unsigned x0 = (unsigned)j, y0 = (unsigned)i;
         int dx0, dy0, xflag;
@@ -267,6 +273,14 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
         step_pixel(xflag, x0, y0, dx0, dy0, end_step[0], &ex[0], &ey[0]);
         step_pixel(xflag, x0, y0, -dx0, -dy0, end_step[1], &ex[1], &ey[1]);
         const bool good_line = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
+#ifdef PRL_PPHT_TRACE
+        if (lane == 0 && page == 0 && a.trace[0] < 4000) {
+            int* t = a.trace + 8 + 8 * a.trace[0];
+            t[0] = j; t[1] = i; t[2] = max_n; t[3] = (int)(key >> 8); t[4] = (int)end_step[0]; t[5] = (int)end_step[1];
+            t[6] = good_line; t[7] = (int)count;
+            a.trace[0] += 1;
+        }
+#endif
         // second walk: clear the set pixels up to the line ends; a good line takes their votes back
         for (int k = 0; k < 2; ++k) {
             const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
@@ -519,7 +533,23 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     a.width = width; a.height = height; a.numrho = numrho; a.threshold = threshold; a.line_length = line_length; a.line_gap = line_gap;
     a.mask = d_mask; a.mask_page = mask_page; a.nz = d_nz; a.nz_off = d_nzoff; a.count = d_count; a.accum = d_accum; a.ttab = d_ttab;
     a.lines = d_lines; a.lines_off = d_lnoff; a.lines_cap = d_cap; a.n_lines = d_nlines;
+#ifdef PRL_PPHT_TRACE
+    static int* d_trace = nullptr;
+    if (!d_trace) PRL_HIP_CHECK(hipMalloc(&d_trace, 4 * 8 * 4002));
+    PRL_HIP_CHECK(hipMemsetAsync(d_trace, 0, 4 * 8 * 4002, stream));
+    a.trace = d_trace;
+#endif
     hipLaunchKernelGGL(k_ppht, dim3((unsigned)n_pages), dim3(64), 0, stream, a);
+#ifdef PRL_PPHT_TRACE
+    {
+        std::vector<int> tr(8 * 4002);
+        PRL_HIP_CHECK(hipMemcpy(tr.data(), d_trace, 4 * 8 * 4002, hipMemcpyDeviceToHost));
+        for (int t = 0; t < tr[0] && t < 60; ++t) {
+            const int* e = tr.data() + 8 + 8 * t;
+            std::fprintf(stderr, "TRACE %d: pt(%d,%d) n=%d val=%d end=(%d,%d) good=%d count=%d\n", t, e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
+        }
+    }
+#endif
     PRL_HIP_CHECK(hipGetLastError());
     std::vector<unsigned> h_nl((size_t)n_pages);
     std::vector<int> h_lines((size_t)ln_total * 4 + 4);
@@ -547,6 +577,44 @@ static size_t ppht_bytes_per_page(int width, int height)
 }  // namespace prl_hip
 
 using namespace prl_hip;
+
+namespace {
+// one page host -> device -> host around a device-side stage that produces a page of per-page size
+template <typename F>
+int host_roundtrip(int channels, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst, size_t dst_step,
+                   int max_w, int max_h, int* out_w, int* out_h, F&& stage)
+{
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    const size_t in_row = (size_t)width * channels, out_row_max = (size_t)max_w * channels;
+    const size_t in_bytes = r256(in_row * (size_t)height), out_bytes = r256(out_row_max * (size_t)max_h);
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    // own buffers: the stage itself uses the shared staging area for its gray pages
+    PRL_HIP_CHECK(hipMalloc(&d_in, in_bytes + 2 * out_bytes));
+    d_out = d_in + in_bytes;
+    uint8_t* d_packed = d_out + out_bytes;  // the result with rows packed to its own width
+    hipStream_t stream = nullptr;
+    {
+        std::lock_guard<std::mutex> slk(ctx->stage_mu);
+        st = ensure_stage_pinned(ctx, std::max(in_bytes, out_bytes));
+        if (st == PRL_OK) st = stage_upload(ctx, 0, src, src_step, in_row, height, d_in, stream);
+        if (st == PRL_OK) st = hipStreamSynchronize(stream) == hipSuccess ? PRL_OK : PRL_ERR_HIP;
+    }
+    if (st == PRL_OK) st = stage(d_in, in_bytes, in_row, d_out, out_bytes, out_row_max, stream);
+    if (st == PRL_OK && (dst_step < (size_t)*out_w * channels)) st = PRL_ERR_BAD_ARG;
+    if (st == PRL_OK) {
+        std::lock_guard<std::mutex> slk(ctx->stage_mu);
+        // rows of the result are out_row_max apart on the device: fetch them packed
+        const size_t out_row = (size_t)*out_w * channels;
+        PRL_HIP_CHECK(hipMemcpy2DAsync(d_packed, out_row, d_out, out_row_max, out_row, (size_t)*out_h, hipMemcpyDeviceToDevice, stream));
+        st = stage_download(ctx, 0, d_packed, out_row, *out_h, dst, dst_step, stream);
+    }
+    (void)hipFree(d_in);
+    return st;
+}
+}  // namespace
 
 extern "C" {
 
@@ -718,6 +786,46 @@ int prl_hip_deskew_batch_device(int n_pages, int channels, const uint8_t* d_src,
         PRL_HIP_CHECK(hipEventRecord(ctx->last_use, hs));
     }
     return PRL_OK;
+}
+
+
+/* prl::rotate on one host image; dst must hold the size prl_hip_rotate_out_size reports. */
+int prl_hip_rotate_host(int channels, double angle, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst,
+                        size_t dst_step)
+{
+    if (width <= 0 || height <= 0 || !src) return PRL_ERR_EMPTY;
+    if (channels < 1 || channels > 4) return PRL_ERR_BAD_CHANNELS;
+    if (!dst || src_step < (size_t)width * channels) return PRL_ERR_BAD_ARG;
+    int ow = 0, oh = 0;
+    int st = prl_hip_rotate_out_size(width, height, angle, &ow, &oh);
+    if (st != PRL_OK) return st;
+    return host_roundtrip(channels, src, src_step, width, height, dst, dst_step, ow, oh, &ow, &oh,
+                          [&](uint8_t* d_in, size_t in_bytes, size_t in_row, uint8_t* d_out, size_t out_bytes, size_t out_row, hipStream_t s) {
+                              return prl_hip_rotate_batch_device(1, channels, &angle, d_in, in_bytes, in_row, width, height, d_out,
+                                                                 out_bytes, out_row, s);
+                          });
+}
+
+/* prl::deskew on one host image; dst must have room for max(width,height)^2 pixels (dst_step >= that side * channels);
+ * *out_w x *out_h is the size of the result, *angle (optional) findAngle's degrees. */
+int prl_hip_deskew_host(int channels, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst, size_t dst_step,
+                        int* out_w, int* out_h, double* angle)
+{
+    if (width <= 0 || height <= 0 || !src) return PRL_ERR_EMPTY;
+    if (channels != 1 && channels != 3 && channels != 4) return PRL_ERR_BAD_CHANNELS;
+    if (!dst || !out_w || !out_h || src_step < (size_t)width * channels) return PRL_ERR_BAD_ARG;
+    const int len = std::max(width, height);
+    int32_t wh[2] = {0, 0};
+    double ang = 0;
+    const int st = host_roundtrip(channels, src, src_step, width, height, dst, dst_step, len, len, &wh[0], &wh[1],
+                                  [&](uint8_t* d_in, size_t in_bytes, size_t in_row, uint8_t* d_out, size_t out_bytes, size_t out_row, hipStream_t s) {
+                                      return prl_hip_deskew_batch_device(1, channels, d_in, in_bytes, in_row, width, height, d_out,
+                                                                         out_bytes, out_row, wh, &ang, s);
+                                  });
+    *out_w = wh[0];
+    *out_h = wh[1];
+    if (angle) *angle = ang;
+    return st;
 }
 
 }  // extern "C"

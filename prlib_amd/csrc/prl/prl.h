@@ -53,6 +53,17 @@ void denoise(const cv::Mat& inputImage, cv::Mat& outputImage, double strength = 
 void thinZhangSuen(cv::Mat& inputImage, cv::Mat& outputImage);
 void thinGuoHall(cv::Mat& inputImage, cv::Mat& outputImage);
 
+// SURVEY.md §8f rank 3 — src/backgroundNormalization.h:40.  8UC1 -> 8UC1; 8UC3 / 8UC4 -> 8UC3 (the reference's
+// Leptonica round trip drops a fourth channel, src/formatConvert.cpp:193-206).  std::invalid_argument for an empty image
+// (src/backgroundNormalization.cpp:40-43).
+void backgroundNormalization(const cv::Mat& inputImage, cv::Mat& outputImage);
+
+// SURVEY.md §8f rank 4a — src/deskew/deskew.h:42, src/rotate.h:39.  deskew: gray -> Otsu -> HoughLinesP angle vote ->
+// rotate; the result is max(cols, rows) square when an angle was found (src/rotate.cpp:64-68), a clone otherwise.
+// The orientation step (src/deskew/deskew.cpp:238) is a no-op for the page the reference hands it.
+bool deskew(const cv::Mat& inputImage, cv::Mat& outputImage);
+void rotate(const cv::Mat& inputImage, cv::Mat& outputImage, double angle);
+
 // BASELINE config 1 (plumbing, host only): global Otsu, the one global threshold the reference uses
 // (cv::threshold(..., THRESH_BINARY | THRESH_OTSU), src/deskew/deskew.cpp:224).  Not a GPU path.
 void binarize(cv::Mat& inputImage, cv::Mat& outputImage);

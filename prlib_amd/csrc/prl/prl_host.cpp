@@ -117,6 +117,47 @@ void prl::denoise(const cv::Mat& inputImage, cv::Mat& outputImage, double streng
     outputImage = result;
 }
 
+void prl::backgroundNormalization(const cv::Mat& inputImage, cv::Mat& outputImage)
+{
+    if (inputImage.empty()) throw std::invalid_argument("Input image for flipping is empty");  // backgroundNormalization.cpp:40-43
+    if (inputImage.depth() != CV_8U) throw cv::Exception("Cannot convert RAW image to Pix\n");   // formatConvert.cpp:103-104
+    const int cn = inputImage.channels();
+    if (cn != 1 && cn != 3 && cn != 4) throw cv::Exception("Cannot convert RAW image to Pix\n");
+    cv::Mat result(inputImage.rows, inputImage.cols, cn == 1 ? CV_8UC1 : CV_8UC3);
+    const int st = prl_hip_bgnorm_host(cn, inputImage.data, inputImage.step, inputImage.cols, inputImage.rows, result.data,
+                                       result.step);
+    if (st != PRL_OK) raise(st);
+    outputImage = result;
+}
+
+void prl::rotate(const cv::Mat& inputImage, cv::Mat& outputImage, double angle)
+{
+    if (inputImage.empty()) raise(PRL_ERR_EMPTY);  // [upstream] cv::transpose / cv::warpAffine assert on an empty source
+    if (inputImage.depth() != CV_8U) throw cv::Exception("prl::rotate: 8-bit images only");
+    int ow = 0, oh = 0;
+    int st = prl_hip_rotate_out_size(inputImage.cols, inputImage.rows, angle, &ow, &oh);
+    if (st != PRL_OK) raise(st);
+    cv::Mat result(oh, ow, inputImage.type());
+    st = prl_hip_rotate_host(inputImage.channels(), angle, inputImage.data, inputImage.step, inputImage.cols, inputImage.rows,
+                             result.data, result.step);
+    if (st != PRL_OK) raise(st);
+    outputImage = result;
+}
+
+bool prl::deskew(const cv::Mat& inputImage, cv::Mat& outputImage)
+{
+    if (inputImage.empty()) throw cv::Exception("!inputImage.empty()");  // CV_Assert, deskew.cpp:210
+    if (inputImage.depth() != CV_8U) throw cv::Exception("prl::deskew: 8-bit images only");
+    const int len = inputImage.cols > inputImage.rows ? inputImage.cols : inputImage.rows;
+    cv::Mat big(len, len, inputImage.type());
+    int ow = 0, oh = 0;
+    const int st = prl_hip_deskew_host(inputImage.channels(), inputImage.data, inputImage.step, inputImage.cols, inputImage.rows,
+                                       big.data, big.step, &ow, &oh, nullptr);
+    if (st != PRL_OK) raise(st);
+    outputImage = (ow == len && oh == len) ? big : big(cv::Rect(0, 0, ow, oh)).clone();
+    return !outputImage.empty();  // deskew.cpp:245-250
+}
+
 namespace {
 void thin_impl(int method, cv::Mat& inputImage, cv::Mat& outputImage)
 {

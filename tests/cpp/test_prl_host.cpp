@@ -61,6 +61,10 @@ static void test_validation()
     CHECK(throws_invalid_argument([&] { prl::thinZhangSuen(empty, out); }));
     cv::Mat two(8, 8, CV_8UC2);
     CHECK(throws_invalid_argument([&] { prl::thinGuoHall(two, out); }));
+    CHECK(throws_invalid_argument([&] { prl::backgroundNormalization(empty, out); }));  // backgroundNormalization.cpp:40-43
+    bool threw_cv = false;
+    try { prl::deskew(empty, out); } catch (const cv::Exception&) { threw_cv = true; } catch (...) {}
+    CHECK(threw_cv);  // CV_Assert(!inputImage.empty()), deskew.cpp:210
     // global Otsu plumbing (host only): bimodal page splits between the modes
     cv::Mat bi(64, 64, CV_8UC1), bo;
     for (int y = 0; y < 64; ++y)
@@ -185,11 +189,78 @@ static void test_gpu()
     }
 }
 
+// a page of horizontal "text lines" drawn at a small slope, for deskew
+static cv::Mat text_page(int rows, int cols, double slope, int channels)
+{
+    cv::Mat m(rows, cols, CV_MAKETYPE(CV_8U, channels));
+    unsigned s = 99u;
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            s = s * 1664525u + 1013904223u;
+            const double v = y - slope * x;
+            const int line = (int)(v / 30.0);
+            const bool ink = v > 20 && v < rows - 20 && x > 15 && x < cols - 15 && (v - 30.0 * line) < 8.0 && ((x + 17 * line) % 60) < 45;
+            const int val = ink ? 40 + (int)((s >> 24) % 20) : 215 + (int)((s >> 24) % 20);
+            for (int c = 0; c < channels; ++c) m.ptr(y)[x * channels + c] = (unsigned char)(val - 5 * c);
+        }
+    return m;
+}
+
+static void test_gpu_round2()
+{
+    // prl::backgroundNormalization: gray and BGR
+    for (int ch : {1, 3, 4}) {
+        cv::Mat in = synth_page(155, 212, 21, ch), out;
+        const int och = ch == 1 ? 1 : 3;
+        std::vector<unsigned char> want((size_t)155 * 212 * och);
+        CHECK(prl_oracle_bgnorm(ch, in.data, in.step, 212, 155, want.data(), (size_t)212 * och) == PRL_OK);
+        prl::backgroundNormalization(in, out);
+        CHECK(out.rows == 155 && out.cols == 212 && out.channels() == och);
+        size_t bad = 0;
+        for (int y = 0; y < out.rows; ++y) bad += std::memcmp(out.ptr(y), &want[(size_t)y * 212 * och], (size_t)212 * och) != 0;
+        CHECK(bad == 0);
+    }
+    // prl::rotate: general angle (square canvas) and a quarter turn (transposed)
+    {
+        cv::Mat in = synth_page(80, 130, 5, 3), out;
+        std::vector<unsigned char> want((size_t)130 * 130 * 3);
+        CHECK(prl_oracle_rotate(3, in.data, in.step, 130, 80, 7.5, want.data(), 130 * 3) == PRL_OK);
+        prl::rotate(in, out, 7.5);
+        CHECK(out.rows == 130 && out.cols == 130 && out.channels() == 3);
+        size_t bad = 0;
+        for (int y = 0; y < out.rows; ++y) bad += std::memcmp(out.ptr(y), &want[(size_t)y * 390], 390) != 0;
+        CHECK(bad == 0);
+        prl::rotate(in, out, 90.0);
+        CHECK(out.rows == 130 && out.cols == 80);
+        CHECK(prl_oracle_rotate(3, in.data, in.step, 130, 80, 90.0, want.data(), 80 * 3) == PRL_OK);
+        bad = 0;
+        for (int y = 0; y < out.rows; ++y) bad += std::memcmp(out.ptr(y), &want[(size_t)y * 240], 240) != 0;
+        CHECK(bad == 0);
+    }
+    // prl::deskew: a skewed text page comes back square, identical to the oracle; a blank page comes back as a clone
+    for (int ch : {1, 3}) {
+        cv::Mat in = text_page(300, 420, 0.04, ch), out;
+        std::vector<unsigned char> want((size_t)420 * 420 * ch);
+        int ow = 0, oh = 0, nl = 0;
+        double ang = 0;
+        CHECK(prl_oracle_deskew(ch, in.data, in.step, 420, 300, want.data(), (size_t)420 * ch, &ow, &oh, &ang, nullptr, &nl) == PRL_OK);
+        CHECK(nl > 5 && ang != 0.0 && ow == 420 && oh == 420);
+        CHECK(prl::deskew(in, out));
+        CHECK(out.rows == oh && out.cols == ow && out.channels() == ch);
+        size_t bad = 0;
+        for (int y = 0; y < out.rows && out.cols == ow; ++y) bad += std::memcmp(out.ptr(y), &want[(size_t)y * ow * ch], (size_t)ow * ch) != 0;
+        CHECK(bad == 0);
+    }
+    cv::Mat blank(60, 90, CV_8UC1), bout;
+    std::memset(blank.data, 230, 60 * 90);
+    CHECK(prl::deskew(blank, bout) && bout.rows == 60 && bout.cols == 90 && std::memcmp(bout.data, blank.data, 60 * 90) == 0);
+}
+
 int main(int argc, char** argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "cpu";
     test_validation();
-    if (mode == "gpu") test_gpu();
+    if (mode == "gpu") { test_gpu(); test_gpu_round2(); }
     else test_no_device_is_loud();
     if (g_failures) {
         std::printf("%d check(s) failed\n", g_failures);

@@ -66,7 +66,7 @@ def test_bgnorm_reference_test_images(prl, oracle, cuda_device, path):
     """The reference's own test_data/binarize images (inputs held in tests/golden/*.npz)."""
     import torch
 
-    img = np.load(path)["input"]
+    img = np.load(path)["gray"]
     got = prl.backgroundNormalization(torch.from_numpy(img).to(cuda_device)).cpu().numpy()
     assert np.array_equal(got, oracle.bgnorm(img))
 
