@@ -3,7 +3,7 @@
 // Reference: src/backgroundNormalization.cpp:36-61 = opencvToLeptonica -> pixBackgroundNormSimple(pixs, NULL, NULL) ->
 // leptonicaToOpenCV, with the channel conventions of src/formatConvert.cpp:38-218 (1 channel -> 8 bpp; 3 / 4 channels ->
 // 32 bpp with Mat byte i in slot i, three channels out).  The arithmetic is Leptonica's adaptmap.c / convolve.c
-// [upstream, restated in oracle/prl_oracle_bgnorm.c with the function-by-function citation]: tile 10 x 15, foreground
+// [upstream, restated function by function in the test oracle (oracle/, bgnorm file)]: tile 10 x 15, foreground
 // threshold 60, mincount 40, bgval 200, smoothing 2 x 1.
 //
 //   k_bg_tiles<CH>  foreground mask (pixel < 60 on the gray / green channel, dilated 7 x 7) and the per-tile average of

@@ -2,7 +2,7 @@
 //
 // Reference: src/deskew/deskew.cpp:208-251 (gray -> Otsu -> findAngle -> rotate), :139-205 (findAngle = bitwise_not,
 // cv::HoughLinesP(1, CV_PI/180, 100, width/8.f, 20), angle vote), src/rotate.cpp:35-72.  OpenCV's arithmetic
-// [upstream] is restated with citations in oracle/prl_oracle_deskew.c; the kernels below reproduce it bit for bit:
+// [upstream] is restated with citations in the test oracle (oracle/, deskew file); the kernels below reproduce it bit for bit:
 //
 //   k_hist / k_otsu      256-bin histogram (LDS-privatised) and getThreshVal_Otsu_8u's float64 scan, one thread per page
 //   k_dark_mask          mask = (p <= thr) (the bitwise_not of the thresholded page, as 0/1 bytes = HoughLinesP's own
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) k_hist(PageSet src, int width, int height
     if (h[t]) atomicAdd(&hist[(size_t)page * 256 + t], h[t]);
 }
 
-// getThreshVal_Otsu_8u [upstream]: the float64 sequence of oracle/prl_oracle.c:prl_oracle_otsu, one thread per page.
+// getThreshVal_Otsu_8u [upstream]: the float64 scan over the 256 bins, one thread per page.
 __global__ void k_otsu(const unsigned* __restrict__ hist, int width, int height, int n_pages, int* __restrict__ thr)
 {
     const int page = blockIdx.x * blockDim.x + threadIdx.x;
