@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PRL_HIP_ABI_VERSION 1
+#define PRL_HIP_ABI_VERSION 2   /* 2: prl_chain_params grew deskew / background_normalization */
 
 typedef enum prl_status {
     PRL_OK = 0,
@@ -239,23 +239,37 @@ int prl_hip_invert_batch_device(int n_pages, const uint8_t* d_src, size_t src_pa
 
 #define PRL_CHAIN_NO_THINNING (-1)
 
-/* One page through prl::denoise -> cvtColor -> prl::binarize* -> bitwise_not -> prl::thin* (BASELINE config 5 without
- * deskew and background normalisation).  Not a function of the reference: a caller writes these calls one after the
- * other; here the intermediates stay in device memory. */
+/* One page through prl::deskew -> prl::denoise -> prl::backgroundNormalization -> cvtColor -> prl::binarize* ->
+ * bitwise_not -> prl::thin* (BASELINE config 5; every stage but the binarizer optional).  Not a function of the
+ * reference: a caller writes these calls one after the other; here the intermediates stay in device memory. */
 typedef struct prl_chain_params {
-    int denoise;                   /* != 0: prl::denoise(denoise_strength) first; needs a 3/4-channel input */
+    int denoise;                   /* != 0: prl::denoise(denoise_strength); needs a 3/4-channel input */
     float denoise_strength;        /* src/denoise/denoiseNLM.h:32 default 5.5 */
     prl_binarize_params binarize;  /* which binarizer and its arguments */
     int thin;                      /* PRL_CHAIN_NO_THINNING, PRL_THIN_ZHANGSUEN or PRL_THIN_GUOHALL */
+    int deskew;                    /* != 0: prl::deskew first (per-page result sizes: prl_hip_chain_pages_device) */
+    int background_normalization;  /* != 0: prl::backgroundNormalization after the denoise stage (4 channels become 3) */
 } prl_chain_params;
 
 void prl_hip_default_chain_params(prl_chain_params* out);
 
 /* d_dst: out_w x out_h bytes per page (prl_hip_binarize_geometry): the binarizer's mask, or, with thinning, the
- * skeleton of the dark strokes (white on black).  Synchronises `stream` where the stages do. */
+ * skeleton of the dark strokes (white on black).  Synchronises `stream` where the stages do.  params->deskew must be 0
+ * here (a deskewed page has its own size). */
 int prl_hip_chain_batch_device(const prl_chain_params* params, int n_pages, int channels, const uint8_t* d_src,
                                size_t src_page_stride, size_t src_step, int width, int height, uint8_t* d_dst,
                                size_t dst_page_stride, size_t dst_step, void* stream);
+
+/* Largest result a page of width x height can have through the chain (with deskew: a max(width,height) square in, so
+ * the binarizer's geometry of that). */
+int prl_hip_chain_max_out_size(const prl_chain_params* params, int width, int height, int* out_w, int* out_h);
+
+/* The chain with per-page result sizes (needed as soon as params->deskew is set): page i's result is
+ * out_wh[2i] x out_wh[2i+1] bytes (host array), written at dst_step bytes per row into a d_dst page with room for
+ * prl_hip_chain_max_out_size; angles (host, optional) receives findAngle's degrees per page.  Synchronises. */
+int prl_hip_chain_pages_device(const prl_chain_params* params, int n_pages, int channels, const uint8_t* d_src,
+                               size_t src_page_stride, size_t src_step, int width, int height, uint8_t* d_dst,
+                               size_t dst_page_stride, size_t dst_step, int32_t* out_wh, double* angles, void* stream);
 
 /* ---- background normalisation (prl::backgroundNormalization) ------------------------------ */
 

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "prl_hip_default_chain_params", "prl_hip_chain_batch_device",
     "prl_hip_bgnorm_out_channels", "prl_hip_bgnorm_batch_device", "prl_hip_bgnorm_host",
     "prl_hip_rotate_out_size", "prl_hip_rotate_batch_device", "prl_hip_houghp_device", "prl_hip_deskew_batch_device",
-    "prl_hip_rotate_host", "prl_hip_deskew_host",
+    "prl_hip_rotate_host", "prl_hip_deskew_host", "prl_hip_chain_max_out_size", "prl_hip_chain_pages_device",
 ]
 
 
@@ -61,7 +61,8 @@ class BinarizeParams(C.Structure):
 class ChainParams(C.Structure):
     """struct prl_chain_params."""
 
-    _fields_ = [("denoise", C.c_int32), ("denoise_strength", C.c_float), ("binarize", BinarizeParams), ("thin", C.c_int32)]
+    _fields_ = [("denoise", C.c_int32), ("denoise_strength", C.c_float), ("binarize", BinarizeParams), ("thin", C.c_int32),
+                ("deskew", C.c_int32), ("background_normalization", C.c_int32)]
 
 
 class BinarizeGeometry(C.Structure):
@@ -139,6 +140,8 @@ def lib() -> C.CDLL:
         L.prl_hip_deskew_batch_device.argtypes = [i, i, vp, sz, sz, i, i, vp, sz, sz, vp, vp, vp]
         L.prl_hip_rotate_host.argtypes = [i, C.c_double, vp, sz, i, i, vp, sz]
         L.prl_hip_deskew_host.argtypes = [i, vp, sz, i, i, vp, sz, P(C.c_int), P(C.c_int), P(C.c_double)]
+        L.prl_hip_chain_max_out_size.argtypes = [P(ChainParams), i, i, P(C.c_int), P(C.c_int)]
+        L.prl_hip_chain_pages_device.argtypes = [P(ChainParams), i, i, vp, sz, sz, i, i, vp, sz, sz, vp, vp, vp]
         _lib = L
     return _lib
 

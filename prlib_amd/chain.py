@@ -85,12 +85,40 @@ def bitwise_not(image, out=None):
 
 
 def process_pages(pages, channels: int, method: int = 0, windowSize: int = 101, k: float = 0.01,
-                  morphIterationCount: int = 2, denoise_strength=None, thin: int = NO_THINNING, out=None, **feng):
-    """denoise (if `denoise_strength` is given; colour pages only) -> gray -> binarize -> thinning of the inverted mask.
+                  morphIterationCount: int = 2, denoise_strength=None, thin: int = NO_THINNING, out=None,
+                  deskew: bool = False, background_normalization: bool = False, **feng):
+    """[deskew] -> [denoise] (if `denoise_strength` is given; colour pages only) -> [backgroundNormalization] -> gray ->
+    binarize -> thinning of the inverted mask: BASELINE config 5's chain with device-resident intermediates.
 
     pages: uint8 CUDA tensor [N,] H x W (channels = 1) or [N,] H x W x channels (BGR / BGRA).
-    Returns [N,] out_h x out_w: the mask, or with `thin` the skeleton of the dark strokes."""
+    Returns [N,] out_h x out_w: the mask, or with `thin` the skeleton of the dark strokes.  With `deskew` every page has
+    its own result size: returns (list of per-page tensors, angles in degrees)."""
+    import numpy as np
     import torch
+
+    if deskew:
+        t, squeeze = _pages(pages, channels != 1)
+        n, h, w = t.shape[0], t.shape[1], t.shape[2]
+        L = _capi.lib()
+        cp = _capi.ChainParams()
+        L.prl_hip_default_chain_params(C.byref(cp))
+        cp.denoise = 0 if denoise_strength is None else 1
+        cp.denoise_strength = 5.5 if denoise_strength is None else float(denoise_strength)
+        cp.binarize = make_params(method, windowSize, k, morphIterationCount, **feng)
+        cp.thin = int(thin)
+        cp.deskew = 1
+        cp.background_normalization = 1 if background_normalization else 0
+        mw, mh = C.c_int(0), C.c_int(0)
+        st = L.prl_hip_chain_max_out_size(C.byref(cp), w, h, C.byref(mw), C.byref(mh))
+        if st in (_capi.PRL_ERR_EMPTY, _capi.PRL_ERR_BAD_WINDOW):
+            raise ValueError(L.prl_hip_strerror(st).decode())
+        _capi.check(st)
+        o = torch.empty((n, mh.value, mw.value), dtype=torch.uint8, device=t.device)
+        wh = np.zeros((n, 2), dtype=np.int32)
+        ang = np.zeros(n, dtype=np.float64)
+        _capi.check(L.prl_hip_chain_pages_device(C.byref(cp), n, channels, t.data_ptr(), t.stride(0), t.stride(1), w, h,
+                                                o.data_ptr(), o.stride(0), o.stride(1), wh.ctypes.data, ang.ctypes.data, _stream(t)))
+        return [o[i, : wh[i, 1], : wh[i, 0]] for i in range(n)], ang
 
     t, squeeze = _pages(pages, channels != 1)
     n, h, w = t.shape[0], t.shape[1], t.shape[2]
@@ -103,6 +131,7 @@ def process_pages(pages, channels: int, method: int = 0, windowSize: int = 101, 
     cp.denoise_strength = 5.5 if denoise_strength is None else float(denoise_strength)
     cp.binarize = make_params(method, windowSize, k, morphIterationCount, **feng)
     cp.thin = int(thin)
+    cp.background_normalization = 1 if background_normalization else 0
     g = _capi.BinarizeGeometry()
     st = L.prl_hip_binarize_geometry(C.byref(cp.binarize), w, h, C.byref(g))
     if st in (_capi.PRL_ERR_EMPTY, _capi.PRL_ERR_BAD_WINDOW):

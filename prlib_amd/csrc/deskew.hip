@@ -574,6 +574,69 @@ static size_t ppht_bytes_per_page(int width, int height)
     return r256((size_t)width * height) + kNumAngle * numrho * 4 + (size_t)height * 8 + 2048 + (size_t)width * height / 2;
 }
 
+
+size_t deskew_gray_bytes(int width, int height) { return r256((size_t)width * height); }
+
+// pages per pass of prl::deskew: bounded by a workspace budget (mask + accumulator + point lists per page)
+int deskew_pages_per_pass(int n_pages, int width, int height)
+{
+    size_t budget = (size_t)24 << 30;
+    if (const char* e = std::getenv("PRL_HIP_DESKEW_WORK_MB")) budget = (size_t)std::max(64ll, std::atoll(e)) << 20;
+    return (int)std::max<size_t>(1, std::min<size_t>({(size_t)n_pages, (size_t)16384, budget / ppht_bytes_per_page(width, height)}));
+}
+
+// prl::deskew on `cnt` pages (cnt <= deskew_pages_per_pass): gray -> Otsu -> HoughLinesP -> vote -> rotate.  gray_ws: room for
+// cnt gray pages of deskew_gray_bytes each (unused for 1-channel input).  Takes ctx->mu; the caller owns gray_ws.
+int deskew_pages(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
+                 int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, int32_t* out_wh, double* angles,
+                 uint8_t* gray_ws, hipStream_t hs)
+{
+    const size_t gray_page = deskew_gray_bytes(width, height);
+    int st;
+    PageSet g{};
+    if (channels != 1) {  // deskew.cpp:214-217
+        st = prl_hip_bgr2gray_batch_device(cnt, channels, src, src_page_stride, src_step, width, height, gray_ws, gray_page,
+                                           (size_t)width, hs);
+        if (st != PRL_OK) return st;
+        g.base = gray_ws; g.page_stride = gray_page; g.step = (size_t)width;
+    } else {
+        g.base = src; g.page_stride = src_page_stride; g.step = src_step;
+    }
+    std::vector<std::vector<int>> lines;
+    std::vector<WarpPage> wp((size_t)cnt);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(hs, ctx->last_use, 0));
+    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+    // cv::threshold(..., THRESH_BINARY | THRESH_OTSU) (:224) + findAngle's bitwise_not (:146): points = (p <= otsu)
+    st = ppht_pages(ctx, cnt, g, width, height, 100, (int)std::lrint((double)(width / 8.f)), (int)std::lrint(20.0), true, 0, &lines,
+                    nullptr, hs);
+    if (st != PRL_OK) return st;
+    int max_ow = 0, max_oh = 0;
+    for (int i = 0; i < cnt; ++i) {
+        const double angle = vote_angle(lines[(size_t)i].data(), (int)(lines[(size_t)i].size() / 4));
+        if (angles) angles[i] = angle;
+        const bool rot = (angle != 0) && (angle <= DBL_MAX && angle >= -DBL_MAX);  // deskew.cpp:228
+        fill_warp_page(width, height, angle, !rot, &wp[(size_t)i]);
+        out_wh[2 * i] = wp[(size_t)i].ow;
+        out_wh[2 * i + 1] = wp[(size_t)i].oh;
+        max_ow = std::max(max_ow, wp[(size_t)i].ow);
+        max_oh = std::max(max_oh, wp[(size_t)i].oh);
+    }
+    st = ensure_small(ctx, sizeof(WarpPage) * (size_t)cnt);
+    if (st != PRL_OK) return st;
+    ctx->lut_small[0] = ctx->lut_small[1] = nullptr;
+    PRL_HIP_CHECK(hipMemcpyAsync(ctx->small, wp.data(), sizeof(WarpPage) * (size_t)cnt, hipMemcpyHostToDevice, hs));
+    PRL_HIP_CHECK(hipStreamSynchronize(hs));
+    PageSet s{};
+    s.base = src; s.page_stride = src_page_stride; s.step = src_step;
+    PageSetOut d{};
+    d.base = dst; d.page_stride = dst_page_stride; d.step = dst_step;
+    st = launch_warp(channels, s, d, width, height, cnt, max_ow, max_oh, static_cast<const WarpPage*>(ctx->small), hs);
+    if (st != PRL_OK) return st;
+    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, hs));
+    return PRL_OK;
+}
+
 }  // namespace prl_hip
 
 using namespace prl_hip;
@@ -729,65 +792,21 @@ int prl_hip_deskew_batch_device(int n_pages, int channels, const uint8_t* d_src,
     int st = current_device(&dev);
     if (st != PRL_OK) return st;
     DeviceCtx* ctx = device_ctx(dev);
-    hipStream_t hs = static_cast<hipStream_t>(stream);
     std::lock_guard<std::mutex> slk(ctx->stage_mu);  // gray pages live in the staging area
-    // pages per pass: bounded by a workspace budget (mask + accumulator + lists per page)
-    size_t budget = (size_t)24 << 30;
-    if (const char* e = std::getenv("PRL_HIP_DESKEW_WORK_MB")) budget = (size_t)std::max(64ll, std::atoll(e)) << 20;
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>({(size_t)n_pages, (size_t)16384, budget / ppht_bytes_per_page(width, height)}));
-    const size_t gray_page = r256((size_t)width * height);
+    const int chunk = deskew_pages_per_pass(n_pages, width, height);
     if (channels != 1) {
-        st = ensure_stage(ctx, gray_page * (size_t)chunk);
+        st = ensure_stage(ctx, deskew_gray_bytes(width, height) * (size_t)chunk);
         if (st != PRL_OK) return st;
     }
-    std::vector<WarpPage> wp((size_t)chunk);
     for (int first = 0; first < n_pages; first += chunk) {
         const int cnt = std::min(chunk, n_pages - first);
-        const uint8_t* src = d_src + (size_t)first * src_page_stride;
-        PageSet g{};
-        if (channels != 1) {  // deskew.cpp:214-217
-            st = prl_hip_bgr2gray_batch_device(cnt, channels, src, src_page_stride, src_step, width, height,
-                                               static_cast<uint8_t*>(ctx->stage), gray_page, (size_t)width, stream);
-            if (st != PRL_OK) return st;
-            g.base = static_cast<uint8_t*>(ctx->stage); g.page_stride = gray_page; g.step = (size_t)width;
-        } else {
-            g.base = src; g.page_stride = src_page_stride; g.step = src_step;
-        }
-        std::vector<std::vector<int>> lines;
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(hs, ctx->last_use, 0));
-        else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
-        // cv::threshold(..., THRESH_BINARY | THRESH_OTSU) (:224) + findAngle's bitwise_not (:146): points = (p <= otsu)
-        st = ppht_pages(ctx, cnt, g, width, height, 100, (int)std::lrint((double)(width / 8.f)), (int)std::lrint(20.0), true, 0,
-                        &lines, nullptr, hs);
+        st = deskew_pages(ctx, cnt, channels, d_src + (size_t)first * src_page_stride, src_page_stride, src_step, width, height,
+                          d_dst + (size_t)first * dst_page_stride, dst_page_stride, dst_step, out_wh + 2 * first,
+                          angles ? angles + first : nullptr, static_cast<uint8_t*>(ctx->stage), static_cast<hipStream_t>(stream));
         if (st != PRL_OK) return st;
-        int max_ow = 0, max_oh = 0;
-        for (int i = 0; i < cnt; ++i) {
-            const double angle = vote_angle(lines[(size_t)i].data(), (int)(lines[(size_t)i].size() / 4));
-            if (angles) angles[first + i] = angle;
-            const bool rot = (angle != 0) && (angle <= DBL_MAX && angle >= -DBL_MAX);  // deskew.cpp:228
-            fill_warp_page(width, height, angle, !rot, &wp[(size_t)i]);
-            out_wh[2 * (first + i)] = wp[(size_t)i].ow;
-            out_wh[2 * (first + i) + 1] = wp[(size_t)i].oh;
-            max_ow = std::max(max_ow, wp[(size_t)i].ow);
-            max_oh = std::max(max_oh, wp[(size_t)i].oh);
-        }
-        st = ensure_small(ctx, sizeof(WarpPage) * (size_t)cnt);
-        if (st != PRL_OK) return st;
-        ctx->lut_small[0] = ctx->lut_small[1] = nullptr;
-        PRL_HIP_CHECK(hipMemcpyAsync(ctx->small, wp.data(), sizeof(WarpPage) * (size_t)cnt, hipMemcpyHostToDevice, hs));
-        PRL_HIP_CHECK(hipStreamSynchronize(hs));
-        PageSet s{};
-        s.base = src; s.page_stride = src_page_stride; s.step = src_step;
-        PageSetOut d{};
-        d.base = d_dst + (size_t)first * dst_page_stride; d.page_stride = dst_page_stride; d.step = dst_step;
-        st = launch_warp(channels, s, d, width, height, cnt, max_ow, max_oh, static_cast<const WarpPage*>(ctx->small), hs);
-        if (st != PRL_OK) return st;
-        PRL_HIP_CHECK(hipEventRecord(ctx->last_use, hs));
     }
     return PRL_OK;
 }
-
 
 /* prl::rotate on one host image; dst must hold the size prl_hip_rotate_out_size reports. */
 int prl_hip_rotate_host(int channels, double angle, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst,

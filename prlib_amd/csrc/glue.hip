@@ -15,6 +15,8 @@
 // device staging workspace.  There is no such function in the reference (a user writes the calls one after the
 // other, each through host memory); BASELINE config 5 is this chain.
 #include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 #include "prl_internal.h"
 
@@ -230,24 +232,110 @@ int prl_hip_invert_batch_device(int n_pages, const uint8_t* d_src, size_t src_pa
     return PRL_OK;
 }
 
-// denoise (optional, colour input only) -> gray -> binarize -> thinning of the inverted mask (optional).
-// d_dst receives out_w x out_h bytes per page (prl_hip_binarize_geometry): the mask, or the skeleton when thinning
-// is requested (white = skeleton of the dark strokes).
-int prl_hip_chain_batch_device(const prl_chain_params* cp, int n_pages, int channels, const uint8_t* d_src,
-                               size_t src_page_stride, size_t src_step, int width, int height, uint8_t* d_dst,
-                               size_t dst_page_stride, size_t dst_step, void* stream)
+// [deskew] -> [denoise] -> [backgroundNormalization] -> gray -> binarize -> [thinning of the inverted mask]: BASELINE
+// config 5's order.  Every deskewed page has its own size, so the stages after it run per RUN of consecutive pages of
+// equal size (all pages of a skewed batch come out max(W,H) square: one run).
+namespace {
+
+size_t r256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct ChainLayout {   // per page of a uniform run, each part rounded up to 256 B
+    size_t denoised, normalised, gray, mask, total;
+    int ch_after;      // channels of the page the gray conversion sees
+};
+
+ChainLayout chain_layout(const prl_chain_params* cp, int channels, int width, int height, const prl_binarize_geometry& g)
+{
+    ChainLayout l{};
+    const size_t px = (size_t)width * height;
+    int ch = channels;
+    if (cp->denoise) l.denoised = r256(px * (size_t)ch);
+    if (cp->background_normalization) {
+        ch = prl_hip_bgnorm_out_channels(ch);
+        l.normalised = r256(px * (size_t)ch);
+    }
+    l.ch_after = ch;
+    if (ch != 1) l.gray = r256(px);
+    if (cp->thin != PRL_CHAIN_NO_THINNING) l.mask = r256((size_t)g.out_w * g.out_h);
+    l.total = l.denoised + l.normalised + l.gray + l.mask;
+    return l;
+}
+
+// the stages after deskew on `cnt` pages of one size; ws: cnt * layout.total bytes
+int chain_uniform(const prl_chain_params* cp, int cnt, int channels, const uint8_t* src, size_t src_ps, size_t src_step, int width,
+                  int height, uint8_t* out, size_t dst_ps, size_t dst_step, uint8_t* ws, void* stream)
+{
+    prl_binarize_geometry g;
+    int st = prl_hip_binarize_geometry(&cp->binarize, width, height, &g);
+    if (st != PRL_OK) return st;
+    const ChainLayout l = chain_layout(cp, channels, width, height, g);
+    const uint8_t* cur = src;
+    size_t cur_ps = src_ps, cur_step = src_step;
+    int ch = channels;
+    uint8_t* w = ws;
+    if (cp->denoise) {
+        st = prl_hip_denoise_batch_device(cnt, ch, cp->denoise_strength, cur, cur_ps, cur_step, width, height, w, l.denoised,
+                                          (size_t)width * ch, stream);
+        if (st != PRL_OK) return st;
+        cur = w; cur_ps = l.denoised; cur_step = (size_t)width * ch;
+        w += l.denoised * (size_t)cnt;
+    }
+    if (cp->background_normalization) {
+        const int och = prl_hip_bgnorm_out_channels(ch);
+        st = prl_hip_bgnorm_batch_device(cnt, ch, cur, cur_ps, cur_step, width, height, w, l.normalised, (size_t)width * och, stream);
+        if (st != PRL_OK) return st;
+        ch = och;
+        cur = w; cur_ps = l.normalised; cur_step = (size_t)width * ch;
+        w += l.normalised * (size_t)cnt;
+    }
+    if (ch != 1) {
+        st = prl_hip_bgr2gray_batch_device(cnt, ch, cur, cur_ps, cur_step, width, height, w, l.gray, (size_t)width, stream);
+        if (st != PRL_OK) return st;
+        cur = w; cur_ps = l.gray; cur_step = (size_t)width;
+        w += l.gray * (size_t)cnt;
+    }
+    if (cp->thin == PRL_CHAIN_NO_THINNING)
+        return prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, out, dst_ps, dst_step, stream);
+    st = prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, w, l.mask, (size_t)g.out_w, stream);
+    if (st != PRL_OK) return st;
+    // cv::bitwise_not between the two stages happens inside the thinning's bit packing (no pass of its own)
+    return prl_hip::thin_batch_device(cp->thin, cnt, w, l.mask, (size_t)g.out_w, g.out_w, g.out_h, out, dst_ps, dst_step, stream, true);
+}
+
+size_t chain_budget()
+{
+    size_t mb = 48 * 1024;  // intermediates of one pass (288 GB of HBM: big passes, few launches)
+    if (const char* e = std::getenv("PRL_HIP_CHAIN_WORK_MB")) mb = (size_t)std::max(16ll, std::atoll(e));
+    return mb << 20;
+}
+
+int chain_check(const prl_chain_params* cp, int n_pages, int channels, const uint8_t* d_src, size_t src_step, int width, int height,
+                uint8_t* d_dst)
 {
     if (!cp) return PRL_ERR_BAD_ARG;
     if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
     if (channels != 1 && channels != 3 && channels != 4) return PRL_ERR_BAD_CHANNELS;
     if (cp->denoise && channels == 1) return PRL_ERR_BAD_CHANNELS;  // fastNlMeansDenoisingColored asserts 8UC3 / 8UC4
-    if (cp->thin != PRL_CHAIN_NO_THINNING && cp->thin != PRL_THIN_ZHANGSUEN && cp->thin != PRL_THIN_GUOHALL)
-        return PRL_ERR_BAD_ARG;
+    if (cp->thin != PRL_CHAIN_NO_THINNING && cp->thin != PRL_THIN_ZHANGSUEN && cp->thin != PRL_THIN_GUOHALL) return PRL_ERR_BAD_ARG;
     if (n_pages < 0 || !d_src || !d_dst || src_step < (size_t)width * channels) return PRL_ERR_BAD_ARG;
-    prl_binarize_geometry g;
-    int st = prl_hip_binarize_geometry(&cp->binarize, width, height, &g);
+    return PRL_OK;
+}
+
+}  // namespace
+
+// The chain on pages whose results may differ in size (deskew): out_wh (host, 2 ints per page) receives each page's
+// result size; d_dst pages need room for the largest possible result (prl_hip_chain_max_out_size) at dst_step bytes per row.
+int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int channels, const uint8_t* d_src, size_t src_page_stride,
+                               size_t src_step, int width, int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step,
+                               int32_t* out_wh, double* angles, void* stream)
+{
+    int st = chain_check(cp, n_pages, channels, d_src, src_step, width, height, d_dst);
     if (st != PRL_OK) return st;
-    if (dst_step < (size_t)g.out_w) return PRL_ERR_BAD_ARG;
+    if (!out_wh) return PRL_ERR_BAD_ARG;
+    int max_w = 0, max_h = 0;
+    st = prl_hip_chain_max_out_size(cp, width, height, &max_w, &max_h);
+    if (st != PRL_OK) return st;
+    if (dst_step < (size_t)max_w) return PRL_ERR_BAD_ARG;
     if (n_pages == 0) return PRL_OK;
     int dev;
     st = current_device(&dev);
@@ -255,54 +343,91 @@ int prl_hip_chain_batch_device(const prl_chain_params* cp, int n_pages, int chan
     DeviceCtx* ctx = device_ctx(dev);
     std::lock_guard<std::mutex> slk(ctx->stage_mu);  // the staging workspace holds the intermediates
 
-    const size_t px = (size_t)width * height, cpx = px * (size_t)channels;
-    const size_t mpx = (size_t)g.out_w * g.out_h;
-    const bool thin = cp->thin != PRL_CHAIN_NO_THINNING;
-    // per page: [denoised colour][gray][mask], each rounded up to 256 B
-    auto r256 = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t per_page = (cp->denoise ? r256(cpx) : 0) + (channels != 1 ? r256(px) : 0) + (thin ? r256(mpx) : 0);
-    const size_t budget = (size_t)1 << 30;
-    int chunk = per_page == 0 ? n_pages : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, budget / per_page));
+    const int len = std::max(width, height);
+    const int dw = cp->deskew ? len : width, dh = cp->deskew ? len : height;  // largest page the later stages can see
+    prl_binarize_geometry gmax;
+    st = prl_hip_binarize_geometry(&cp->binarize, dw, dh, &gmax);
+    if (st != PRL_OK) return st;
+    const ChainLayout lmax = chain_layout(cp, channels, dw, dh, gmax);
+    const size_t desk_page = cp->deskew ? r256((size_t)len * len * channels) : 0;
+    const size_t gray_page = (cp->deskew && channels != 1) ? deskew_gray_bytes(width, height) : 0;
+    const size_t per_page = desk_page + gray_page + lmax.total;
+    int chunk = per_page == 0 ? n_pages : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, chain_budget() / per_page));
     chunk = std::min(chunk, 32768);
+    if (cp->deskew) chunk = std::min(chunk, deskew_pages_per_pass(n_pages, width, height));
     if (per_page) {
         st = ensure_stage(ctx, per_page * (size_t)chunk);
         if (st != PRL_OK) return st;
     }
+    std::vector<int32_t> wh((size_t)chunk * 2);
     for (int first = 0; first < n_pages; first += chunk) {
         const int cnt = std::min(chunk, n_pages - first);
-        uint8_t* w = static_cast<uint8_t*>(ctx->stage);
+        uint8_t* ws = static_cast<uint8_t*>(ctx->stage);
         const uint8_t* cur = d_src + (size_t)first * src_page_stride;
         size_t cur_ps = src_page_stride, cur_step = src_step;
-        if (cp->denoise) {
-            st = prl_hip_denoise_batch_device(cnt, channels, cp->denoise_strength, cur, cur_ps, cur_step, width, height, w,
-                                              r256(cpx), (size_t)width * channels, stream);
+        if (cp->deskew) {
+            uint8_t* desk = ws;
+            uint8_t* gray = ws + desk_page * (size_t)cnt;
+            ws = gray + gray_page * (size_t)cnt;
+            st = deskew_pages(ctx, cnt, channels, cur, cur_ps, cur_step, width, height, desk, desk_page, (size_t)len * channels,
+                              wh.data(), angles ? angles + first : nullptr, gray, static_cast<hipStream_t>(stream));
             if (st != PRL_OK) return st;
-            cur = w; cur_ps = r256(cpx); cur_step = (size_t)width * channels;
-            w += r256(cpx) * (size_t)cnt;
-        }
-        if (channels != 1) {
-            st = prl_hip_bgr2gray_batch_device(cnt, channels, cur, cur_ps, cur_step, width, height, w, r256(px), (size_t)width,
-                                               stream);
-            if (st != PRL_OK) return st;
-            cur = w; cur_ps = r256(px); cur_step = (size_t)width;
-            w += r256(px) * (size_t)cnt;
-        }
-        uint8_t* out = d_dst + (size_t)first * dst_page_stride;
-        if (!thin) {
-            st = prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, out, dst_page_stride,
-                                               dst_step, stream);
-            if (st != PRL_OK) return st;
+            cur = desk; cur_ps = desk_page; cur_step = (size_t)len * channels;
         } else {
-            st = prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, w, r256(mpx),
-                                               (size_t)g.out_w, stream);
+            for (int i = 0; i < cnt; ++i) { wh[2 * (size_t)i] = width; wh[2 * (size_t)i + 1] = height; }
+            if (angles) for (int i = 0; i < cnt; ++i) angles[first + i] = 0.0;
+        }
+        for (int r0 = 0; r0 < cnt;) {  // runs of equal page size
+            int r1 = r0 + 1;
+            while (r1 < cnt && wh[2 * (size_t)r1] == wh[2 * (size_t)r0] && wh[2 * (size_t)r1 + 1] == wh[2 * (size_t)r0 + 1]) ++r1;
+            const int pw = wh[2 * (size_t)r0], ph = wh[2 * (size_t)r0 + 1];
+            prl_binarize_geometry g;
+            st = prl_hip_binarize_geometry(&cp->binarize, pw, ph, &g);
             if (st != PRL_OK) return st;
-            // cv::bitwise_not between the two stages happens inside the thinning's bit packing (no pass of its own)
-            st = prl_hip::thin_batch_device(cp->thin, cnt, w, r256(mpx), (size_t)g.out_w, g.out_w, g.out_h, out, dst_page_stride,
-                                            dst_step, stream, true);
+            st = chain_uniform(cp, r1 - r0, channels, cur + (size_t)r0 * cur_ps, cur_ps, cur_step, pw, ph,
+                               d_dst + (size_t)(first + r0) * dst_page_stride, dst_page_stride, dst_step, ws, stream);
             if (st != PRL_OK) return st;
+            for (int i = r0; i < r1; ++i) {
+                out_wh[2 * (size_t)(first + i)] = g.out_w;
+                out_wh[2 * (size_t)(first + i) + 1] = g.out_h;
+            }
+            r0 = r1;
         }
     }
     return PRL_OK;
+}
+
+int prl_hip_chain_max_out_size(const prl_chain_params* cp, int width, int height, int* out_w, int* out_h)
+{
+    if (!cp || !out_w || !out_h) return PRL_ERR_BAD_ARG;
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    const int len = std::max(width, height);
+    prl_binarize_geometry g;
+    int st = prl_hip_binarize_geometry(&cp->binarize, cp->deskew ? len : width, cp->deskew ? len : height, &g);
+    if (st != PRL_OK) return st;
+    *out_w = g.out_w;
+    *out_h = g.out_h;
+    if (cp->deskew) {  // pages without an angle keep width x height: their result can be larger in one dimension only if ... never
+        prl_binarize_geometry g2;
+        st = prl_hip_binarize_geometry(&cp->binarize, width, height, &g2);
+        if (st != PRL_OK) return st;  // (a page that keeps its size must be binarizable too)
+        *out_w = std::max(*out_w, g2.out_w);
+        *out_h = std::max(*out_h, g2.out_h);
+    }
+    return PRL_OK;
+}
+
+// Uniform result size: the chain without deskew.  d_dst receives out_w x out_h bytes per page (prl_hip_binarize_geometry).
+int prl_hip_chain_batch_device(const prl_chain_params* cp, int n_pages, int channels, const uint8_t* d_src,
+                               size_t src_page_stride, size_t src_step, int width, int height, uint8_t* d_dst,
+                               size_t dst_page_stride, size_t dst_step, void* stream)
+{
+    if (cp && cp->deskew) return PRL_ERR_BAD_ARG;  // per-page result sizes: prl_hip_chain_pages_device
+    int st = chain_check(cp, n_pages, channels, d_src, src_step, width, height, d_dst);
+    if (st != PRL_OK) return st;
+    std::vector<int32_t> wh((size_t)std::max(n_pages, 1) * 2);
+    return prl_hip_chain_pages_device(cp, n_pages, channels, d_src, src_page_stride, src_step, width, height, d_dst, dst_page_stride,
+                                      dst_step, wh.data(), nullptr, stream);
 }
 
 void prl_hip_default_chain_params(prl_chain_params* out)
@@ -312,6 +437,8 @@ void prl_hip_default_chain_params(prl_chain_params* out)
     out->denoise_strength = 5.5f;  // src/denoise/denoiseNLM.h:32
     prl_hip_default_params(PRL_SAUVOLA, &out->binarize);
     out->thin = PRL_CHAIN_NO_THINNING;
+    out->deskew = 0;
+    out->background_normalization = 0;
 }
 
 }  // extern "C"

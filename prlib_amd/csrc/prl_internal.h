@@ -135,6 +135,13 @@ bool fused_supports(const ThrParams& tp);
 int thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step, int width,
                       int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream, bool invert_input);
 
+// ---- deskew (deskew.hip): one pass over `cnt` pages with the gray workspace supplied by the caller (chain glue) ------
+size_t deskew_gray_bytes(int width, int height);
+int deskew_pages_per_pass(int n_pages, int width, int height);
+int deskew_pages(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
+                 int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, int32_t* out_wh, double* angles,
+                 uint8_t* gray_ws, hipStream_t hs);
+
 // ---- morphology (morph.hip) ------------------------------------------------------------------
 int morph_run(int iterations, const PageSet& src, int n_pages, int width, int height,
               const PageSetOut& dst, hipStream_t stream);

@@ -137,3 +137,73 @@ def test_more_pages_than_one_grid_dimension(prl, oracle, cuda_device):
     g2 = prl.cvtColorBGR2GRAY(bgr).cpu().numpy()
     for i in (0, 32768, 65535, 65999):
         assert np.array_equal(g2[i], oracle.bgr2gray(np.repeat(gray[i][:, :, None], 3, axis=2).copy())), i
+
+
+def _oracle_chain5(oracle, img, channels, w, k, morph, strength, thin, bgnorm=True, deskew=True):
+    """BASELINE config 5 composed from the oracle's stages: deskew -> denoise -> backgroundNormalization -> gray ->
+    Sauvola -> bitwise_not -> thinning."""
+    cur, info = (oracle.deskew(img) if deskew else (img, dict(angle=0.0)))
+    if strength is not None:
+        cur = oracle.denoise(np.ascontiguousarray(cur), strength, threads=8)
+    if bgnorm:
+        cur = oracle.bgnorm(np.ascontiguousarray(cur))
+    if cur.ndim == 3:
+        cur = oracle.bgr2gray(np.ascontiguousarray(cur))
+    mask = oracle.binarize(np.ascontiguousarray(cur), oracle.make_params(oracle.SAUVOLA, w, k, morph))
+    return (mask if thin < 0 else oracle.thin(255 - mask, thin)), info["angle"]
+
+
+@pytest.mark.parametrize("channels", [3, 4])
+def test_config5_chain_matches_the_composed_oracle(prl, oracle, cuda_device, channels):
+    """deskew -> NL-means -> backgroundNormalization -> Sauvola -> Zhang-Suen thinning (BASELINE config 5) on a batch whose
+    pages come out in different sizes: skewed pages as max(W,H) squares, a straight and a blank page unchanged."""
+    import torch
+    from prlib_amd import synth
+
+    h, w = 150, 208
+    pages = []
+    for i, skew in enumerate((2.0, 0.0, -3.0)):
+        g = synth.text_page_numpy(h, w, 40 + i, skew_deg=skew, shading=0.3)
+        rng = np.random.default_rng(i)
+        col = np.clip(g[..., None].astype(np.int32) + rng.normal(0, 6, (h, w, channels)), 0, 255).round().astype(np.uint8)
+        pages.append(col)
+    pages.append(np.full((h, w, channels), 228, np.uint8))   # blank: no segments, stays 150 x 208
+    batch = np.stack(pages)
+    outs, angles = prl.process_pages(torch.from_numpy(batch).to(cuda_device), channels, prl.SAUVOLA, 31, 0.34, 0,
+                                     denoise_strength=10.0, thin=0, deskew=True, background_normalization=True)
+    sizes = set()
+    for i in range(len(pages)):
+        want, ang = _oracle_chain5(oracle, batch[i], channels, 31, 0.34, 0, 10.0, 0)
+        got = outs[i].cpu().numpy()
+        assert angles[i] == ang
+        assert got.shape == want.shape, (i, got.shape, want.shape)
+        assert np.array_equal(got, want), f"page {i}: {int((got != want).sum())} mismatching pixels"
+        sizes.add(got.shape)
+    assert len(sizes) >= 2 and angles[-1] == 0.0
+
+
+def test_chain_stage_subsets(prl, oracle, cuda_device):
+    import torch
+    from prlib_amd import synth
+
+    g = synth.text_page_numpy(130, 170, 50, skew_deg=1.5, shading=0.4)
+    t = torch.from_numpy(np.stack([g, g[::-1].copy()])).to(cuda_device)
+    # gray pages: deskew + backgroundNormalization + Sauvola, no thinning
+    outs, angles = prl.process_pages(t, 1, prl.SAUVOLA, 15, 0.2, 1, deskew=True, background_normalization=True)
+    for i, src in enumerate((g, g[::-1].copy())):
+        want, ang = _oracle_chain5(oracle, src, 1, 15, 0.2, 1, None, -1)
+        assert angles[i] == ang and np.array_equal(outs[i].cpu().numpy(), want)
+    # backgroundNormalization without deskew goes through the uniform-size entry
+    got = prl.process_pages(t, 1, prl.SAUVOLA, 15, 0.2, 0, background_normalization=True, thin=1).cpu().numpy()
+    for i, src in enumerate((g, g[::-1].copy())):
+        want, _ = _oracle_chain5(oracle, src, 1, 15, 0.2, 0, None, 1, deskew=False)
+        assert np.array_equal(got[i], want)
+    # the uniform entry refuses deskew (per-page sizes)
+    from prlib_amd import _capi
+    import ctypes as C
+    cp = _capi.ChainParams()
+    _capi.lib().prl_hip_default_chain_params(C.byref(cp))
+    cp.deskew = 1
+    o = torch.empty((2, 130, 170), dtype=torch.uint8, device=cuda_device)
+    assert _capi.lib().prl_hip_chain_batch_device(C.byref(cp), 2, 1, t.data_ptr(), t.stride(0), t.stride(1), 170, 130,
+                                                  o.data_ptr(), o.stride(0), o.stride(1), None) == _capi.PRL_ERR_BAD_ARG
