@@ -81,3 +81,42 @@ def text_page_numpy(height: int, width: int, index: int = 0, skew_deg: float = 0
     light = 1.0 - shading * (0.6 * xx / max(1, width - 1) + 0.4 * yy / max(1, height - 1))
     page = np.where(ink, rng.normal(45.0, 10.0, size=(height, width)), paper) * light
     return np.clip(np.rint(page), 0, 255).astype(np.uint8)
+
+
+def text_pages_torch(n_pages: int, height: int, width: int, device, seed: int = 7000, max_skew_deg: float = 4.0,
+                     shading: float = 0.3, channels: int = 1):
+    """text_page_numpy's recipe drawn on the device (full-size chain batches): N x H x W [x C] uint8, one skew per page
+    uniform in +-max_skew_deg (returned as well)."""
+    import torch
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    shape = (n_pages, height, width) if channels == 1 else (n_pages, height, width, channels)
+    out = torch.empty(shape, dtype=torch.uint8, device=device)
+    skews = (torch.rand(n_pages, generator=gen, device=device) * 2 - 1) * max_skew_deg
+    yy = torch.arange(height, device=device, dtype=torch.float32)[:, None]
+    xx = torch.arange(width, device=device, dtype=torch.float32)[None, :]
+    pitch, line_h = 40.0, 6.0
+    margin = 0.06 * min(height, width)
+    span = int((height ** 2 + width ** 2) ** 0.5) + 64
+    n_lines = span // int(pitch) + 4
+    for i in range(n_pages):
+        a = torch.deg2rad(skews[i])
+        u = xx * torch.cos(a) + yy * torch.sin(a)
+        v = -xx * torch.sin(a) + yy * torch.cos(a)
+        # word pattern: per line a random phase and period; ink where (u + phase) mod period < 0.8 period
+        phase = torch.rand(2 * n_lines, generator=gen, device=device) * 90
+        period = 45 + torch.rand(2 * n_lines, generator=gen, device=device) * 60
+        li = torch.clamp(torch.floor(v / pitch).long() + n_lines, 0, 2 * n_lines - 1)
+        inside = (torch.remainder(v, pitch) < line_h) & (xx > margin) & (xx < width - margin) & (yy > margin) & (yy < height - margin)
+        ink = inside & (torch.remainder(u + span + phase[li], period[li]) < 0.8 * period[li])
+        light = 1.0 - shading * (0.6 * xx / max(1, width - 1) + 0.4 * yy / max(1, height - 1))
+        for c in range(channels):
+            paper = torch.empty((height, width), dtype=torch.float32, device=device).normal_(225.0, 6.0, generator=gen)
+            dark = torch.empty((height, width), dtype=torch.float32, device=device).normal_(45.0, 10.0, generator=gen)
+            page = (torch.where(ink, dark, paper) * light).round_().clamp_(0, 255).to(torch.uint8)
+            if channels == 1:
+                out[i] = page
+            else:
+                out[i, :, :, c] = page
+    return out, skews.cpu().numpy()

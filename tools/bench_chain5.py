@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 on one GPU: deskew -> NL-means -> backgroundNormalization -> Sauvola -> Zhang-Suen thinning on a batch
+of A4 colour scans, device resident.  Prints one JSON object: per-stage times (stages called one after the other through
+the public entry points) and the one-call chain (prl_hip_chain_pages_device)."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import prlib_amd
+from prlib_amd import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--pages", type=int, default=1024)
+ap.add_argument("--width", type=int, default=2480)
+ap.add_argument("--height", type=int, default=3508)
+ap.add_argument("--channels", type=int, default=3)
+ap.add_argument("--window", type=int, default=31)
+ap.add_argument("--strength", type=float, default=10.0)
+ap.add_argument("--stages", type=int, default=1, help="also time the stages one by one on the first --stage-pages pages")
+ap.add_argument("--stage-pages", type=int, default=64)
+ap.add_argument("--check-pages", type=int, default=0, help="pages compared with the composed CPU oracle (slow: NL-means on the host)")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+t0 = time.perf_counter()
+pages, skews = synth.text_pages_torch(a.pages, a.height, a.width, dev, channels=a.channels)
+torch.cuda.synchronize()
+gen_s = time.perf_counter() - t0
+px_in = a.pages * a.width * a.height
+
+
+def timed(fn):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    r = fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t, r
+
+
+res = {"workload": f"{a.pages} x {a.width}x{a.height}x{a.channels} synthetic text scans (skew +-4 deg, shaded), 1 GPU, device resident; "
+                   f"deskew -> denoise({a.strength}) -> backgroundNormalization -> Sauvola w={a.window} k=0.34 morph=0 -> Zhang-Suen",
+       "generate_s": round(gen_s, 2)}
+if a.stages:
+    n = min(a.stage_pages, a.pages)
+    sub = pages[:n]
+    t_desk, (outs, ang) = timed(lambda: prlib_amd.deskew(sub))
+    sq = torch.stack([o for o in outs if o.shape[0] == o.shape[1] == max(a.width, a.height)]) if any(o.shape[0] == o.shape[1] for o in outs) else sub
+    m = sq.shape[0]
+    px_sq = m * sq.shape[1] * sq.shape[2]
+    t_den, den = timed(lambda: prlib_amd.denoise(sq, a.strength))
+    t_bg, bg = timed(lambda: prlib_amd.backgroundNormalization(den))
+    t_gray, g8 = timed(lambda: prlib_amd.cvtColorBGR2GRAY(bg))
+    t_bin, mask = timed(lambda: prlib_amd.binarizeSauvola(g8, a.window, 0.34, 0))
+    t_inv, inv = timed(lambda: prlib_amd.bitwise_not(mask))
+    t_thin, sk = timed(lambda: prlib_amd.thinZhangSuen(inv))
+    res["stages"] = {"pages": n, "rotated_pages": m, "deskew_ms": round(t_desk * 1e3, 1),
+                     "deskew_Mpx_s": round(n * a.width * a.height / t_desk / 1e6, 1),
+                     "denoise_ms": round(t_den * 1e3, 1), "denoise_Mpx_s": round(px_sq / t_den / 1e6, 1),
+                     "bgnorm_ms": round(t_bg * 1e3, 2), "bgnorm_Mpx_s": round(px_sq / t_bg / 1e6, 1),
+                     "bgr2gray_ms": round(t_gray * 1e3, 2), "sauvola_ms": round(t_bin * 1e3, 2),
+                     "invert_ms": round(t_inv * 1e3, 2), "thin_ms": round(t_thin * 1e3, 2),
+                     "angle_abs_err_deg_mean": round(float(np.abs(ang - skews[:n]).mean()), 3)}
+    del outs, sq, den, bg, g8, mask, inv, sk
+    torch.cuda.empty_cache()
+t_chain, (outs, angles) = timed(lambda: prlib_amd.process_pages(pages, a.channels, prlib_amd.SAUVOLA, a.window, 0.34, 0,
+                                                                denoise_strength=a.strength, thin=0, deskew=True,
+                                                                background_normalization=True))
+res.update({"chain_one_call_s": round(t_chain, 3), "chain_input_Mpx_s": round(px_in / t_chain / 1e6, 1),
+            "pages_per_s": round(a.pages / t_chain, 2),
+            "rotated_pages": int(sum(1 for o in outs if o.shape[0] == o.shape[1])),
+            "angle_abs_err_deg_mean": round(float(np.abs(angles - skews).mean()), 3),
+            "skeleton_fraction": round(float(np.mean([float((o > 0).float().mean()) for o in outs[:8]])), 5)})
+if a.check_pages:
+    from oracle import capi as oc
+    bad = 0
+    for i in np.linspace(0, a.pages - 1, a.check_pages).round().astype(int):
+        cur, info = oc.deskew(np.ascontiguousarray(pages[i].cpu().numpy()))
+        cur = oc.denoise(np.ascontiguousarray(cur), a.strength, threads=os.cpu_count() or 1)
+        cur = oc.bgnorm(np.ascontiguousarray(cur))
+        cur = oc.bgr2gray(np.ascontiguousarray(cur)) if cur.ndim == 3 else cur
+        mask = oc.binarize(np.ascontiguousarray(cur), oc.make_params(oc.SAUVOLA, a.window, 0.34, 0))
+        want = oc.thin(255 - mask, 0)
+        got = outs[i].cpu().numpy()
+        bad += int(got.shape != want.shape or (got != want).sum() or info["angle"] != angles[i])
+    res["parity"] = {"checked_pages": int(a.check_pages), "pages_with_any_difference": bad}
+print(json.dumps(res))
