@@ -1228,7 +1228,7 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     // wavefronts are independent; one per workgroup schedules best (256 x 4K pages: 4 per workgroup 4.38 ms, 2: 4.18,
     // 1: 4.13 - a finished wavefront's slot is refilled at once instead of when its whole workgroup has drained)
     unsigned wpb = 1u;
-    if (const char* e = std::getenv("PRL_HIP_WPB")) wpb = (unsigned)std::max(1, std::min(4, std::atoi(e)));
+    wpb = (unsigned)env_knobs().fused_wpb;
     if (fp.total_waves > 0x7fffff00u) wpb = std::max(wpb, 4u);  // grid.x is limited to 2^31 - 1 workgroups
     unsigned blocks = (fp.total_waves + wpb - 1) / wpb;
     blocks = (blocks + 7) / 8 * 8;
@@ -1392,7 +1392,7 @@ bool fused_supports(const ThrParams& tp)
 // only happen when Q >= 2^24 - 8 (w-1) 65025 =: Qmin, which turns the absolute bound into a relative one.
 static bool flt_usable(const ThrParams& tp, size_t src_step, double* cq, double* delta_out = nullptr, double* qmin_out = nullptr)
 {
-    if (const char* e = std::getenv("PRL_HIP_FLT")) if (e[0] == '0') return false;
+    if (!env_knobs().flt) return false;
     const int n1 = tp.w - 1;
     if (n1 > 30) return false;
     if ((unsigned long long)src_step * (unsigned long long)tp.height >= 0x7fffffffull) return false;  // 32-bit buffer offsets
@@ -1427,6 +1427,17 @@ size_t fused_small_bytes(int)
            sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(float) * kSegmaxCap;
 }
 
+// Pages one fused_run call may take.  Wolf-Jolion keeps one float per wavefront of the call (sweep A -> sweep B), kSegmaxCap
+// of them: a call's wavefronts = pages x strips x segments, with at most 128 rows per segment.
+int fused_max_pages(const ThrParams& tp)
+{
+    if (tp.method != PRL_WOLFJOLION) return 0x7fffffff;
+    const int uo = ((SW - (tp.w - 1)) / 8) * 8;
+    if (uo <= 0) return 0x7fffffff;  // not a fused configuration
+    const long long n_strips = (tp.ow + uo - 1) / uo, n_segs = (tp.oh + 127) / 128;
+    return (int)std::max<long long>(1, (long long)env_knobs().segmax_cap / (n_strips * n_segs));
+}
+
 // phase 0: the whole pipeline; 1: everything up to and including k_refine; 2: only the literal fix-up of the pixels
 // k_refine queued in an earlier phase-1 call with the same arguments (the caller reads PageGlobals::n_exact in between
 // and skips phase 2 - two launches and a 1 MB memset - when nothing was queued, the usual case)
@@ -1438,7 +1449,7 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.bit_out = bit_out ? 1 : 0;
     // non-temporal mask stores: the output stream is never re-read, and keeping it out of L2 leaves the cache to the
     // window rows that ARE re-read (the leaving row, the compared-pixel row): 4.31-4.47 -> 4.15 ms on 256 x 4K pages
-    fp.nt_store = (std::getenv("PRL_HIP_NT") && std::getenv("PRL_HIP_NT")[0] == '0') ? 0 : 1;
+    fp.nt_store = env_knobs().nt_store ? 1 : 0;
     fp.uo = ((SW - (tp.w - 1)) / 8) * 8;
     fp.n_strips = (tp.ow + fp.uo - 1) / fp.uo;
     // rows per segment: long segments amortise the (w-1)-row warm-up, short ones fill the chip
@@ -1454,7 +1465,9 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         while (min_rps < (tp.w - 1) / 4) min_rps *= 2;
         while (rps > min_rps && waves_at(rps) < 4096) rps /= 2;
     }
-    if (const char* e = std::getenv("PRL_HIP_ROWS_PER_SEG")) rps = std::max(16, std::atoi(e));  // tuning knob
+    if (env_knobs().rows_per_seg) rps = env_knobs().rows_per_seg;  // tuning knob
+    if (tp.method == PRL_WOLFJOLION)  // one sweep-A maximum per wavefront is kept: never more wavefronts than slots
+        while ((unsigned long long)waves_at(rps) > env_knobs().segmax_cap && rps < tp.oh) rps *= 2;
     fp.rows_per_seg = rps;
     fp.n_segs = (tp.oh + rps - 1) / rps;
     fp.lane_off = (tp.w - 1) / 8;
@@ -1517,7 +1530,10 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         // devianceMax first (binarizeWolfJolion.cpp:118-121): sweep A finds the float32 variance maximum,
         // sweep B revisits only the wavefront segments that can hold the literal maximum and queues their
         // candidate pixels, k_wolf_exact evaluates those literally, k_wolf_coeff forms k / devianceMax.
-        if (fp.total_waves > kSegmaxCap) return PRL_ERR_BAD_ARG;
+        if (fp.total_waves > env_knobs().segmax_cap) {  // (unreachable through the C ABI: its page chunks follow fused_max_pages)
+            set_error_detail("Wolf-Jolion: more wavefronts in one call than per-wavefront maxima slots");
+            return PRL_ERR_BAD_ARG;
+        }
         // (cv::minMaxLoc(imageInput) rides on sweep A - every window row a wavefront fetches goes into a running
         // minimum - plus a small kernel for the bottom rows / right columns the sweeps never fetch; Feng, which has no
         // sweep, uses k_page_min)
@@ -1540,7 +1556,7 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         PRL_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(k_wolf_final, dim3(16), dim3(256), 0, stream, fp, d_globals, cand, acc, cnt);
         PRL_HIP_CHECK(hipGetLastError());
-        if (std::getenv("PRL_HIP_DEBUG")) {
+        if (env_knobs().debug) {
             unsigned hc[4] = {0, 0, 0, 0};
             (void)hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, stream);
             (void)hipStreamSynchronize(stream);

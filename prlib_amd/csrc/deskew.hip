@@ -580,8 +580,7 @@ size_t deskew_gray_bytes(int width, int height) { return r256((size_t)width * he
 // pages per pass of prl::deskew: bounded by a workspace budget (mask + accumulator + point lists per page)
 int deskew_pages_per_pass(int n_pages, int width, int height)
 {
-    size_t budget = (size_t)24 << 30;
-    if (const char* e = std::getenv("PRL_HIP_DESKEW_WORK_MB")) budget = (size_t)std::max(64ll, std::atoll(e)) << 20;
+    const size_t budget = env_knobs().deskew_work_mb << 20;
     return (int)std::max<size_t>(1, std::min<size_t>({(size_t)n_pages, (size_t)16384, budget / ppht_bytes_per_page(width, height)}));
 }
 

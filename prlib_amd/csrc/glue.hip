@@ -304,9 +304,7 @@ int chain_uniform(const prl_chain_params* cp, int cnt, int channels, const uint8
 
 size_t chain_budget()
 {
-    size_t mb = 48 * 1024;  // intermediates of one pass (288 GB of HBM: big passes, few launches)
-    if (const char* e = std::getenv("PRL_HIP_CHAIN_WORK_MB")) mb = (size_t)std::max(16ll, std::atoll(e));
-    return mb << 20;
+    return env_knobs().chain_work_mb << 20;  // intermediates of one pass (default 48 GiB: 288 GB of HBM, big passes, few launches)
 }
 
 int chain_check(const prl_chain_params* cp, int n_pages, int channels, const uint8_t* d_src, size_t src_step, int width, int height,

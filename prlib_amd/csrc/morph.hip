@@ -647,12 +647,12 @@ int launch_morph_bits(int iterations, bool bitsrc, const PageSet& src, int n_pag
     int rps = 64;  // 256 x 4K pages: 64 rows per segment 1.18 ms, 128: 1.23, 256: 1.24, 512: 1.31
     // small batches: fill the chip first (one 4K page, closing 2: 0.082 -> 0.069 ms per call at 8 rows per segment)
     while (rps > 8 && (long long)n_pages * n_strips * ((height + rps - 1) / rps) < 16384) rps /= 2;
-    if (const char* e = std::getenv("PRL_MORPH_RPS")) rps = std::max(8, std::atoi(e));  // tuning knob
+    if (env_knobs().morph_rps) rps = env_knobs().morph_rps;  // tuning knob
     const int n_segs = (height + rps - 1) / rps;
     const unsigned long long tw = (unsigned long long)n_pages * n_strips * n_segs;
     if (tw >= 0xfffffff0ull) return PRL_ERR_BAD_ARG;
     // independent wavefronts: one per workgroup refills a finished slot at once (see launch_sweep in binarize_fused.hip)
-    const unsigned wpb = std::getenv("PRL_MORPH_WPB") ? (unsigned)std::max(1, std::min(4, std::atoi(std::getenv("PRL_MORPH_WPB")))) : 1u;
+    const unsigned wpb = (unsigned)env_knobs().morph_wpb;
     if ((tw + wpb - 1) / wpb > 0x7fffff00ull) return PRL_ERR_BAD_ARG;  // grid.x limit: the caller falls back
     const dim3 grid((unsigned)((tw + wpb - 1) / wpb)), block(64 * wpb);
 #define PRL_LAUNCH_BITS2(NV, OR1, BS)                                                                                  \

@@ -643,7 +643,7 @@ int launch_nlm(const PageSet& src_all, const PageSetOut& dst_all, int n_pages, c
         const dim3 grid((np.width + TILE_W - 1) / TILE_W, (np.height + TILE_H - 1) / TILE_H, cnt);
         if (CH <= 2) {
             constexpr int C = CH <= 2 ? CH : 1;
-            static const int xl_env = [] { const char* e = std::getenv("PRL_NLM_XL"); return e ? std::atoi(e) : 3; }();
+            const int xl_env = env_knobs().nlm_xl;
             const bool xl = np.n_lut <= kLutMaxXL && ((xl_env >> (C - 1)) & 1);
             if (xl) hipLaunchKernelGGL((k_nlm_y<C, true, true>), grid, dim3(256), 0, stream, src, dst, np);
             else if (lds_lut) hipLaunchKernelGGL((k_nlm_y<C, true>), grid, dim3(256), 0, stream, src, dst, np);

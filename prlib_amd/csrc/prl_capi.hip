@@ -13,6 +13,7 @@
 #include <thread>
 #include <mutex>
 #include <condition_variable>
+#include <atomic>
 
 #include "prl_internal.h"
 
@@ -37,12 +38,43 @@ thread_local LastCall t_last;
 
 std::mutex g_ctx_mu;
 std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
-int g_exec_mode = -1;  // -1: read PRL_HIP_MODE once
-bool g_profiling = false;
+std::atomic<int> g_exec_mode{-1};  // -1: take PRL_HIP_MODE
+std::atomic<bool> g_profiling{false};
 
 }  // namespace
 
 void set_error_detail(const std::string& s) { t_error_detail = s; }
+
+const EnvKnobs& env_knobs()
+{
+    static const EnvKnobs knobs = [] {
+        EnvKnobs k;
+        auto geti = [](const char* name, long long dflt) { const char* e = std::getenv(name); return e ? std::atoll(e) : dflt; };
+        auto is0 = [](const char* name) { const char* e = std::getenv(name); return e && e[0] == '0'; };
+        k.fused_wpb = (int)std::max(1ll, std::min(4ll, geti("PRL_HIP_WPB", 1)));
+        k.flt = !is0("PRL_HIP_FLT");
+        k.nt_store = !is0("PRL_HIP_NT");
+        k.rows_per_seg = (int)geti("PRL_HIP_ROWS_PER_SEG", 0);
+        if (k.rows_per_seg) k.rows_per_seg = std::max(16, k.rows_per_seg);
+        k.debug = std::getenv("PRL_HIP_DEBUG") != nullptr;
+        k.byte_mask = std::getenv("PRL_HIP_BYTE_MASK") != nullptr;
+        k.morph_rps = (int)geti("PRL_MORPH_RPS", 0);
+        if (k.morph_rps) k.morph_rps = std::max(8, k.morph_rps);
+        k.morph_wpb = (int)std::max(1ll, std::min(4ll, geti("PRL_MORPH_WPB", 1)));
+        k.thin_rps = (int)geti("PRL_THIN_RPS", 0);
+        if (k.thin_rps) k.thin_rps = std::max(4, k.thin_rps);
+        k.thin_wpb = (int)std::max(1ll, std::min(4ll, geti("PRL_THIN_WPB", 4)));
+        k.nlm_xl = (int)geti("PRL_NLM_XL", 3);
+        k.literal_scratch_mb = (size_t)std::max(64ll, geti("PRL_HIP_LITERAL_SCRATCH_MB", 8192));
+        k.deskew_work_mb = (size_t)std::max(64ll, geti("PRL_HIP_DESKEW_WORK_MB", 24576));
+        k.chain_work_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_WORK_MB", 49152));
+        k.segmax_cap = (unsigned)std::max(64ll, std::min(1ll << 20, geti("PRL_HIP_SEGMAX_CAP", 1 << 20)));
+        const char* m = std::getenv("PRL_HIP_MODE");
+        k.literal_mode = (m && std::strcmp(m, "literal") == 0) ? 1 : 0;
+        return k;
+    }();
+    return knobs;
+}
 
 int current_device(int* dev)
 {
@@ -301,20 +333,18 @@ namespace {
 
 int exec_mode()
 {
-    if (g_exec_mode < 0) {
-        const char* e = std::getenv("PRL_HIP_MODE");
-        g_exec_mode = (e && std::strcmp(e, "literal") == 0) ? PRL_MODE_LITERAL : PRL_MODE_AUTO;
+    int m = g_exec_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        m = env_knobs().literal_mode ? PRL_MODE_LITERAL : PRL_MODE_AUTO;
+        g_exec_mode.store(m, std::memory_order_relaxed);
     }
-    return g_exec_mode;
+    return m;
 }
 
 size_t literal_scratch_budget()
 {
     // bytes of float64 integral scratch the literal pipeline may hold at once (default 8 GiB)
-    const char* e = std::getenv("PRL_HIP_LITERAL_SCRATCH_MB");
-    size_t mb = e ? (size_t)std::strtoull(e, nullptr, 10) : 8192;
-    if (mb < 64) mb = 64;
-    return mb << 20;
+    return env_knobs().literal_scratch_mb << 20;
 }
 
 // Argument checks in the reference's order: empty (binarizeSauvola.cpp:38-41), window (:43-47).
@@ -444,7 +474,7 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
     // With morphology the thresholded mask goes to a scratch buffer first, then the morph kernel writes dst.  When the
     // fused kernel runs and the radius allows it, that buffer is a BIT plane (1/8 B per pixel written and re-read
     // instead of 1 B): [bit planes of all pages][one byte page for a literal redo of an overflowing page].
-    const bool bit_mask = use_fused && morph != 0 && std::abs(morph) <= morph_bits_max_radius() && !std::getenv("PRL_HIP_BYTE_MASK");
+    const bool bit_mask = use_fused && morph != 0 && std::abs(morph) <= morph_bits_max_radius() && !env_knobs().byte_mask;
     const size_t bit_step = ((size_t)g.out_w + 127) / 128 * 16;
     const size_t bit_page = (bit_step * (size_t)g.out_h + 255) / 256 * 256;
     PageSetOut thr_dst = dst;
@@ -468,7 +498,7 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ctx->prof_valid = false;
-    if (g_profiling) {
+    if (g_profiling.load()) {
         if (!ctx->prof_start) {
             PRL_HIP_CHECK(hipEventCreate(&ctx->prof_start));
             PRL_HIP_CHECK(hipEventCreate(&ctx->prof_stop));
@@ -562,6 +592,16 @@ using namespace prl_hip;
 
 namespace {
 constexpr int kMaxPagesPerLaunch = 32768;
+
+// Pages one binarize_common call takes: several kernels keep the page index in a grid dimension limited to 65535, and
+// Wolf-Jolion stores one maximum per wavefront of a call (fused_max_pages).  Longer batches go in chunks.
+int pages_per_call(const prl_binarize_params* p, int width, int height)
+{
+    prl_binarize_geometry g;
+    if (prl_hip::geometry_impl(p, width, height, &g) != PRL_OK) return kMaxPagesPerLaunch;  // the error surfaces in binarize_common
+    const ThrParams tp = prl_hip::make_thr_params(p, g, width, height);
+    return std::max(1, std::min(kMaxPagesPerLaunch, fused_max_pages(tp)));
+}
 }
 
 extern "C" {
@@ -613,7 +653,7 @@ int prl_hip_set_device(int device)
 int prl_hip_set_exec_mode(int mode)
 {
     if (mode != PRL_MODE_AUTO && mode != PRL_MODE_LITERAL) return PRL_ERR_BAD_ARG;
-    g_exec_mode = mode;
+    g_exec_mode.store(mode);
     return PRL_OK;
 }
 
@@ -621,7 +661,7 @@ int prl_hip_get_exec_mode(void) { return exec_mode(); }
 
 int prl_hip_set_profiling(int enabled)
 {
-    g_profiling = enabled != 0;
+    g_profiling.store(enabled != 0);
     return PRL_OK;
 }
 
@@ -734,10 +774,10 @@ int prl_hip_binarize_batch_device(const prl_binarize_params* p, int n_pages, con
     d.base = d_dst;
     d.page_stride = dst_page_stride;
     d.step = dst_step;
-    // several kernels put the page index in a grid dimension limited to 65535: longer batches go in chunks
     // (prl_hip_last_stats then describes the last chunk)
-    for (int first = 0; first < n_pages || first == 0; first += kMaxPagesPerLaunch) {
-        const int cnt = std::min(kMaxPagesPerLaunch, n_pages - first);
+    const int per_call = pages_per_call(p, width, height);
+    for (int first = 0; first < n_pages || first == 0; first += per_call) {
+        const int cnt = std::min(per_call, n_pages - first);
         PageSet sc = s;
         PageSetOut dc = d;
         sc.base = d_src ? d_src + (size_t)first * src_page_stride : nullptr;
@@ -757,8 +797,9 @@ int prl_hip_binarize_pages_device(const prl_binarize_params* p, int n_pages,
     s.step = src_step;
     PageSetOut d{};
     d.step = dst_step;
-    for (int first = 0; first < n_pages || first == 0; first += kMaxPagesPerLaunch) {
-        const int cnt = std::min(kMaxPagesPerLaunch, n_pages - first);
+    const int per_call = pages_per_call(p, width, height);
+    for (int first = 0; first < n_pages || first == 0; first += per_call) {
+        const int cnt = std::min(per_call, n_pages - first);
         const int st = binarize_common(p, cnt, s, width, height, d, d_src_pages ? d_src_pages + first : nullptr,
                                        d_dst_pages ? d_dst_pages + first : nullptr, static_cast<hipStream_t>(stream));
         if (st != PRL_OK || n_pages <= 0) return st;

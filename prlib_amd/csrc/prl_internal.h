@@ -54,6 +54,25 @@ struct DeviceCtx {
     hipEvent_t last_use = nullptr;  // recorded after each call; the next call's stream waits on it
 };
 
+// Tuning / debugging knobs of the PRL_* environment variables, read ONCE (first use) instead of on every call.
+struct EnvKnobs {
+    int fused_wpb = 1;            // PRL_HIP_WPB          wavefronts per workgroup of k_fused (1..4)
+    bool flt = true;              // PRL_HIP_FLT=0        forces the integer sum pipeline everywhere
+    bool nt_store = true;         // PRL_HIP_NT=0         plain instead of non-temporal mask stores
+    int rows_per_seg = 0;         // PRL_HIP_ROWS_PER_SEG (0 = chosen from the batch size)
+    bool debug = false;           // PRL_HIP_DEBUG
+    bool byte_mask = false;       // PRL_HIP_BYTE_MASK    byte instead of bit-plane hand-off to the morphology pass
+    int morph_rps = 0, morph_wpb = 1;   // PRL_MORPH_RPS, PRL_MORPH_WPB
+    int thin_rps = 0, thin_wpb = 4;     // PRL_THIN_RPS, PRL_THIN_WPB
+    int nlm_xl = 3;               // PRL_NLM_XL
+    size_t literal_scratch_mb = 8192;   // PRL_HIP_LITERAL_SCRATCH_MB
+    size_t deskew_work_mb = 24576;      // PRL_HIP_DESKEW_WORK_MB
+    size_t chain_work_mb = 49152;       // PRL_HIP_CHAIN_WORK_MB
+    unsigned segmax_cap = 1u << 20;     // PRL_HIP_SEGMAX_CAP   wavefronts per Wolf-Jolion call (tests shrink it)
+    int literal_mode = 0;         // PRL_HIP_MODE=literal
+};
+const EnvKnobs& env_knobs();
+
 int current_device(int* dev);             // validates that a gfx950 device is usable
 DeviceCtx* device_ctx(int dev);
 int ensure_scratch(DeviceCtx* ctx, size_t bytes);
@@ -130,6 +149,7 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
               void* small, PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start,
               hipEvent_t ev_stop, bool bit_out = false, int phase = 0);
 bool fused_supports(const ThrParams& tp);
+int fused_max_pages(const ThrParams& tp);  // pages one fused_run call can take (Wolf-Jolion: per-wavefront maxima storage)
 
 // ---- thinning (thin.hip): the C entry plus the option to thin cv::bitwise_not of the source (chain glue) ------
 int thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step, int width,

@@ -317,7 +317,7 @@ int thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_
     const int n_strips = (wpr + kThinUseful - 1) / kThinUseful;
     int rps = 256;  // measured (16 A4 pages): 32 rows 31 us per pass, 16: 26, 8: 26, 4: 31
     while (rps > 16 && (long long)n_pages * n_strips * ((height + rps - 1) / rps) < 16384) rps /= 2;
-    if (const char* e = std::getenv("PRL_THIN_RPS")) rps = std::max(4, std::atoi(e));
+    if (env_knobs().thin_rps) rps = env_knobs().thin_rps;
     const int n_segs = (height + rps - 1) / rps;
     const unsigned long long tw = (unsigned long long)n_pages * n_strips * n_segs;
     if (tw >= 0xfffffff0ull) return PRL_ERR_BAD_ARG;
@@ -352,7 +352,7 @@ int thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_
     unsigned* h_done = static_cast<unsigned*>(ctx->pinned);
     const int max_passes = std::max(width, height) + 2;  // every effective pass removes at least one pixel layer
     int group = 4;  // passes per host check, doubled each time (a pass over converged pages / idle tiles is nearly free)
-    const unsigned wpb = std::getenv("PRL_THIN_WPB") ? (unsigned)std::max(1, std::min(4, std::atoi(std::getenv("PRL_THIN_WPB")))) : 4u;
+    const unsigned wpb = (unsigned)env_knobs().thin_wpb;
     const dim3 gp((unsigned)((tw + wpb - 1) / wpb)), bp(64 * wpb);  // short wavefronts: 4 per workgroup measured best (26.1 vs 28.4 us)
     // Passes alternate A -> B -> A.  The pass that finds a page unchanged has just written a copy of its input, so
     // from then on BOTH buffers hold that page's final plane (later passes skip it): k_thin_unpack can always read A.

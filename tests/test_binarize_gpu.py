@@ -4,10 +4,13 @@ Integer/byte output => the bar is 0 mismatching pixels.  Cases follow SURVEY.md 
 synthetic pages, odd/even sizes, ragged (non-multiple-of-tile) sizes, window clamping, all five
 methods, morphology in both directions, flat/black/white/binary pages, and both execution modes.
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SAUVOLA, NIBLACK, WOLFJOLION, NICK, FENG = range(5)
 
@@ -396,3 +399,30 @@ def test_float_pipeline_at_the_largest_sums(prl, oracle, cuda_device, method, wi
     stripes = (stripes.astype(np.int16) - rng.integers(0, 3, (h, w))).clip(0, 255).astype(np.uint8)
     k = {SAUVOLA: 0.34, NIBLACK: -0.2, WOLFJOLION: 0.3, NICK: -0.1, FENG: 0.2}[method]
     _check(prl, oracle, cuda_device, [white, checker, halves, stripes], method, win, k, 0)
+
+
+def test_wolfjolion_batches_larger_than_the_per_call_wavefront_budget(cuda_device):
+    """Wolf-Jolion keeps one maximum per wavefront of a call (2^20 slots); a batch with more wavefronts used
+    to be rejected with PRL_ERR_BAD_ARG.  The C ABI now cuts such batches into page chunks (fused_max_pages).  The slot
+    count is shrunk to 64 in a child process (PRL_HIP_SEGMAX_CAP is read once per process) so that 12 small pages need
+    several chunks."""
+    import subprocess
+    import sys
+
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import prlib_amd
+from oracle import capi as oc
+from prlib_amd import synth
+pages = np.stack([synth.page_numpy(200, 1300, index=i) for i in range(12)])
+p = prlib_amd.make_params(prlib_amd.WOLFJOLION, 31, 0.3, 0)
+got = prlib_amd.binarize(torch.from_numpy(pages).cuda(), p).cpu().numpy()
+po = oc.make_params(oc.WOLFJOLION, 31, 0.3, 0)
+bad = sum(int((got[i] != oc.binarize(pages[i], po)).sum()) for i in range(12))
+print("MISMATCH", bad)
+''' % ROOT
+    env = dict(os.environ, PRL_HIP_SEGMAX_CAP="64")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "MISMATCH 0" in r.stdout, r.stdout + r.stderr
