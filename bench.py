@@ -156,7 +156,12 @@ def main():
     def step():
         prlib_amd.binarize(pages, params, out=out)
 
+    # the device entry point only enqueues (deferred completion): the K steps of the timed region pipeline on the stream
+    # and prl_hip_finish - flag check of every call + stream wait - closes the region on every rank
+    prlib_amd.set_deferred_completion(True)
+
     def barrier():
+        prlib_amd.finish(dev)
         torch.cuda.synchronize(dev)
         pdist.barrier()
 

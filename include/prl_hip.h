@@ -119,6 +119,11 @@ int         prl_hip_release_workspace(void);           /* free cached device scr
  * is launched on; prl_hip_last_kernel_ms() waits for them and returns the elapsed milliseconds. */
 int         prl_hip_set_profiling(int enabled);
 int         prl_hip_last_kernel_ms(float* ms);
+/* Deferred completion of prl_hip_binarize_*_device (process-wide switch, default off): see the comment there. */
+int         prl_hip_set_deferred_completion(int enabled);
+/* Completes every binarize call enqueued on `stream` of the current device (flag check, literal redo of overflowing
+ * pages) and waits for the stream.  Cheap when nothing is pending. */
+int         prl_hip_finish(void* stream);
 
 /* ---- binarizers -------------------------------------------------------------------------- */
 
@@ -133,7 +138,14 @@ int prl_hip_binarize_geometry(const prl_binarize_params* p, int width, int heigh
  *   d_src        first page; page i starts at d_src + i*src_page_stride
  *   d_dst        first output page (out_w x out_h, see prl_hip_binarize_geometry); values {0,255}
  *   stream       hipStream_t or NULL
- * Enqueues on `stream`; synchronises only if a page needs the literal pipeline.
+ * Everything is enqueued on `stream` (threshold sweep, interval refinement, literal fix-up - the last two find their
+ * work lists on the device and do nothing when they are empty - and the morphology pass).  One thing needs the host:
+ * a page with more than 2^14 pixels within ~1e-6 of their threshold (pathological input) is flagged and redone by the
+ * literal pipeline.  Default: the call waits for its own work once, looks at the flags and returns with the result
+ * complete.  With prl_hip_set_deferred_completion(1) it returns right after enqueuing; the flags are looked at later
+ * (a later call that needs the slot, prl_hip_last_stats, prl_hip_finish), so the caller must call
+ * prl_hip_finish(stream) before consuming the masks.  Calls on different streams of a device use separate
+ * workspaces and overlap.
  * Replaces the body of prl::binarize{Sauvola,Niblack,WolfJolion,NICK,Feng} after cvtColor.
  */
 int prl_hip_binarize_batch_device(const prl_binarize_params* p, int n_pages,

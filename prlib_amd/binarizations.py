@@ -71,6 +71,21 @@ def last_stats() -> BinarizeStats:
     return s
 
 
+def set_deferred_completion(enabled: bool) -> None:
+    """prl_hip_set_deferred_completion: binarize calls return right after enqueuing; call finish() before using the masks."""
+    _capi.check(_capi.lib().prl_hip_set_deferred_completion(1 if enabled else 0))
+
+
+def finish(device=None) -> None:
+    """prl_hip_finish on torch's current stream of `device` (default: the current device)."""
+    import torch
+
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    L = _capi.lib()
+    _capi.check(L.prl_hip_set_device(dev.index or 0))
+    _capi.check(L.prl_hip_finish(torch.cuda.current_stream(dev).cuda_stream))
+
+
 def set_exec_mode(mode: int) -> None:
     _capi.check(_capi.lib().prl_hip_set_exec_mode(mode))
 

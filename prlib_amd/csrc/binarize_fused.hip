@@ -60,6 +60,9 @@ struct WorkItem {  // undecided after the float64 interval test
     int page, y, x;
     int pad;
 };
+struct CornerAcc {   // absolute integral corners of a queued pixel, accumulated by k_corner_partial
+    unsigned long long a[8];  // [0..3] sums of P over top-left, top-right, bottom-left, bottom-right; [4..7] of P*P
+};
 
 // pseudo-methods of the two extra Wolf-Jolion sweeps (max deviation search)
 constexpr int kWolfMax = 100;      // sweep A: float32 variance maximum per page and per wavefront
@@ -967,7 +970,7 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
 template <int METHOD>
 __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, FusedParams fp, PageGlobals* __restrict__ g,
                                                const RefItem* __restrict__ rl, WorkItem* __restrict__ wl,
-                                               unsigned* __restrict__ counters)
+                                               unsigned* __restrict__ counters, CornerAcc* __restrict__ acc)
 {
     const unsigned n = min(counters[0], fp.ref_cap);
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
@@ -1011,6 +1014,8 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
                 w.x = it.x;
                 w.pad = 0;
                 wl[idx] = w;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[idx].a[k] = 0ull;  // (instead of a 1 MB memset per call: nothing is queued as a rule)
             } else {
                 atomicOr(&g[it.page].worklist_overflow, 1u);
             }
@@ -1031,9 +1036,6 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
 // weighted by how many padded rows/columns replicate it.  Integer arithmetic: exact.
 constexpr int kSplit = 64;  // workgroups per queued pixel: the row loop of a wavefront is a chain of dependent loads, so the
                             // parallelism has to come from the grid (16 -> 64: Wolf-Jolion's candidate pass 0.35 -> see DESIGN 4.2)
-struct CornerAcc {
-    unsigned long long a[8];  // [0..3] sums of P over top-left, top-right, bottom-left, bottom-right; [4..7] of P*P
-};
 
 // number of padded indices i in [lo, hi] that replicate-clamp to page index r (page size n, padding h)
 __device__ __forceinline__ int pad_count(int lo, int hi, int r, int n, int h)
@@ -1262,10 +1264,11 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     int st = launch_sweep<METHOD>(sh, stream, src, dst, fp, g, rl, cand, cnt);
     if (st != PRL_OK) return st;
     if (ev_stop) PRL_HIP_CHECK(hipEventRecord(ev_stop, stream));
-    hipLaunchKernelGGL((k_refine<METHOD>), dim3(fp.flt ? 1024 : 64), dim3(256), 0, stream, src, dst, fp, g, rl, wl, cnt);
+    hipLaunchKernelGGL((k_refine<METHOD>), dim3(fp.flt ? 1024 : 64), dim3(256), 0, stream, src, dst, fp, g, rl, wl, cnt, acc);
     PRL_HIP_CHECK(hipGetLastError());
-    if (!with_fixup) return PRL_OK;  // the caller runs the literal fix-up (phase 2) only if k_refine left pixels for it
-    PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, stream));
+    if (!with_fixup) return PRL_OK;
+    // literal fix-up of what k_refine queued: both kernels read the queue length on the device and do nothing when it is
+    // empty (the usual case), so no host round trip decides whether they run; k_refine zeroed the accumulators it uses
     hipLaunchKernelGGL(k_corner_partial, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc);
     PRL_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_fixup_final, dim3(16), dim3(256), 0, stream, src, dst, fp, g, wl, acc, cnt);

@@ -298,6 +298,8 @@ int chain_uniform(const prl_chain_params* cp, int cnt, int channels, const uint8
         return prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, out, dst_ps, dst_step, stream);
     st = prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, w, l.mask, (size_t)g.out_w, stream);
     if (st != PRL_OK) return st;
+    st = prl_hip_finish(stream);  // (deferred-completion mode: the mask is final before it is thinned)
+    if (st != PRL_OK) return st;
     // cv::bitwise_not between the two stages happens inside the thinning's bit packing (no pass of its own)
     return prl_hip::thin_batch_device(cp->thin, cnt, w, l.mask, (size_t)g.out_w, g.out_w, g.out_h, out, dst_ps, dst_step, stream, true);
 }

@@ -29,9 +29,7 @@ thread_local int t_device = -1;  // -1: follow hipGetDevice()
 struct LastCall {
     int device = -1;
     hipStream_t stream = nullptr;
-    int n_pages = 0;
-    uint64_t pixels = 0;
-    uint64_t literal_pages = 0;
+    uint64_t seq = 0;       // which call of that stream's workspace
     bool valid = false;
 };
 thread_local LastCall t_last;
@@ -40,6 +38,7 @@ std::mutex g_ctx_mu;
 std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
 std::atomic<int> g_exec_mode{-1};  // -1: take PRL_HIP_MODE
 std::atomic<bool> g_profiling{false};
+std::atomic<bool> g_deferred{false};  // prl_hip_set_deferred_completion
 
 }  // namespace
 
@@ -75,6 +74,93 @@ const EnvKnobs& env_knobs()
     }();
     return knobs;
 }
+
+
+// ---- per-(device, stream) workspace of the binarizers -------------------------------------------------------------
+// Calls on different streams of one device share nothing (so they overlap); calls on one stream are ordered by the
+// stream.  The per-page flags of a PRL_MODE_AUTO call (queue overflow -> the page must be redone literally; counters
+// for prl_hip_last_stats) are copied into a pinned slot and looked at LATER: at once in the default mode, lazily
+// (next call that needs the slot, prl_hip_last_stats, prl_hip_finish) with prl_hip_set_deferred_completion(1).
+constexpr int kSlots = 4;
+
+struct PendingCall {
+    int slot = -1;
+    bool has_flags = false;   // (literal-mode calls only hold their slot for the page tables)
+    uint64_t seq = 0;
+    prl_binarize_params params{};
+    int width = 0, height = 0, n_pages = 0;
+    PageSet src{};            // base / stride form (table == nullptr) ...
+    PageSetOut dst{};
+    std::vector<const uint8_t*> src_tab;  // ... or host copies of the page tables
+    std::vector<uint8_t*> dst_tab;
+    uint64_t pixels = 0;
+};
+
+struct CallStats {
+    uint64_t seq = 0, pixels = 0, refined = 0, exact = 0, literal_pages = 0;
+};
+
+struct StreamWs {
+    std::mutex mu;            // enqueue / resolve on this stream's workspace
+    hipStream_t stream = nullptr;
+    void* small = nullptr; size_t small_bytes = 0;      // globals, tables, fused work area
+    void* mask = nullptr; size_t mask_bytes = 0;        // thresholded masks waiting for the morphology pass
+    void* scratch = nullptr; size_t scratch_bytes = 0;  // literal pipeline
+    void* pinned = nullptr; size_t slot_bytes = 0;      // kSlots x [src table][dst table][PageGlobals]
+    hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    int next_slot = 0;
+    uint64_t seq = 0;
+    std::deque<PendingCall> pending;
+    CallStats last;           // the most recent call whose numbers are known
+    hipEvent_t prof_start = nullptr, prof_stop = nullptr;
+    bool prof_valid = false;
+};
+
+int ws_grow(void** p, size_t* cur, size_t need, hipStream_t stream, size_t floor_bytes = 0)
+{
+    if (*cur >= need) return PRL_OK;
+    if (*p) {
+        PRL_HIP_CHECK(hipStreamSynchronize(stream));  // kernels of this stream may still use the old block
+        PRL_HIP_CHECK(hipFree(*p));
+        *p = nullptr;
+        *cur = 0;
+    }
+    need = std::max(need, floor_bytes);
+    PRL_HIP_CHECK(hipMalloc(p, need));
+    *cur = need;
+    return PRL_OK;
+}
+
+StreamWs* stream_ws(DeviceCtx* ctx, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto& p = ctx->streams[stream];
+    if (!p) {
+        p.reset(new StreamWs());
+        p->stream = stream;
+    }
+    return p.get();
+}
+
+void ws_free(StreamWs* ws)
+{
+    if (ws->small) (void)hipFree(ws->small);
+    if (ws->mask) (void)hipFree(ws->mask);
+    if (ws->scratch) (void)hipFree(ws->scratch);
+    if (ws->pinned) (void)hipHostFree(ws->pinned);
+    for (auto& e : ws->ev) if (e) (void)hipEventDestroy(e);
+    if (ws->prof_start) (void)hipEventDestroy(ws->prof_start);
+    if (ws->prof_stop) (void)hipEventDestroy(ws->prof_stop);
+    ws->small = ws->mask = ws->scratch = ws->pinned = nullptr;
+    ws->small_bytes = ws->mask_bytes = ws->scratch_bytes = ws->slot_bytes = 0;
+    for (auto& e : ws->ev) e = nullptr;
+    ws->prof_start = ws->prof_stop = nullptr;
+    ws->prof_valid = false;
+    ws->pending.clear();
+    ws->next_slot = 0;
+}
+
+DeviceCtx::~DeviceCtx() = default;  // (process teardown: the driver reclaims device memory)
 
 int current_device(int* dev)
 {
@@ -397,6 +483,129 @@ ThrParams make_thr_params(const prl_binarize_params* p, const prl_binarize_geome
     return tp;
 }
 
+size_t r256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct SlotLayout {
+    size_t table_bytes, globals_bytes, total;
+};
+SlotLayout slot_layout(int n_pages)
+{
+    SlotLayout l;
+    l.table_bytes = r256(sizeof(void*) * (size_t)n_pages);
+    l.globals_bytes = r256(sizeof(PageGlobals) * (size_t)n_pages);
+    l.total = 2 * l.table_bytes + l.globals_bytes;
+    return l;
+}
+
+// One overflowing page of a PRL_MODE_AUTO call, redone by the literal pipeline (and its morphology pass) from the
+// caller's own source page into the caller's destination page.  Pathological inputs only (more than 2^14 pixels of a
+// call within ~1e-6 of their threshold).
+int redo_page_literal(StreamWs* ws, const PendingCall& pc, int i)
+{
+    prl_binarize_geometry g;
+    int st = geometry_impl(&pc.params, pc.width, pc.height, &g);
+    if (st != PRL_OK) return st;
+    const ThrParams tp = make_thr_params(&pc.params, g, pc.width, pc.height);
+    const int morph = pc.params.morph_iterations;
+    const size_t lit = r256(literal_scratch_per_page(tp));
+    const size_t mask_step = ((size_t)g.out_w + 63) / 64 * 64, mask_page = r256(mask_step * (size_t)g.out_h);
+    // [literal integral planes][PageGlobals][byte mask (morph != 0)][second buffer for large radii]
+    st = ws_grow(&ws->scratch, &ws->scratch_bytes, lit + 256 + 2 * mask_page, ws->stream);
+    if (st != PRL_OK) return st;
+    auto* base = static_cast<uint8_t*>(ws->scratch);
+    auto* d_g = reinterpret_cast<PageGlobals*>(base + lit);
+    uint8_t* d_mask = base + lit + 256;
+    PageSet one{};
+    one.base = pc.src_tab.empty() ? pc.src.base + (size_t)i * pc.src.page_stride : pc.src_tab[(size_t)i];
+    one.step = pc.src.step;
+    PageSetOut out{};
+    out.base = pc.dst_tab.empty() ? pc.dst.base + (size_t)i * pc.dst.page_stride : pc.dst_tab[(size_t)i];
+    out.step = pc.dst.step;
+    st = init_globals_run(d_g, 1, ws->stream);
+    if (st != PRL_OK) return st;
+    if (tp.method == PRL_WOLFJOLION || tp.method == PRL_FENG) {
+        st = page_min_run(tp, one, 1, d_g, ws->stream);
+        if (st != PRL_OK) return st;
+    }
+    PageSetOut thr = out;
+    if (morph != 0) {
+        thr = PageSetOut{};
+        thr.base = d_mask;
+        thr.step = mask_step;
+    }
+    st = literal_run(tp, one, 0, 1, thr, ws->scratch, d_g, ws->stream);
+    if (st != PRL_OK || morph == 0) return st;
+    PageSet msrc{};
+    msrc.base = d_mask;
+    msrc.step = mask_step;
+    if (std::abs(morph) <= kMorphMaxFusedRadius) return morph_binary_run(morph, msrc, 1, g.out_w, g.out_h, out, ws->stream);
+    return morph_large_run(morph, msrc, 1, g.out_w, g.out_h, out, d_mask + mask_page, mask_step, ws->stream);
+}
+
+// Look at the flags of the oldest pending call (waits for that call's work): statistics, literal redo of overflow pages.
+int resolve_front(StreamWs* ws)
+{
+    PendingCall pc = std::move(ws->pending.front());
+    ws->pending.pop_front();
+    PRL_HIP_CHECK(hipEventSynchronize(ws->ev[pc.slot]));
+    if (!pc.has_flags) return PRL_OK;
+    const SlotLayout l = slot_layout(pc.n_pages);
+    const auto* hg = reinterpret_cast<const PageGlobals*>(static_cast<uint8_t*>(ws->pinned) + (size_t)pc.slot * ws->slot_bytes +
+                                                          2 * l.table_bytes);
+    CallStats cs;
+    cs.seq = pc.seq;
+    cs.pixels = pc.pixels;
+    int st = PRL_OK;
+    for (int i = 0; i < pc.n_pages; ++i) {
+        cs.refined += hg[(size_t)i].n_refined;
+        cs.exact += hg[(size_t)i].n_exact;
+        if (hg[(size_t)i].worklist_overflow) {
+            cs.literal_pages += 1;
+            if (st == PRL_OK) st = redo_page_literal(ws, pc, i);
+        }
+    }
+    ws->last = cs;
+    return st;
+}
+
+int resolve_all(StreamWs* ws)
+{
+    int st = PRL_OK;
+    while (!ws->pending.empty()) {
+        const int s2 = resolve_front(ws);
+        if (st == PRL_OK) st = s2;
+    }
+    return st;
+}
+
+// A pinned slot for this call: [src table][dst table][flags].  Slots are recycled in order; a slot still referenced
+// by an unresolved call is resolved first.
+int take_slot(StreamWs* ws, int n_pages, int* slot)
+{
+    const SlotLayout l = slot_layout(n_pages);
+    if (ws->slot_bytes < l.total) {
+        int st = resolve_all(ws);
+        if (st != PRL_OK) return st;
+        if (ws->pinned) {
+            PRL_HIP_CHECK(hipStreamSynchronize(ws->stream));
+            PRL_HIP_CHECK(hipHostFree(ws->pinned));
+            ws->pinned = nullptr;
+            ws->slot_bytes = 0;
+        }
+        const size_t bytes = std::max<size_t>(l.total, 1 << 14);
+        PRL_HIP_CHECK(hipHostMalloc(&ws->pinned, bytes * kSlots, hipHostMallocDefault));
+        ws->slot_bytes = bytes;
+    }
+    while ((int)ws->pending.size() >= kSlots) {
+        int st = resolve_front(ws);
+        if (st != PRL_OK) return st;
+    }
+    *slot = ws->next_slot;
+    ws->next_slot = (ws->next_slot + 1) % kSlots;
+    if (!ws->ev[*slot]) PRL_HIP_CHECK(hipEventCreateWithFlags(&ws->ev[*slot], hipEventDisableTiming));
+    return PRL_OK;
+}
+
 int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int width, int height,
                     PageSetOut dst, const uint8_t* const* h_src_tab, uint8_t* const* h_dst_tab,
                     hipStream_t stream)
@@ -414,75 +623,79 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
     st = current_device(&dev);
     if (st != PRL_OK) return st;
     DeviceCtx* ctx = device_ctx(dev);
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    StreamWs* ws = stream_ws(ctx, stream);
+    std::lock_guard<std::mutex> lk(ws->mu);
 
     const ThrParams tp = make_thr_params(p, g, width, height);
 
-    // the scratch areas are shared by every stream of this device: order this call after the last one
-    if (!ctx->last_use)
-        PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
-    else
-        PRL_HIP_CHECK(hipStreamWaitEvent(stream, ctx->last_use, 0));
-
     // small device area: [PageGlobals x n][src table][dst table][fused work area]
-    const size_t globals_bytes = ((sizeof(PageGlobals) * (size_t)n_pages + 255) / 256) * 256;
-    const size_t table_bytes = ((sizeof(void*) * (size_t)n_pages + 255) / 256) * 256;
+    const SlotLayout sl = slot_layout(n_pages);
     const size_t fused_bytes = fused_small_bytes(n_pages);
-    st = ensure_small(ctx, globals_bytes + 2 * table_bytes + fused_bytes);
+    st = ws_grow(&ws->small, &ws->small_bytes, sl.globals_bytes + 2 * sl.table_bytes + fused_bytes, stream, 1 << 20);
     if (st != PRL_OK) return st;
-    ctx->lut_small[0] = ctx->lut_small[1] = nullptr;  // this call overwrites the area the NL-means tables live in
-    auto* small = static_cast<uint8_t*>(ctx->small);
+    auto* small = static_cast<uint8_t*>(ws->small);
     auto* d_globals = reinterpret_cast<PageGlobals*>(small);
-    auto* d_src_tab = reinterpret_cast<const uint8_t**>(small + globals_bytes);
-    auto* d_dst_tab = reinterpret_cast<uint8_t**>(small + globals_bytes + table_bytes);
-    void* d_fused = small + globals_bytes + 2 * table_bytes;
-
-    if (h_src_tab || h_dst_tab) {
-        st = ensure_pinned(ctx, 2 * table_bytes + globals_bytes);
-        if (st != PRL_OK) return st;
-        auto* pin = static_cast<uint8_t*>(ctx->pinned);
-        // the pinned staging area is reused by the next call: wait for earlier copies out of it
-        PRL_HIP_CHECK(hipStreamSynchronize(stream));
-        if (h_src_tab) {
-            std::memcpy(pin, h_src_tab, sizeof(void*) * (size_t)n_pages);
-            PRL_HIP_CHECK(hipMemcpyAsync(d_src_tab, pin, sizeof(void*) * (size_t)n_pages,
-                                         hipMemcpyHostToDevice, stream));
-            src.table = d_src_tab;
-        }
-        if (h_dst_tab) {
-            std::memcpy(pin + table_bytes, h_dst_tab, sizeof(void*) * (size_t)n_pages);
-            PRL_HIP_CHECK(hipMemcpyAsync(d_dst_tab, pin + table_bytes, sizeof(void*) * (size_t)n_pages,
-                                         hipMemcpyHostToDevice, stream));
-            dst.table = d_dst_tab;
-        }
-    }
-
-    // With morphology the thresholded mask goes to scratch first, then the morph kernel writes dst.
-    const size_t mask_step = ((size_t)g.out_w + 63) / 64 * 64;
-    const size_t mask_page = mask_step * (size_t)g.out_h;
-    const size_t mask_bytes = morph != 0 ? mask_page * (size_t)n_pages : 0;
+    auto* d_src_tab = reinterpret_cast<const uint8_t**>(small + sl.globals_bytes);
+    auto* d_dst_tab = reinterpret_cast<uint8_t**>(small + sl.globals_bytes + sl.table_bytes);
+    void* d_fused = small + sl.globals_bytes + 2 * sl.table_bytes;
 
     const bool use_fused = exec_mode() == PRL_MODE_AUTO && fused_supports(tp);
+    const bool need_slot = use_fused || h_src_tab || h_dst_tab;
+    int slot = -1;
+    uint8_t* pin = nullptr;
+    if (need_slot) {
+        st = take_slot(ws, n_pages, &slot);
+        if (st != PRL_OK) return st;
+        pin = static_cast<uint8_t*>(ws->pinned) + (size_t)slot * ws->slot_bytes;
+    }
+    PendingCall pc;
+    pc.slot = slot;
+    pc.has_flags = use_fused;
+    pc.seq = ++ws->seq;
+    pc.params = *p;
+    pc.width = width;
+    pc.height = height;
+    pc.n_pages = n_pages;
+    pc.src = src;
+    pc.dst = dst;
+    pc.pixels = (uint64_t)g.out_w * g.out_h * (uint64_t)n_pages;
+    if (h_src_tab) {
+        pc.src_tab.assign(h_src_tab, h_src_tab + n_pages);
+        std::memcpy(pin, h_src_tab, sizeof(void*) * (size_t)n_pages);
+        PRL_HIP_CHECK(hipMemcpyAsync(d_src_tab, pin, sizeof(void*) * (size_t)n_pages, hipMemcpyHostToDevice, stream));
+        src.table = d_src_tab;
+    }
+    if (h_dst_tab) {
+        pc.dst_tab.assign(h_dst_tab, h_dst_tab + n_pages);
+        std::memcpy(pin + sl.table_bytes, h_dst_tab, sizeof(void*) * (size_t)n_pages);
+        PRL_HIP_CHECK(hipMemcpyAsync(d_dst_tab, pin + sl.table_bytes, sizeof(void*) * (size_t)n_pages, hipMemcpyHostToDevice, stream));
+        dst.table = d_dst_tab;
+    }
+
+    const size_t mask_step = ((size_t)g.out_w + 63) / 64 * 64;
+    const size_t mask_page = mask_step * (size_t)g.out_h;
     const size_t literal_per_page = literal_scratch_per_page(tp);
     size_t literal_pages_per_chunk = 0;
     if (!use_fused) {
         literal_pages_per_chunk = std::max<size_t>(1, literal_scratch_budget() / literal_per_page);
         literal_pages_per_chunk = std::min<size_t>(literal_pages_per_chunk, (size_t)n_pages);
-        st = ensure_scratch(ctx, literal_per_page * literal_pages_per_chunk);
+        st = ws_grow(&ws->scratch, &ws->scratch_bytes, literal_per_page * literal_pages_per_chunk, stream);
         if (st != PRL_OK) return st;
     }
-    // With morphology the thresholded mask goes to a scratch buffer first, then the morph kernel writes dst.  When the
+    // With morphology the thresholded mask goes to a workspace buffer first, then the morph kernel writes dst.  When the
     // fused kernel runs and the radius allows it, that buffer is a BIT plane (1/8 B per pixel written and re-read
-    // instead of 1 B): [bit planes of all pages][one byte page for a literal redo of an overflowing page].
+    // instead of 1 B).
     const bool bit_mask = use_fused && morph != 0 && std::abs(morph) <= morph_bits_max_radius() && !env_knobs().byte_mask;
     const size_t bit_step = ((size_t)g.out_w + 127) / 128 * 16;
     const size_t bit_page = (bit_step * (size_t)g.out_h + 255) / 256 * 256;
+    const bool large_morph = morph != 0 && std::abs(morph) > kMorphMaxFusedRadius;
     PageSetOut thr_dst = dst;
     if (morph != 0) {
-        st = ensure_mask(ctx, bit_mask ? bit_page * (size_t)n_pages + mask_page : mask_bytes);
+        const size_t first = bit_mask ? bit_page * (size_t)n_pages : mask_page * (size_t)n_pages;
+        st = ws_grow(&ws->mask, &ws->mask_bytes, first + (large_morph ? mask_page * (size_t)n_pages : 0), stream);
         if (st != PRL_OK) return st;
         thr_dst = PageSetOut{};
-        thr_dst.base = static_cast<uint8_t*>(ctx->mask);
+        thr_dst.base = static_cast<uint8_t*>(ws->mask);
         thr_dst.page_stride = bit_mask ? bit_page : mask_page;
         thr_dst.step = bit_mask ? bit_step : mask_step;
     }
@@ -490,62 +703,24 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
     st = init_globals_run(d_globals, n_pages, stream);
     if (st != PRL_OK) return st;
 
-    t_last = LastCall{};
-    t_last.device = dev;
-    t_last.stream = stream;
-    t_last.n_pages = n_pages;
-    t_last.pixels = (uint64_t)g.out_w * g.out_h * (uint64_t)n_pages;
-
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    ctx->prof_valid = false;
+    ws->prof_valid = false;
     if (g_profiling.load()) {
-        if (!ctx->prof_start) {
-            PRL_HIP_CHECK(hipEventCreate(&ctx->prof_start));
-            PRL_HIP_CHECK(hipEventCreate(&ctx->prof_stop));
+        if (!ws->prof_start) {
+            PRL_HIP_CHECK(hipEventCreate(&ws->prof_start));
+            PRL_HIP_CHECK(hipEventCreate(&ws->prof_stop));
         }
-        ev0 = ctx->prof_start;
-        ev1 = ctx->prof_stop;
+        ev0 = ws->prof_start;
+        ev1 = ws->prof_stop;
     }
     if (use_fused) {
-        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask, 1);
+        // threshold sweep, float64 interval test of what it left open, literal fix-up of what THAT left open: all enqueued,
+        // the last two find their queues on the device and do nothing when they are empty.  Pages whose fix-up queue
+        // overflowed are flagged; the flags travel to the pinned slot and are looked at in resolve_front().
+        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask, 0);
         if (st != PRL_OK) return st;
-        // Pages whose fix-up list overflowed (pathological: a large share of their pixels sits within
-        // ~1e-6 of the decision boundary) are redone by the literal pipeline.  Knowing that needs the
-        // per-page flags on the host, hence one stream synchronisation per call.
-        // (read back through pinned memory: a pageable destination turns the copy into a staged, slower one)
-        st = ensure_pinned(ctx, 2 * table_bytes + globals_bytes);
-        if (st != PRL_OK) return st;
-        const PageGlobals* hg = reinterpret_cast<const PageGlobals*>(static_cast<uint8_t*>(ctx->pinned) + 2 * table_bytes);
-        PRL_HIP_CHECK(hipMemcpyAsync(const_cast<PageGlobals*>(hg), d_globals, sizeof(PageGlobals) * (size_t)n_pages,
+        PRL_HIP_CHECK(hipMemcpyAsync(pin + 2 * sl.table_bytes, d_globals, sizeof(PageGlobals) * (size_t)n_pages,
                                      hipMemcpyDeviceToHost, stream));
-        PRL_HIP_CHECK(hipStreamSynchronize(stream));
-        // literal fix-up of what the float64 interval test left open: launched only when there is something to fix
-        unsigned long long n_open = 0;
-        for (int i = 0; i < n_pages; ++i) n_open += hg[(size_t)i].n_exact;
-        if (n_open > 0) {
-            st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, nullptr, nullptr, bit_mask, 2);
-            if (st != PRL_OK) return st;
-        }
-        for (int i = 0; i < n_pages; ++i) {
-            if (!hg[(size_t)i].worklist_overflow) continue;
-            st = ensure_scratch(ctx, literal_per_page);
-            if (st != PRL_OK) return st;
-            // (the page minimum Feng needs is already in the globals: fused_run reduced it)
-            if (bit_mask) {
-                // literal result as bytes into the spare page, then packed into this page's bit plane
-                PageSetOut one{};
-                one.base = static_cast<uint8_t*>(ctx->mask) + bit_page * (size_t)n_pages;
-                one.page_stride = 0;  // page(i) == base for every i
-                one.step = mask_step;
-                st = literal_run(tp, src, i, 1, one, ctx->scratch, d_globals, stream);
-                if (st != PRL_OK) return st;
-                st = pack_mask_run(one.base, mask_step, g.out_w, g.out_h, thr_dst.page(i), bit_step, stream);
-            } else {
-                st = literal_run(tp, src, i, 1, thr_dst, ctx->scratch, d_globals, stream);
-            }
-            if (st != PRL_OK) return st;
-            t_last.literal_pages += 1;
-        }
     } else {
         if (tp.method == PRL_WOLFJOLION || tp.method == PRL_FENG) {
             st = page_min_run(tp, src, n_pages, d_globals, stream);
@@ -554,11 +729,11 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         if (ev0) PRL_HIP_CHECK(hipEventRecord(ev0, stream));
         for (int first = 0; first < n_pages; first += (int)literal_pages_per_chunk) {
             const int cnt = std::min<int>((int)literal_pages_per_chunk, n_pages - first);
-            st = literal_run(tp, src, first, cnt, thr_dst, ctx->scratch, d_globals, stream);
+            st = literal_run(tp, src, first, cnt, thr_dst, ws->scratch, d_globals, stream);
             if (st != PRL_OK) return st;
         }
         if (ev1) PRL_HIP_CHECK(hipEventRecord(ev1, stream));
-        t_last.literal_pages = (uint64_t)n_pages;
+        ws->last = CallStats{pc.seq, pc.pixels, 0, 0, (uint64_t)n_pages};
     }
 
     if (morph != 0) {
@@ -568,20 +743,24 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         msrc.step = thr_dst.step;
         if (bit_mask) {
             st = morph_bitplane_run(morph, msrc, n_pages, g.out_w, g.out_h, dst, stream);
-        } else if (std::abs(morph) <= kMorphMaxFusedRadius) {
+        } else if (!large_morph) {
             st = morph_binary_run(morph, msrc, n_pages, g.out_w, g.out_h, dst, stream);
-        } else {
-            // large radii: chained single-operator passes through one more page-sized buffer
-            st = ensure_scratch(ctx, mask_page * (size_t)n_pages);
-            if (st != PRL_OK) return st;
-            st = morph_large_run(morph, msrc, n_pages, g.out_w, g.out_h, dst, static_cast<uint8_t*>(ctx->scratch),
-                                 mask_step, stream);
+        } else {  // large radii: chained single-operator passes through one more page-sized buffer
+            st = morph_large_run(morph, msrc, n_pages, g.out_w, g.out_h, dst,
+                                 static_cast<uint8_t*>(ws->mask) + mask_page * (size_t)n_pages, mask_step, stream);
         }
         if (st != PRL_OK) return st;
     }
-    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, stream));
-    ctx->prof_valid = (ev0 != nullptr);
+    ws->prof_valid = (ev0 != nullptr);
+    t_last.device = dev;
+    t_last.stream = stream;
+    t_last.seq = pc.seq;
     t_last.valid = true;
+    if (need_slot) {
+        PRL_HIP_CHECK(hipEventRecord(ws->ev[slot], stream));
+        ws->pending.push_back(std::move(pc));
+        if (!g_deferred.load()) return resolve_all(ws);  // default: the call is complete (one wait) when it returns
+    }
     return PRL_OK;
 }
 
@@ -671,12 +850,33 @@ int prl_hip_last_kernel_ms(float* ms)
     *ms = 0.0f;
     if (!t_last.valid) return PRL_ERR_BAD_ARG;
     PRL_HIP_CHECK(hipSetDevice(t_last.device));
-    DeviceCtx* ctx = device_ctx(t_last.device);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!ctx->prof_valid) return PRL_ERR_BAD_ARG;
-    PRL_HIP_CHECK(hipEventSynchronize(ctx->prof_stop));
-    PRL_HIP_CHECK(hipEventElapsedTime(ms, ctx->prof_start, ctx->prof_stop));
+    StreamWs* ws = stream_ws(device_ctx(t_last.device), t_last.stream);
+    std::lock_guard<std::mutex> lk(ws->mu);
+    if (!ws->prof_valid) return PRL_ERR_BAD_ARG;
+    PRL_HIP_CHECK(hipEventSynchronize(ws->prof_stop));
+    PRL_HIP_CHECK(hipEventElapsedTime(ms, ws->prof_start, ws->prof_stop));
     return PRL_OK;
+}
+
+int prl_hip_set_deferred_completion(int enabled)
+{
+    g_deferred.store(enabled != 0);
+    return PRL_OK;
+}
+
+int prl_hip_finish(void* stream)
+{
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    StreamWs* ws = stream_ws(device_ctx(dev), hs);
+    {
+        std::lock_guard<std::mutex> lk(ws->mu);
+        st = resolve_all(ws);
+    }
+    PRL_HIP_CHECK(hipStreamSynchronize(hs));
+    return st;
 }
 
 int prl_hip_release_workspace(void)
@@ -687,7 +887,15 @@ int prl_hip_release_workspace(void)
     DeviceCtx* ctx = device_ctx(dev);
     std::lock_guard<std::mutex> slk(ctx->stage_mu);  // lock order everywhere: stage_mu, then mu
     std::lock_guard<std::mutex> lk(ctx->mu);
+    for (auto& kv : ctx->streams) {
+        std::lock_guard<std::mutex> wl(kv.second->mu);
+        (void)resolve_all(kv.second.get());
+    }
     PRL_HIP_CHECK(hipDeviceSynchronize());
+    for (auto& kv : ctx->streams) {
+        std::lock_guard<std::mutex> wl(kv.second->mu);
+        ws_free(kv.second.get());
+    }
     if (ctx->scratch) PRL_HIP_CHECK(hipFree(ctx->scratch));
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
@@ -716,17 +924,18 @@ int prl_hip_last_stats(prl_binarize_stats* out)
     std::memset(out, 0, sizeof(*out));
     if (!t_last.valid) return PRL_OK;
     PRL_HIP_CHECK(hipSetDevice(t_last.device));
-    DeviceCtx* ctx = device_ctx(t_last.device);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    std::vector<PageGlobals> g((size_t)t_last.n_pages);
-    PRL_HIP_CHECK(hipStreamSynchronize(t_last.stream));
-    PRL_HIP_CHECK(hipMemcpy(g.data(), ctx->small, sizeof(PageGlobals) * g.size(), hipMemcpyDeviceToHost));
-    out->pixels = t_last.pixels;
-    out->literal_pages = t_last.literal_pages;
-    for (const auto& pg : g) {
-        out->refined_pixels += pg.n_refined;
-        out->exact_pixels += pg.n_exact;
+    StreamWs* ws = stream_ws(device_ctx(t_last.device), t_last.stream);
+    std::lock_guard<std::mutex> lk(ws->mu);
+    // the numbers of this thread's last call live in its pinned flag slot: look at it now if nobody has yet
+    while (!ws->pending.empty() && ws->pending.front().seq <= t_last.seq) {
+        const int st = resolve_front(ws);
+        if (st != PRL_OK) return st;
     }
+    if (ws->last.seq != t_last.seq) return PRL_OK;  // a later call on this stream has replaced them
+    out->pixels = ws->last.pixels;
+    out->refined_pixels = ws->last.refined;
+    out->exact_pixels = ws->last.exact;
+    out->literal_pages = ws->last.literal_pages;
     return PRL_OK;
 }
 
@@ -835,6 +1044,8 @@ int prl_hip_binarize_host(const prl_binarize_params* p, const uint8_t* src, size
     st = stage_upload(ctx, 0, src, src_step, (size_t)width, height, d_in, stream);
     if (st != PRL_OK) return st;
     st = prl_hip_binarize_batch_device(p, 1, d_in, in_bytes, in_pitch, width, height, d_out, out_bytes, out_pitch, stream);
+    if (st != PRL_OK) return st;
+    st = prl_hip_finish(stream);  // (deferred-completion mode: the page is final before it is fetched)
     if (st != PRL_OK) return st;
     st = stage_download(ctx, in_bytes, d_out, (size_t)g.out_w, g.out_h, dst, dst_step, stream);
     if (st != PRL_OK) return st;

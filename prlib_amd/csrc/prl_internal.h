@@ -5,6 +5,9 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <deque>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 #include <string>
@@ -25,8 +28,12 @@ void set_error_detail(const std::string& s);
         }                                                                                         \
     } while (0)
 
+struct StreamWs;  // per-(device, stream) workspace of the binarizers (prl_capi.hip)
+
 // ---- per-device context: cached scratch memory ------------------------------------------------
 struct DeviceCtx {
+    std::map<hipStream_t, std::unique_ptr<StreamWs>> streams;  // guarded by `mu`; the entries have their own locks
+    ~DeviceCtx();
     std::mutex mu;          // one binarize/denoise call at a time per device (scratch is shared)
     int device = -1;
     void* scratch = nullptr;   // literal pipeline: float64 integral planes

@@ -426,3 +426,41 @@ print("MISMATCH", bad)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "MISMATCH 0" in r.stdout, r.stdout + r.stderr
+
+
+def test_deferred_completion_and_two_streams(prl, oracle, cuda_device):
+    """prl_hip_set_deferred_completion(1): calls return after enqueuing, the per-page flags (and the literal redo of an
+    overflowing page) are handled by later calls / prl_hip_finish.  Two torch streams use separate workspaces."""
+    import torch
+
+    w, c = 15, 200
+    k = _flat_boundary_k(c, w, c)
+    adversarial = [np.full((640, 700), c, np.uint8), _pages((640, 700), ["doc"], seed=29)[0]]   # page 0 overflows the fix-up list
+    docs = _pages((300, 600), ["doc", "doc", "doc"], seed=41)
+    s1, s2 = torch.cuda.Stream(device=cuda_device), torch.cuda.Stream(device=cuda_device)
+    t_adv = torch.from_numpy(np.stack(adversarial)).to(cuda_device)
+    t_doc = torch.from_numpy(np.stack(docs)).to(cuda_device)
+    torch.cuda.synchronize(cuda_device)
+    prl.set_deferred_completion(True)
+    try:
+        outs = []
+        with torch.cuda.stream(s2):
+            for method, win, kk in ((SAUVOLA, 31, 0.34), (NICK, 21, -0.1), (WOLFJOLION, 31, 0.3)):
+                outs.append((docs, method, win, kk, 0, prl.binarize(t_doc, prl.make_params(method, win, kk, 0))))
+        with torch.cuda.stream(s1):
+            # six calls in a row on one stream: more than the four flag slots, so earlier calls get resolved on the way
+            for morph in (0, 2, 0, -1, 0, 2):
+                outs.append((adversarial, SAUVOLA, w, k, morph, prl.binarize(t_adv, prl.make_params(SAUVOLA, w, k, morph))))
+        with torch.cuda.stream(s1):
+            prl.finish(cuda_device)
+            st = prl.last_stats()
+        with torch.cuda.stream(s2):
+            prl.finish(cuda_device)
+        assert st.literal_pages == 1
+        for pages, method, win, kk, morph, got in outs:
+            want = _oracle_batch(oracle, pages, method, win, kk, morph)
+            g = got.cpu().numpy()
+            for i in range(len(pages)):
+                assert np.array_equal(g[i], want[i]), (method, win, morph, i, int((g[i] != want[i]).sum()))
+    finally:
+        prl.set_deferred_completion(False)
