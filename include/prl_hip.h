@@ -171,6 +171,19 @@ int prl_hip_binarize_host(const prl_binarize_params* p,
                           uint8_t* dst, size_t dst_step,
                           uint8_t* padded_out, size_t padded_step);
 
+/*
+ * A list of n_pages equal-size 1-channel pages in HOST memory (what a caller holding n cv::Mat has,
+ * samples/binarizations/binarizeSauvola_sample.cpp:48-53), sharded over the devices of the node: contiguous blocks
+ * (prl_hip_page_range), one worker thread + two streams + pinned double buffers per device, results in the caller's
+ * buffers in the caller's order.  n_devices: 0 = every visible device.  No collective; returns when all pages are done.
+ */
+int prl_hip_binarize_batch_host(const prl_binarize_params* p, int n_pages, const uint8_t* const* src, size_t src_step,
+                                int width, int height, uint8_t* const* dst, size_t dst_step, int n_devices);
+
+/* The block of a list of n_items that part `part` of `n_parts` owns (sizes differ by at most one): the split used by
+ * prl_hip_binarize_batch_host over devices and by one-process-per-GPU launchers over ranks. */
+int prl_hip_page_range(int n_items, int n_parts, int part, int* first, int* count);
+
 /* (2n+1)x(2n+1) rectangular closing (n>0) / opening (n<0) with out-of-image pixels ignored:
  * the cv::dilate/cv::erode pair at binarizeSauvola.cpp:125-134.  In place is NOT allowed. */
 int prl_hip_morph_batch_device(int morph_iterations, int n_pages,

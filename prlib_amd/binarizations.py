@@ -71,6 +71,26 @@ def last_stats() -> BinarizeStats:
     return s
 
 
+def binarize_pages_host(pages, params: BinarizeParams, n_devices: int = 0):
+    """prl_hip_binarize_batch_host: a list (or N x H x W array) of equal-size uint8 host pages, sharded over the node's
+    GPUs by the library (worker thread + two streams per device).  Returns an N x out_h x out_w array."""
+    pages = [np.ascontiguousarray(p) if p.strides[1] != 1 else p for p in pages]
+    n = len(pages)
+    h, w = pages[0].shape
+    if any(p.shape != (h, w) or p.dtype != np.uint8 for p in pages):
+        raise TypeError("expected equal-size uint8 pages")
+    g = geometry(params, w, h)
+    out = np.empty((n, g.out_h, g.out_w), dtype=np.uint8)
+    if any(p.strides[0] != pages[0].strides[0] for p in pages):
+        pages = [np.ascontiguousarray(p) for p in pages]
+    src = (C.c_void_p * n)(*[p.ctypes.data for p in pages])
+    dst = (C.c_void_p * n)(*[out[i].ctypes.data for i in range(n)])
+    st = _capi.lib().prl_hip_binarize_batch_host(C.byref(params), n, src, pages[0].strides[0], w, h, dst, out.strides[1], n_devices)
+    if st != _capi.PRL_OK:
+        _raise_like_reference(st)
+    return out
+
+
 def set_deferred_completion(enabled: bool) -> None:
     """prl_hip_set_deferred_completion: binarize calls return right after enqueuing; call finish() before using the masks."""
     _capi.check(_capi.lib().prl_hip_set_deferred_completion(1 if enabled else 0))

@@ -39,6 +39,7 @@ std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
 std::atomic<int> g_exec_mode{-1};  // -1: take PRL_HIP_MODE
 std::atomic<bool> g_profiling{false};
 std::atomic<bool> g_deferred{false};  // prl_hip_set_deferred_completion
+thread_local bool t_force_deferred = false;  // library-internal callers that call prl_hip_finish themselves (host batch)
 
 }  // namespace
 
@@ -67,6 +68,8 @@ const EnvKnobs& env_knobs()
         k.literal_scratch_mb = (size_t)std::max(64ll, geti("PRL_HIP_LITERAL_SCRATCH_MB", 8192));
         k.deskew_work_mb = (size_t)std::max(64ll, geti("PRL_HIP_DESKEW_WORK_MB", 24576));
         k.chain_work_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_WORK_MB", 49152));
+        k.host_chunk_mb = (size_t)std::max(1ll, geti("PRL_HIP_HOST_CHUNK_MB", 128));
+        k.host_copy_threads = (int)std::max(1ll, std::min(32ll, geti("PRL_HIP_HOST_COPY_THREADS", 4)));
         k.segmax_cap = (unsigned)std::max(64ll, std::min(1ll << 20, geti("PRL_HIP_SEGMAX_CAP", 1 << 20)));
         const char* m = std::getenv("PRL_HIP_MODE");
         k.literal_mode = (m && std::strcmp(m, "literal") == 0) ? 1 : 0;
@@ -759,12 +762,17 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
     if (need_slot) {
         PRL_HIP_CHECK(hipEventRecord(ws->ev[slot], stream));
         ws->pending.push_back(std::move(pc));
-        if (!g_deferred.load()) return resolve_all(ws);  // default: the call is complete (one wait) when it returns
+        if (!g_deferred.load() && !t_force_deferred) return resolve_all(ws);  // default: the call is complete (one wait) when it returns
     }
     return PRL_OK;
 }
 
 }  // namespace
+}  // namespace prl_hip
+
+namespace prl_hip {
+DeferredScope::DeferredScope() : prev_(t_force_deferred) { t_force_deferred = true; }
+DeferredScope::~DeferredScope() { t_force_deferred = prev_; }
 }  // namespace prl_hip
 
 using namespace prl_hip;

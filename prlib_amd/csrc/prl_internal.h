@@ -75,10 +75,22 @@ struct EnvKnobs {
     size_t literal_scratch_mb = 8192;   // PRL_HIP_LITERAL_SCRATCH_MB
     size_t deskew_work_mb = 24576;      // PRL_HIP_DESKEW_WORK_MB
     size_t chain_work_mb = 49152;       // PRL_HIP_CHAIN_WORK_MB
+    size_t host_chunk_mb = 128;         // PRL_HIP_HOST_CHUNK_MB   pages staged per buffer of prl_hip_binarize_batch_host
+    int host_copy_threads = 4;          // PRL_HIP_HOST_COPY_THREADS  host threads per device copying pages in / out of pinned memory
     unsigned segmax_cap = 1u << 20;     // PRL_HIP_SEGMAX_CAP   wavefronts per Wolf-Jolion call (tests shrink it)
     int literal_mode = 0;         // PRL_HIP_MODE=literal
 };
 const EnvKnobs& env_knobs();
+
+// While alive, binarize calls of this thread only enqueue (as with prl_hip_set_deferred_completion(1)); the owner calls
+// prl_hip_finish(stream) itself.
+class DeferredScope {
+public:
+    DeferredScope();
+    ~DeferredScope();
+private:
+    bool prev_;
+};
 
 int current_device(int* dev);             // validates that a gfx950 device is usable
 DeviceCtx* device_ctx(int dev);

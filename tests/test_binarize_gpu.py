@@ -464,3 +464,30 @@ def test_deferred_completion_and_two_streams(prl, oracle, cuda_device):
                 assert np.array_equal(g[i], want[i]), (method, win, morph, i, int((g[i] != want[i]).sum()))
     finally:
         prl.set_deferred_completion(False)
+
+
+def test_host_batch_entry_shards_and_double_buffers(prl, oracle, cuda_device):
+    """prl_hip_binarize_batch_host on one device: 40 pages of 2048^2 are three chunks alternating between two streams;
+    results come back in the caller's order, from pages with a row stride larger than the width."""
+    n, h, w = 40, 2048, 2048
+    from prlib_amd import synth
+
+    base = [synth.page_numpy(h, w, index=i % 5) for i in range(5)]
+    store = np.empty((n, h, w + 64), np.uint8)           # strided pages (cv::Mat ROI-like)
+    for i in range(n):
+        store[i, :, :w] = np.roll(base[i % 5], i * 37, axis=1)
+    pages = [store[i, :, :w] for i in range(n)]
+    p = prl.make_params(SAUVOLA, 31, 0.34, 2)
+    got = prl.binarize_pages_host(pages, p, n_devices=1)
+    po = oracle.make_params(SAUVOLA, 31, 0.34, 2)
+    for i in (0, 1, 15, 16, 17, 31, 32, 39):
+        want = oracle.binarize(np.ascontiguousarray(pages[i]), po)
+        assert np.array_equal(got[i], want), (i, int((got[i] != want).sum()))
+    # every page = a rolled copy of one of five bases: cheap whole-batch check through the five distinct results
+    assert len({got[i].tobytes() for i in range(n)}) >= 5
+    # a short list (fewer pages than a chunk: single buffer) and n_devices = 0 (all visible)
+    got2 = prl.binarize_pages_host(pages[:3], prl.make_params(NICK, 21, -0.1, 0), n_devices=0)
+    for i in range(3):
+        assert np.array_equal(got2[i], oracle.binarize(np.ascontiguousarray(pages[i]), oracle.make_params(NICK, 21, -0.1, 0)))
+    with pytest.raises(ValueError):
+        prl.binarize_pages_host(pages[:2], prl.make_params(SAUVOLA, 30, 0.34, 0))

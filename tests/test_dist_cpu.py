@@ -24,6 +24,26 @@ def test_page_range_partitions_exactly():
         page_range(10, 2, 2)
 
 
+def test_c_abi_page_range_is_the_same_split(prl):
+    """prl_hip_page_range (what prl_hip_binarize_batch_host shards devices with) == prlib_amd.dist.page_range."""
+    import ctypes as C
+
+    from prlib_amd import _capi
+    from prlib_amd.dist import page_range
+
+    L = _capi.lib()
+    for n in (0, 1, 7, 256, 1000, 1024):
+        for parts in (1, 2, 3, 4, 8):
+            for r in range(parts):
+                first, count = C.c_int(-1), C.c_int(-1)
+                assert L.prl_hip_page_range(n, parts, r, C.byref(first), C.byref(count)) == 0
+                pr = page_range(n, parts, r)
+                assert (first.value, count.value) == (pr.start, len(pr))
+    first, count = C.c_int(0), C.c_int(0)
+    assert L.prl_hip_page_range(10, 2, 2, C.byref(first), C.byref(count)) == _capi.PRL_ERR_BAD_ARG
+    assert L.prl_hip_page_range(10, 0, 0, C.byref(first), C.byref(count)) == _capi.PRL_ERR_BAD_ARG
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
