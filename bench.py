@@ -211,6 +211,7 @@ def main():
     mismatches = None
     checked = []
     cpu = None
+    vs_opencv = None
     if rank == 0:
         from oracle import capi as oc
 
@@ -225,6 +226,14 @@ def main():
             got = out.index_select(0, sel)[:, :, : g.out_w].cpu().numpy()
             mismatches = int((want != got).sum())
             checked = idx
+        if world == 1:
+            try:   # the oracle against real OpenCV where this box has it (None: not installed, parity unpinned)
+                from oracle import opencv_check
+
+                rep = opencv_check.report(timeout=300)
+                vs_opencv = None if (rep is None or rep.get("opencv") is None) else rep
+            except Exception:
+                vs_opencv = None
         if args.cpu_seconds > 0 and world == 1:   # the CPU baseline leg runs at N=1 only
             n_host = min(n_mine, 64)
             cpu = cpu_baseline(pages[:n_host].cpu().numpy().copy(), po, args.cpu_seconds)
@@ -275,7 +284,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": {"checked_pages": checked, "mismatching_pixels": mismatches,
                        "refined_pixels": int(stats.refined_pixels), "exact_pixels": int(stats.exact_pixels),
-                       "literal_pages": int(stats.literal_pages)},
+                       "literal_pages": int(stats.literal_pages), "vs_opencv": vs_opencv},
         }
         print(json.dumps(line), flush=True)
     pdist.finish()
