@@ -311,6 +311,22 @@ int prl_hip_bgnorm_batch_device(int n_pages, int channels, const uint8_t* d_src,
 int prl_hip_bgnorm_host(int channels, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst,
                         size_t dst_step);
 
+/* ---- local-variance binarizers ------------------------------------------------------------- */
+
+/*
+ * prl::binarizeByLocalVariances(in, out, varianceThresholdCoeff = 0.125, minResultVariance = 25, gamma = 2.0)
+ * (with_filters != 0; src/binarizations/binarizeByLocalVariances.cpp:13-145) and
+ * prl::binarizeByLocalVariancesWithoutFilters(in, out, varianceThresholdCoeff = 0.125, minResultVariance = 10)
+ * (with_filters == 0; :148-292, gamma ignored) on 8-bit 3-CHANNEL pages (the reference reads three variance planes);
+ * d_dst: width x height bytes, 0 / 255.  Enqueues on `stream`.  The filtered variant evaluates float32 log / exp / pow
+ * (cv::log, cv::exp in the reference): identical results across libraries are not defined, see DESIGN.md.
+ */
+int prl_hip_binarize_lv_batch_device(int n_pages, int with_filters, double coeff, int min_result_variance, double gamma,
+                                     const uint8_t* d_src, size_t src_page_stride, size_t src_step, int width, int height,
+                                     uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream);
+int prl_hip_binarize_lv_host(int with_filters, double coeff, int min_result_variance, double gamma, const uint8_t* src,
+                             size_t src_step, int width, int height, uint8_t* dst, size_t dst_step);
+
 /* ---- deskew / rotate (prl::deskew, prl::rotate) ----------------------------------------------- */
 
 /* Size of prl::rotate's result (src/rotate.cpp:35-72): transposed for 90 / 270 degrees, unchanged for 180, else a square

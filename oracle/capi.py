@@ -129,6 +129,10 @@ def lib() -> C.CDLL:
         L.prl_oracle_rotate.argtypes = [C.c_int, u8p, C.c_size_t, C.c_int, C.c_int, C.c_double, u8p, C.c_size_t]
         L.prl_oracle_deskew.argtypes = [C.c_int, u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t, C.POINTER(C.c_int),
                                         C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.prl_oracle_local_variance_map.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.prl_oracle_local_variance_map.restype = None
+        L.prl_oracle_binarize_lv.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, u8p, C.c_size_t]
+        L.prl_oracle_binarize_lv_nofilters.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_int, u8p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -423,3 +427,38 @@ def deskew(img: np.ndarray):
     out = buf[: oh.value, : ow.value].copy()
     info = dict(angle=ang.value, otsu=thr.value, n_lines=nl.value)
     return (out if img.ndim == 3 else out[:, :, 0]), info
+
+
+# ---- binarizeByLocalVariances (prl_oracle_lv.c) ----------------------------------------------------
+
+def local_variance_map(img: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(img)
+    h, w, c = a.shape
+    assert c == 3 and a.dtype == np.uint8
+    out = np.empty((h, w, 3), dtype=np.float32)
+    lib().prl_oracle_local_variance_map(_ptr(a), a.strides[0], w, h, _ptr(out))
+    return out
+
+
+def binarize_lv(img: np.ndarray, coeff: float = 0.125, min_result_variance: int = 25, gamma: float = 2.0) -> np.ndarray:
+    a = np.ascontiguousarray(img)
+    h, w, c = a.shape
+    if c != 3:
+        raise OracleError(PRL_ERR_BAD_CHANNELS)
+    out = np.empty((h, w), dtype=np.uint8)
+    st = lib().prl_oracle_binarize_lv(_ptr(a), a.strides[0], w, h, coeff, min_result_variance, gamma, _ptr(out), out.strides[0])
+    if st != PRL_OK:
+        raise OracleError(st)
+    return out
+
+
+def binarize_lv_nofilters(img: np.ndarray, coeff: float = 0.125, min_result_variance: int = 10) -> np.ndarray:
+    a = np.ascontiguousarray(img)
+    h, w, c = a.shape
+    if c != 3:
+        raise OracleError(PRL_ERR_BAD_CHANNELS)
+    out = np.empty((h, w), dtype=np.uint8)
+    st = lib().prl_oracle_binarize_lv_nofilters(_ptr(a), a.strides[0], w, h, coeff, min_result_variance, _ptr(out), out.strides[0])
+    if st != PRL_OK:
+        raise OracleError(st)
+    return out

@@ -126,6 +126,13 @@ int    prl_oracle_rotate(int channels, const uint8_t* src, size_t src_step, int 
 int    prl_oracle_deskew(int channels, const uint8_t* src, size_t src_step, int width, int height, uint8_t* dst,
                          size_t dst_step, int* out_w, int* out_h, double* angle_out, int* thr_out, int* n_lines_out);
 
+/* ---- binarizeByLocalVariances (src/binarizations/binarizeByLocalVariances.cpp; prl_oracle_lv.c) ---- */
+void prl_oracle_local_variance_map(const uint8_t* bgr, size_t step, int width, int height, float* var);
+int  prl_oracle_binarize_lv(const uint8_t* bgr, size_t step, int width, int height, double coeff, int min_result_variance,
+                            double gamma, uint8_t* dst, size_t dst_step);
+int  prl_oracle_binarize_lv_nofilters(const uint8_t* bgr, size_t step, int width, int height, double coeff,
+                                      int min_result_variance, uint8_t* dst, size_t dst_step);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,11 +13,11 @@ from .chain import bitwise_not, cvtColorBGR2GRAY, cvtColorGRAY2BGR, process_page
 from .binarizations import (  # noqa: F401
     FENG, NICK, NIBLACK, SAUVOLA, WOLFJOLION, binarize, binarizeFeng, binarizeNICK, binarizeNiblack,
     binarizeSauvola, binarizeWolfJolion, default_params, geometry, last_stats, make_params, morph,
-    set_exec_mode, set_deferred_completion, finish, binarize_pages_host,
+    set_exec_mode, set_deferred_completion, finish, binarize_pages_host, binarizeByLocalVariances, binarizeByLocalVariancesWithoutFilters,
 )
 
 __all__ = [
-    "binarize", "binarizeSauvola", "binarizeNiblack", "binarizeWolfJolion", "binarizeNICK", "binarizeFeng",
+    "binarize", "binarizeSauvola", "binarizeNiblack", "binarizeWolfJolion", "binarizeNICK", "binarizeFeng", "binarizeByLocalVariances", "binarizeByLocalVariancesWithoutFilters",
     "denoise", "nlm_planes", "backgroundNormalization", "deskew", "rotate", "houghp", "thinZhangSuen", "thinGuoHall", "cvtColorBGR2GRAY", "cvtColorGRAY2BGR", "bitwise_not", "process_pages", "make_params", "default_params", "geometry", "last_stats", "morph", "set_exec_mode", "set_deferred_completion", "finish", "binarize_pages_host",
     "SAUVOLA", "NIBLACK", "WOLFJOLION", "NICK", "FENG",
 ]

@@ -228,3 +228,44 @@ def morph(mask, iterations: int, out=None):
                                              w, h, out.data_ptr(), out.stride(0), out.stride(1), stream))
     res = out[:, :, :w]
     return res[0] if squeeze else res
+
+
+def _lv(inputImage, with_filters, coeff, min_result_variance, gamma, out=None):
+    L = _capi.lib()
+    if isinstance(inputImage, np.ndarray):
+        img = np.ascontiguousarray(inputImage)
+        if img.size == 0:
+            raise ValueError("binarizeByLocalVariances: Input inputImage for binarization is empty")
+        if img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
+            raise TypeError("expected an H x W x 3 uint8 image")
+        h, w = img.shape[:2]
+        res = np.empty((h, w), dtype=np.uint8)
+        _capi.check(L.prl_hip_binarize_lv_host(with_filters, coeff, min_result_variance, gamma, img.ctypes.data, img.strides[0],
+                                               w, h, res.ctypes.data, res.strides[0]))
+        return res
+    import torch
+
+    t = inputImage
+    squeeze = t.dim() == 3
+    if squeeze:
+        t = t.unsqueeze(0)
+    if t.dtype != torch.uint8 or not t.is_cuda or t.dim() != 4 or t.shape[3] != 3 or t.stride(3) != 1 or t.stride(2) != 3:
+        raise TypeError("expected a uint8 CUDA tensor [N,] H x W x 3")
+    n, h, w = t.shape[:3]
+    o = torch.empty((n, h, w), dtype=torch.uint8, device=t.device) if out is None else (out.unsqueeze(0) if out.dim() == 2 else out)
+    _capi.check(L.prl_hip_set_device(t.device.index or 0))
+    stream = torch.cuda.current_stream(t.device).cuda_stream
+    _capi.check(L.prl_hip_binarize_lv_batch_device(n, with_filters, coeff, min_result_variance, gamma, t.data_ptr(), t.stride(0),
+                                                   t.stride(1), w, h, o.data_ptr(), o.stride(0), o.stride(1), stream))
+    return o[0] if squeeze else o
+
+
+def binarizeByLocalVariances(inputImage, varianceThresholdCoeff: float = 0.125, minResultVariance: int = 25,
+                             gamma: float = 2.0, out=None):
+    """src/binarizations/binarizeByLocalVariances.h:8-9"""
+    return _lv(inputImage, 1, float(varianceThresholdCoeff), int(minResultVariance), float(gamma), out)
+
+
+def binarizeByLocalVariancesWithoutFilters(inputImage, varianceThresholdCoeff: float = 0.125, minResultVariance: int = 10, out=None):
+    """src/binarizations/binarizeByLocalVariances.h:11-12"""
+    return _lv(inputImage, 0, float(varianceThresholdCoeff), int(minResultVariance), 2.0, out)

@@ -53,6 +53,13 @@ void denoise(const cv::Mat& inputImage, cv::Mat& outputImage, double strength = 
 void thinZhangSuen(cv::Mat& inputImage, cv::Mat& outputImage);
 void thinGuoHall(cv::Mat& inputImage, cv::Mat& outputImage);
 
+// SURVEY.md §8f rank 4b — src/binarizations/binarizeByLocalVariances.h:8-12.  8UC3 input (the reference reads three
+// variance planes); std::invalid_argument for an empty image (binarizeByLocalVariances.cpp:16-19, :151-154).
+void binarizeByLocalVariances(cv::Mat& inputImage, cv::Mat& outputImage, double varianceThresholdCoeff = 0.125,
+                              int minResultVariance = 25, double gamma = 2.0);
+void binarizeByLocalVariancesWithoutFilters(cv::Mat& inputImage, cv::Mat& outputImage, double varianceThresholdCoeff = 0.125,
+                                            int minResultVariance = 10);
+
 // SURVEY.md §8f rank 3 — src/backgroundNormalization.h:40.  8UC1 -> 8UC1; 8UC3 / 8UC4 -> 8UC3 (the reference's
 // Leptonica round trip drops a fourth channel, src/formatConvert.cpp:193-206).  std::invalid_argument for an empty image
 // (src/backgroundNormalization.cpp:40-43).

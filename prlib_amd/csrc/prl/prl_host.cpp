@@ -117,6 +117,34 @@ void prl::denoise(const cv::Mat& inputImage, cv::Mat& outputImage, double streng
     outputImage = result;
 }
 
+namespace {
+void lv_impl(int with_filters, cv::Mat& in, cv::Mat& out, double coeff, int minVar, double gamma, const char* empty_msg)
+{
+    if (in.empty()) throw std::invalid_argument(empty_msg);
+    // [upstream] MatToLocalVarianceMap accepts 8UC1 / 8UC3 (imageLibCommon.cpp:404-408), but the callers index three planes
+    if (in.type() != CV_8UC3)
+        throw std::invalid_argument("Image for local variance map extraction has unsupported type (3 channels, 8 bits required here)");
+    cv::Mat result(in.rows, in.cols, CV_8UC1);
+    const int st = prl_hip_binarize_lv_host(with_filters, coeff, minVar, gamma, in.data, in.step, in.cols, in.rows, result.data, result.step);
+    if (st != PRL_OK) raise(st);
+    out = result;
+}
+}  // namespace
+
+void prl::binarizeByLocalVariances(cv::Mat& inputImage, cv::Mat& outputImage, double varianceThresholdCoeff, int minResultVariance,
+                                   double gamma)
+{
+    lv_impl(1, inputImage, outputImage, varianceThresholdCoeff, minResultVariance, gamma,
+            "binarizeByLocalVariances: Input inputImage for binarization is empty");
+}
+
+void prl::binarizeByLocalVariancesWithoutFilters(cv::Mat& inputImage, cv::Mat& outputImage, double varianceThresholdCoeff,
+                                                 int minResultVariance)
+{
+    lv_impl(0, inputImage, outputImage, varianceThresholdCoeff, minResultVariance, 2.0,
+            "binarizeByLocalVariancesWithoutFilters: Input inputImage for binarization is empty");
+}
+
 void prl::backgroundNormalization(const cv::Mat& inputImage, cv::Mat& outputImage)
 {
     if (inputImage.empty()) throw std::invalid_argument("Input image for flipping is empty");  // backgroundNormalization.cpp:40-43

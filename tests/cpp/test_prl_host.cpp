@@ -62,6 +62,8 @@ static void test_validation()
     cv::Mat two(8, 8, CV_8UC2);
     CHECK(throws_invalid_argument([&] { prl::thinGuoHall(two, out); }));
     CHECK(throws_invalid_argument([&] { prl::backgroundNormalization(empty, out); }));  // backgroundNormalization.cpp:40-43
+    CHECK(throws_invalid_argument([&] { prl::binarizeByLocalVariances(empty, out); }));
+    CHECK(throws_invalid_argument([&] { prl::binarizeByLocalVariancesWithoutFilters(empty, out); }));
     bool threw_cv = false;
     try { prl::deskew(empty, out); } catch (const cv::Exception&) { threw_cv = true; } catch (...) {}
     CHECK(threw_cv);  // CV_Assert(!inputImage.empty()), deskew.cpp:210
@@ -250,6 +252,25 @@ static void test_gpu_round2()
         size_t bad = 0;
         for (int y = 0; y < out.rows && out.cols == ow; ++y) bad += std::memcmp(out.ptr(y), &want[(size_t)y * ow * ch], (size_t)ow * ch) != 0;
         CHECK(bad == 0);
+    }
+    // prl::binarizeByLocalVariancesWithoutFilters (integer-exact) and binarizeByLocalVariances (float32 log / exp: tolerance)
+    {
+        cv::Mat in = synth_page(140, 190, 31, 3), out;
+        std::vector<unsigned char> want((size_t)140 * 190);
+        CHECK(prl_oracle_binarize_lv_nofilters(in.data, in.step, 190, 140, 0.125, 10, want.data(), 190) == PRL_OK);
+        prl::binarizeByLocalVariancesWithoutFilters(in, out);
+        CHECK(out.rows == 140 && out.cols == 190 && out.type() == CV_8UC1);
+        size_t bad = 0;
+        for (int y = 0; y < out.rows; ++y) bad += std::memcmp(out.ptr(y), &want[(size_t)y * 190], 190) != 0;
+        CHECK(bad == 0);
+        CHECK(prl_oracle_binarize_lv(in.data, in.step, 190, 140, 0.125, 25, 2.0, want.data(), 190) == PRL_OK);
+        prl::binarizeByLocalVariances(in, out);
+        size_t diff = 0;
+        for (int y = 0; y < out.rows; ++y)
+            for (int x = 0; x < out.cols; ++x) diff += out.ptr(y)[x] != want[(size_t)y * 190 + x];
+        CHECK(diff <= 27);  // 1e-3 of the page
+        cv::Mat gray1 = synth_page(20, 20, 3, 1);
+        CHECK(throws_invalid_argument([&] { prl::binarizeByLocalVariances(gray1, out); }));
     }
     cv::Mat blank(60, 90, CV_8UC1), bout;
     std::memset(blank.data, 230, 60 * 90);
