@@ -754,6 +754,8 @@ int prl_hip_houghp_device(const uint8_t* d_image, size_t step, int width, int he
     const size_t bytes = (size_t)width * height;
     st = ensure_stage(ctx, bytes);
     if (st != PRL_OK) return st;
+    st = stage_acquire(ctx, hs);
+    if (st != PRL_OK) return st;
     st = prl_hip_invert_batch_device(1, d_image, 0, step, width, height, static_cast<uint8_t*>(ctx->stage), bytes, (size_t)width, stream);
     if (st != PRL_OK) return st;
     PageSet g{};
@@ -797,6 +799,12 @@ int prl_hip_deskew_batch_device(int n_pages, int channels, const uint8_t* d_src,
         st = ensure_stage(ctx, deskew_gray_bytes(width, height) * (size_t)chunk);
         if (st != PRL_OK) return st;
     }
+    st = stage_acquire(ctx, static_cast<hipStream_t>(stream));
+    if (st != PRL_OK) return st;
+    struct Release {
+        DeviceCtx* c; hipStream_t s;
+        ~Release() { (void)stage_release(c, s); }
+    } release{ctx, static_cast<hipStream_t>(stream)};
     for (int first = 0; first < n_pages; first += chunk) {
         const int cnt = std::min(chunk, n_pages - first);
         st = deskew_pages(ctx, cnt, channels, d_src + (size_t)first * src_page_stride, src_page_stride, src_step, width, height,

@@ -359,6 +359,12 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
         st = ensure_stage(ctx, per_page * (size_t)chunk);
         if (st != PRL_OK) return st;
     }
+    st = stage_acquire(ctx, static_cast<hipStream_t>(stream));  // another stream's chain / host call may still read the area
+    if (st != PRL_OK) return st;
+    struct Release {   // records the area's new last use on every exit, error exits included
+        DeviceCtx* c; hipStream_t s;
+        ~Release() { (void)stage_release(c, s); }
+    } release{ctx, static_cast<hipStream_t>(stream)};
     std::vector<int32_t> wh((size_t)chunk * 2);
     for (int first = 0; first < n_pages; first += chunk) {
         const int cnt = std::min(chunk, n_pages - first);

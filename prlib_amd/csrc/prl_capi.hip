@@ -257,6 +257,23 @@ int ensure_stage(DeviceCtx* ctx, size_t bytes)
     return PRL_OK;
 }
 
+int stage_acquire(DeviceCtx* ctx, hipStream_t stream)
+{
+    if (!ctx->stage_use) {
+        PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->stage_use, hipEventDisableTiming));
+        return PRL_OK;
+    }
+    PRL_HIP_CHECK(hipStreamWaitEvent(stream, ctx->stage_use, 0));
+    return PRL_OK;
+}
+
+int stage_release(DeviceCtx* ctx, hipStream_t stream)
+{
+    if (!ctx->stage_use) PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->stage_use, hipEventDisableTiming));
+    PRL_HIP_CHECK(hipEventRecord(ctx->stage_use, stream));
+    return PRL_OK;
+}
+
 int ensure_stage_pinned(DeviceCtx* ctx, size_t bytes)
 {
     if (ctx->stage_pinned_bytes >= bytes) return PRL_OK;
@@ -367,6 +384,10 @@ int stage_upload(DeviceCtx* ctx, size_t pin_off, const uint8_t* src, size_t src_
 {
     uint8_t* pin = static_cast<uint8_t*>(ctx->stage_pinned) + pin_off;
     const int band = rows_per_band(row_bytes, rows);
+    {   // the staging area may still be read by a chain call enqueued on another (non-blocking) stream
+        const int st = stage_acquire(ctx, stream);
+        if (st != PRL_OK) return st;
+    }
     for (int y0 = 0; y0 < rows; y0 += band) {
         const int n = std::min(band, rows - y0);
         uint8_t* p = pin + (size_t)y0 * row_bytes;

@@ -59,6 +59,7 @@ struct DeviceCtx {
     hipEvent_t prof_start = nullptr, prof_stop = nullptr;  // prl_hip_set_profiling
     bool prof_valid = false;
     hipEvent_t last_use = nullptr;  // recorded after each call; the next call's stream waits on it
+    hipEvent_t stage_use = nullptr; // same for the staging area (`stage`): recorded by its last user (guarded by stage_mu)
 };
 
 // Tuning / debugging knobs of the PRL_* environment variables, read ONCE (first use) instead of on every call.
@@ -99,6 +100,10 @@ int ensure_mask(DeviceCtx* ctx, size_t bytes);
 int ensure_small(DeviceCtx* ctx, size_t bytes);
 int ensure_pinned(DeviceCtx* ctx, size_t bytes);
 int ensure_stage(DeviceCtx* ctx, size_t bytes);  // caller holds stage_mu
+// The staging area is shared by every stream of the device: a user makes its stream wait for the previous user's work
+// (stage_acquire) before the first write and records its own work at the end (stage_release).  Caller holds stage_mu.
+int stage_acquire(DeviceCtx* ctx, hipStream_t stream);
+int stage_release(DeviceCtx* ctx, hipStream_t stream);
 // Host image <-> device staging through the cached pinned bounce buffer (caller holds stage_mu).  hipMemcpy2D from
 // pageable memory runs at ~1 GB/s on this stack; row memcpy into pinned memory + one DMA is an order faster.
 // `pin_off`: byte offset inside the bounce buffer (so an upload and a download can share it).

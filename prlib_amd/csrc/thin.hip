@@ -350,14 +350,16 @@ int thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_
     st = ensure_pinned(ctx, sizeof(unsigned) * (size_t)n_pages);  // flag readback through pinned memory
     if (st != PRL_OK) return st;
     unsigned* h_done = static_cast<unsigned*>(ctx->pinned);
-    const int max_passes = std::max(width, height) + 2;  // every effective pass removes at least one pixel layer
+    // No cap on the number of passes: the reference loops until a pass changes nothing (thinZhangSuen.cpp:93-104), and a
+    // 2-pixel diagonal stroke erodes from its ends only, about a row per pass (max(W,H)+2 was an unproven bound
+    // that returned a non-converged plane).  Every effective pass removes at least one pixel, so the loop ends.
     int group = 4;  // passes per host check, doubled each time (a pass over converged pages / idle tiles is nearly free)
     const unsigned wpb = (unsigned)env_knobs().thin_wpb;
     const dim3 gp((unsigned)((tw + wpb - 1) / wpb)), bp(64 * wpb);  // short wavefronts: 4 per workgroup measured best (26.1 vs 28.4 us)
     // Passes alternate A -> B -> A.  The pass that finds a page unchanged has just written a copy of its input, so
     // from then on BOTH buffers hold that page's final plane (later passes skip it): k_thin_unpack can always read A.
-    for (int pass = 0; pass < max_passes;) {
-        for (int gidx = 0; gidx < group && pass < max_passes; ++gidx, ++pass) {
+    for (int pass = 0;;) {
+        for (int gidx = 0; gidx < group; ++gidx, ++pass) {
             const unsigned* in = (pass & 1) ? B : A;
             unsigned* out = (pass & 1) ? A : B;
             const unsigned char* act_prev = (pass & 1) ? act1 : act0;

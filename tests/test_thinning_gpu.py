@@ -127,3 +127,30 @@ def test_thinning_random_sweep(prl, oracle, cuda_device, seed):
     for i in range(2):
         want = oracle.thin(imgs[i], method)
         assert np.array_equal(got[i], want), f"seed {seed} page {i}: {int((got[i] != want).sum())} mismatches ({h}x{w}, method {method})"
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_thinning_needs_more_passes_than_the_page_is_large(prl, oracle, cuda_device, method):
+    """a 2-pixel-thick zigzag erodes from its free ends only, about one row per pass and end; on a small page
+    that takes more passes than max(width, height) + 2, the cap round 1 used.  No cap now: the loop runs until a pass
+    changes nothing, as the reference's do-while does."""
+    import torch
+
+    h, w = 40, 24
+    img = np.zeros((h, w), np.uint8)
+    x, dx = 3, 1
+    for y in range(2, h - 2):       # 2-pixel-thick diagonal bouncing between the margins
+        img[y, x:x + 2] = 255
+        x += dx
+        if x >= w - 5 or x <= 3:
+            dx = -dx
+    want, passes = oracle.thin(img, method, return_passes=True)
+    got = (prl.thinZhangSuen if method == 0 else prl.thinGuoHall)(torch.from_numpy(img).to(cuda_device)).cpu().numpy()
+    assert np.array_equal(got, want), passes
+    # a long thin stroke on a wide, very low page: passes > max(w, h) + 2 by construction is hard to hit in general, so also
+    # check a page where the oracle itself reports many passes
+    big = np.zeros((12, 300), np.uint8)
+    big[4:8, 5:295] = 255
+    want, passes = oracle.thin(big, method, return_passes=True)
+    got = (prl.thinZhangSuen if method == 0 else prl.thinGuoHall)(torch.from_numpy(big).to(cuda_device)).cpu().numpy()
+    assert np.array_equal(got, want), passes
