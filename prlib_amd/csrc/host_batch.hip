@@ -55,7 +55,8 @@ struct Buf {
 };
 
 int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geometry& g, int first, int count,
-                  const uint8_t* const* src, size_t src_step, int width, int height, uint8_t* const* dst, size_t dst_step)
+                  const uint8_t* const* src, size_t src_step, int width, int height, uint8_t* const* dst, size_t dst_step,
+                  int copy_threads)
 {
     if (count == 0) return PRL_OK;
     int st = prl_hip_set_device(dev);
@@ -106,7 +107,7 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
             set_error_detail("host batch: download failed");
             return PRL_ERR_HIP;
         }
-        copy_pages(x.count, (size_t)g.out_w, g.out_h, nullptr, 0, x.pin_out, false, dst + x.first, dst_step, knobs.host_copy_threads);
+        copy_pages(x.count, (size_t)g.out_w, g.out_h, nullptr, 0, x.pin_out, false, dst + x.first, dst_step, copy_threads);
         x.count = 0;
         return PRL_OK;
     };
@@ -118,7 +119,7 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
         const int cnt = std::min(chunk, count - off);
         x.first = first + off;
         x.count = cnt;
-        copy_pages(cnt, (size_t)width, height, src + x.first, src_step, x.pin_in, true, nullptr, 0, knobs.host_copy_threads);
+        copy_pages(cnt, (size_t)width, height, src + x.first, src_step, x.pin_in, true, nullptr, 0, copy_threads);
         HB_CHECK(hipMemcpy2DAsync(x.d_in, in_pitch_page, x.pin_in, in_page, in_page, (size_t)cnt, hipMemcpyHostToDevice, x.stream));
         st = prl_hip_binarize_batch_device(p, cnt, x.d_in, in_pitch_page, (size_t)width, width, height, x.d_out, out_pitch_page,
                                            (size_t)g.out_w, x.stream);
@@ -173,6 +174,9 @@ int prl_hip_binarize_batch_host(const prl_binarize_params* p, int n_pages, const
         return PRL_ERR_NO_DEVICE;
     }
     const int devs = std::min(n_pages, n_devices == 0 ? visible : std::min(n_devices, visible));
+    // host threads copying pages in / out of pinned memory, per device worker: the knob, bounded by the cores there are
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int copy_threads = std::max(1, std::min(env_knobs().host_copy_threads, hw ? (int)(hw / (unsigned)devs) : 1));
     std::vector<int> status((size_t)devs, PRL_OK);
     std::vector<std::string> detail((size_t)devs);
     std::vector<std::thread> workers;
@@ -180,7 +184,7 @@ int prl_hip_binarize_batch_host(const prl_binarize_params* p, int n_pages, const
         int first = 0, count = 0;
         prl_hip_page_range(n_pages, devs, d, &first, &count);
         workers.emplace_back([=, &status, &detail]() {
-            status[(size_t)d] = device_worker(d, p, g, first, count, src, src_step, width, height, dst, dst_step);
+            status[(size_t)d] = device_worker(d, p, g, first, count, src, src_step, width, height, dst, dst_step, copy_threads);
             if (status[(size_t)d] != PRL_OK) detail[(size_t)d] = prl_hip_last_error_detail();
         });
     }

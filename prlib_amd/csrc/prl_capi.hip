@@ -69,7 +69,7 @@ const EnvKnobs& env_knobs()
         k.deskew_work_mb = (size_t)std::max(64ll, geti("PRL_HIP_DESKEW_WORK_MB", 24576));
         k.chain_work_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_WORK_MB", 49152));
         k.host_chunk_mb = (size_t)std::max(1ll, geti("PRL_HIP_HOST_CHUNK_MB", 128));
-        k.host_copy_threads = (int)std::max(1ll, std::min(32ll, geti("PRL_HIP_HOST_COPY_THREADS", 4)));
+        k.host_copy_threads = (int)std::max(1ll, std::min(32ll, geti("PRL_HIP_HOST_COPY_THREADS", 8)));
         k.segmax_cap = (unsigned)std::max(64ll, std::min(1ll << 20, geti("PRL_HIP_SEGMAX_CAP", 1 << 20)));
         const char* m = std::getenv("PRL_HIP_MODE");
         k.literal_mode = (m && std::strcmp(m, "literal") == 0) ? 1 : 0;
@@ -136,7 +136,7 @@ int ws_grow(void** p, size_t* cur, size_t need, hipStream_t stream, size_t floor
 
 StreamWs* stream_ws(DeviceCtx* ctx, hipStream_t stream)
 {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> lk(ctx->streams_mu);
     auto& p = ctx->streams[stream];
     if (!p) {
         p.reset(new StreamWs());
@@ -916,6 +916,7 @@ int prl_hip_release_workspace(void)
     DeviceCtx* ctx = device_ctx(dev);
     std::lock_guard<std::mutex> slk(ctx->stage_mu);  // lock order everywhere: stage_mu, then mu
     std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> mlk(ctx->streams_mu);
     for (auto& kv : ctx->streams) {
         std::lock_guard<std::mutex> wl(kv.second->mu);
         (void)resolve_all(kv.second.get());

@@ -32,7 +32,8 @@ struct StreamWs;  // per-(device, stream) workspace of the binarizers (prl_capi.
 
 // ---- per-device context: cached scratch memory ------------------------------------------------
 struct DeviceCtx {
-    std::map<hipStream_t, std::unique_ptr<StreamWs>> streams;  // guarded by `mu`; the entries have their own locks
+    std::mutex streams_mu;  // guards `streams` only (never held across device work: deskew holds `mu` for seconds)
+    std::map<hipStream_t, std::unique_ptr<StreamWs>> streams;  // the entries have their own locks
     ~DeviceCtx();
     std::mutex mu;          // one binarize/denoise call at a time per device (scratch is shared)
     int device = -1;
@@ -77,7 +78,7 @@ struct EnvKnobs {
     size_t deskew_work_mb = 24576;      // PRL_HIP_DESKEW_WORK_MB
     size_t chain_work_mb = 49152;       // PRL_HIP_CHAIN_WORK_MB
     size_t host_chunk_mb = 128;         // PRL_HIP_HOST_CHUNK_MB   pages staged per buffer of prl_hip_binarize_batch_host
-    int host_copy_threads = 4;          // PRL_HIP_HOST_COPY_THREADS  host threads per device copying pages in / out of pinned memory
+    int host_copy_threads = 8;          // PRL_HIP_HOST_COPY_THREADS  host threads per device copying pages in / out of pinned memory (bounded by cores / devices)
     unsigned segmax_cap = 1u << 20;     // PRL_HIP_SEGMAX_CAP   wavefronts per Wolf-Jolion call (tests shrink it)
     int literal_mode = 0;         // PRL_HIP_MODE=literal
 };
