@@ -109,7 +109,10 @@ int         prl_hip_abi_version(void);
 const char* prl_hip_strerror(int status);
 const char* prl_hip_last_error_detail(void);           /* thread-local, never NULL */
 int         prl_hip_device_count(int* count);          /* number of visible HIP devices */
-int         prl_hip_set_device(int device);            /* device used by subsequent calls of this thread */
+/* Device used by subsequent calls of this thread (thread-local, sticky).  Each call then makes it the thread's current HIP
+ * device, exactly as hipSetDevice(device) would, and leaves it so: a caller that juggles several devices on one thread sets
+ * its own device again afterwards.  Without this call the library follows hipGetDevice(). */
+int         prl_hip_set_device(int device);
 int         prl_hip_set_exec_mode(int mode);           /* prl_exec_mode */
 int         prl_hip_get_exec_mode(void);
 int         prl_hip_last_stats(prl_binarize_stats* out);

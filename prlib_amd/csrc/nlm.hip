@@ -645,7 +645,9 @@ int launch_nlm(const PageSet& src_all, const PageSetOut& dst_all, int n_pages, c
             constexpr int C = CH <= 2 ? CH : 1;
             const int xl_env = env_knobs().nlm_xl;
             const bool xl = np.n_lut <= kLutMaxXL && ((xl_env >> (C - 1)) & 1);
-            if (xl) hipLaunchKernelGGL((k_nlm_y<C, true, true>), grid, dim3(256), 0, stream, src, dst, np);
+            const bool glut = (env_knobs().nlm_glut >> (C - 1)) & 1;  // weight table from memory (L1) instead of LDS
+            if (xl && glut) hipLaunchKernelGGL((k_nlm_y<C, false, true>), grid, dim3(256), 0, stream, src, dst, np);
+            else if (xl) hipLaunchKernelGGL((k_nlm_y<C, true, true>), grid, dim3(256), 0, stream, src, dst, np);
             else if (lds_lut) hipLaunchKernelGGL((k_nlm_y<C, true>), grid, dim3(256), 0, stream, src, dst, np);
             else hipLaunchKernelGGL((k_nlm_y<C, false>), grid, dim3(256), 0, stream, src, dst, np);
         } else {

@@ -65,6 +65,7 @@ const EnvKnobs& env_knobs()
         if (k.thin_rps) k.thin_rps = std::max(4, k.thin_rps);
         k.thin_wpb = (int)std::max(1ll, std::min(4ll, geti("PRL_THIN_WPB", 4)));
         k.nlm_xl = (int)geti("PRL_NLM_XL", 3);
+        k.nlm_glut = (int)geti("PRL_NLM_GLUT", 0);
         k.literal_scratch_mb = (size_t)std::max(64ll, geti("PRL_HIP_LITERAL_SCRATCH_MB", 8192));
         k.deskew_work_mb = (size_t)std::max(64ll, geti("PRL_HIP_DESKEW_WORK_MB", 24576));
         k.chain_work_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_WORK_MB", 49152));

@@ -74,6 +74,7 @@ struct EnvKnobs {
     int morph_rps = 0, morph_wpb = 1;   // PRL_MORPH_RPS, PRL_MORPH_WPB
     int thin_rps = 0, thin_wpb = 4;     // PRL_THIN_RPS, PRL_THIN_WPB
     int nlm_xl = 3;               // PRL_NLM_XL
+    int nlm_glut = 0;             // PRL_NLM_GLUT   bit 0 / 1: L / ab plane read the weight table from memory instead of LDS
     size_t literal_scratch_mb = 8192;   // PRL_HIP_LITERAL_SCRATCH_MB
     size_t deskew_work_mb = 24576;      // PRL_HIP_DESKEW_WORK_MB
     size_t chain_work_mb = 49152;       // PRL_HIP_CHAIN_WORK_MB
