@@ -97,3 +97,49 @@ def test_nlm_4k_interior_equals_oracle_on_crop(prl, oracle, cuda_device):
         assert np.array_equal(got[ys, xs], want[ys, xs])
     flat = torch.full((300, 300, 3), 77, dtype=torch.uint8, device=cuda_device)
     assert torch.equal(prl.denoise(flat, 10.0), flat)                   # constant images are fixed points
+
+
+def test_config5_full_size_a4_chain(prl, oracle, cuda_device):
+    """BASELINE config 5 at its page size: deskew -> NL-means -> backgroundNormalization -> Sauvola -> Zhang-Suen on A4@300dpi
+    colour scans (6 pages through the device chain, one of them through the composed oracle - host NL-means on a 3508^2 page
+    takes tens of seconds), plus batch independence: a page's result does not depend on its neighbours."""
+    import torch
+    from prlib_amd import synth
+
+    pages, skews = synth.text_pages_torch(6, 3508, 2480, cuda_device, seed=7100, channels=3)
+    outs, angles = prl.process_pages(pages, 3, prl.SAUVOLA, 31, 0.34, 0, denoise_strength=10.0, thin=0, deskew=True,
+                                     background_normalization=True)
+    assert sum(1 for o in outs if o.shape[0] == o.shape[1]) >= 4          # most pages are skewed -> square canvases
+    assert float(np.abs(angles - skews).max()) < 1.0                       # the vote recovers the drawn skew
+    alone, a1 = prl.process_pages(pages[4:5].contiguous(), 3, prl.SAUVOLA, 31, 0.34, 0, denoise_strength=10.0, thin=0, deskew=True,
+                                  background_normalization=True)
+    assert a1[0] == angles[4] and torch.equal(alone[0], outs[4])
+    i = 1
+    cur, info = oracle.deskew(np.ascontiguousarray(pages[i].cpu().numpy()))
+    cur = oracle.denoise(np.ascontiguousarray(cur), 10.0, threads=64)
+    cur = oracle.bgr2gray(np.ascontiguousarray(oracle.bgnorm(np.ascontiguousarray(cur))))
+    mask = oracle.binarize(np.ascontiguousarray(cur), oracle.make_params(SAUVOLA, 31, 0.34, 0))
+    want = oracle.thin(255 - mask, 0)
+    assert info["angle"] == angles[i]
+    got = outs[i].cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_round2_stages_on_the_reference_test_images(prl, oracle, cuda_device):
+    """deskew and backgroundNormalization on the reference's own test_data/binarize images (inputs in tests/golden/*.npz)."""
+    import glob
+    import os
+
+    import torch
+
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    n = 0
+    for path in sorted(glob.glob(os.path.join(gdir, "0*.npz"))):
+        gray = np.load(path)["gray"]
+        t = torch.from_numpy(gray).to(cuda_device)
+        outs, angles = prl.deskew(t[None])
+        want, info = oracle.deskew(gray)
+        assert angles[0] == info["angle"] and np.array_equal(outs[0].cpu().numpy(), want), path
+        assert np.array_equal(prl.backgroundNormalization(t).cpu().numpy(), oracle.bgnorm(gray)), path
+        n += 1
+    assert n >= 6
