@@ -164,9 +164,6 @@ struct PphtArgs {
     int* accum;                 // per page kNumAngle * numrho, zeroed
     const float* ttab;          // kNumAngle x {cos, sin}
     int* lines; const unsigned long long* lines_off; const unsigned* lines_cap; unsigned* n_lines;
-#ifdef PRL_PPHT_TRACE
-    int* trace;  // 8 ints per trigger of page 0: j, i, max_n, max_val, end0, end1, good, count
-#endif
 };
 
 __device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }
@@ -181,6 +178,33 @@ __device__ __forceinline__ void step_pixel(int xflag, unsigned x0, unsigned y0, 
     else { *j1 = x >> 16; *i1 = y; }
 }
 
+// max over the 64 lanes of a signed value (DPP row shifts + row broadcasts; the result is uniform)
+__device__ __forceinline__ int wave_max_i32(int x)
+{
+    x = max(x, __builtin_amdgcn_update_dpp(INT_MIN, x, 0x111, 0xf, 0xf, false));  // row_shr:1
+    x = max(x, __builtin_amdgcn_update_dpp(INT_MIN, x, 0x112, 0xf, 0xf, false));  // row_shr:2
+    x = max(x, __builtin_amdgcn_update_dpp(INT_MIN, x, 0x114, 0xf, 0xf, false));  // row_shr:4
+    x = max(x, __builtin_amdgcn_update_dpp(INT_MIN, x, 0x118, 0xf, 0xf, false));  // row_shr:8
+    x = max(x, __builtin_amdgcn_update_dpp(INT_MIN, x, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+    x = max(x, __builtin_amdgcn_update_dpp(INT_MIN, x, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+constexpr int kBlk = 64;  // points per block of k_ppht
+
+// HoughLinesP stage 2, one wavefront per page, BLOCKS OF 64 POINTS (round 2, second version).  The first version walked the
+// points one by one: list fetch -> mask byte -> 180 voting atomics -> decision, three dependent memory round trips per
+// point (1.9 us).  Two facts allow overlapping them without changing a single result:
+//  * the visiting order does not depend on the data (cv::RNG draws idx_t = next() % (N - t) and the list swap
+//    nz[idx_t] = nz[N - t - 1] happens whatever the point does), so 64 steps of it are taken at once: lane L fetches the list
+//    entries of step t0 + L, and the swaps of the earlier steps of the same block are applied to its values in registers
+//    (a 64-step loop of readlane / compare / select), duplicates resolved so that memory ends in the sequential state;
+//  * a vote only matters when its cell reaches the threshold, which a fraction of a percent of the points do: the votes of
+//    all points of the block are ISSUED back to back (atomics with return into 192 registers; a lane owns its angles' rows, so
+//    successive points hitting one cell arrive in order) and then RETIRED in order; the first point that triggers a line has
+//    the votes of the younger points taken back, its line is walked exactly as before, and the rest of the block starts
+//    over (masks re-read: the walk may have erased some of them).
+// Up to 63 vector memory instructions are in flight per wavefront (the vmcnt counter), i.e. about 21 points.
 __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
 {
     const int page = blockIdx.x, lane = threadIdx.x;
@@ -202,29 +226,10 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
     const bool has2 = lane + 128 < kNumAngle;
     unsigned long long rng = ~0ull;
     unsigned n_lines = 0;
-    for (unsigned count = a.count[page]; count > 0; --count) {
-        rng = (unsigned long long)(unsigned)rng * 4164903690ull + (rng >> 32);
-        const unsigned idx = uni((unsigned)rng % count);
-        const unsigned pt = nz[idx];
-        const unsigned last = nz[count - 1];
-        if (lane == 0) nz[idx] = last;
-        const int j = (int)(uni(pt) & 0xffffu), i = (int)(uni(pt) >> 16);
-        if (!uni(mask[(size_t)i * W + j])) continue;
-        // vote; key = count * 256 + (255 - angle), signed: the largest count, the first angle among equals.  Counts can be
-        // negative (a good line takes back the votes of points that have not voted yet, as in the reference).
-        int key = INT_MIN;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            if (q < 2 || has2) {
-                const int r = cv_round_f((float)j * tc[q] + (float)i * ts[q]);
-                const int val = atomicAdd(arow[q] + r, 1) + 1;
-                key = max(key, val * 256 + (255 - (lane + 64 * q)));
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o));
-        key = (int)uni((unsigned)key);
-        if ((key >> 8) < a.threshold) continue;
-        const int max_n = 255 - (key & 255);
+    const unsigned N = a.count[page];
+
+    // One detected line: walk both ways from (j, i) along angle max_n, clear the mask, take votes back (as the first version).
+    auto process_line = [&](int j, int i, int max_n) {
         const float fa = -a.ttab[2 * max_n + 1], fb = a.ttab[2 * max_n];
         unsigned x0 = (unsigned)j, y0 = (unsigned)i;
         int dx0, dy0, xflag;
@@ -273,23 +278,15 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
         step_pixel(xflag, x0, y0, dx0, dy0, end_step[0], &ex[0], &ey[0]);
         step_pixel(xflag, x0, y0, -dx0, -dy0, end_step[1], &ex[1], &ey[1]);
         const bool good_line = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
-#ifdef PRL_PPHT_TRACE
-        if (lane == 0 && page == 0 && a.trace[0] < 4000) {
-            int* t = a.trace + 8 + 8 * a.trace[0];
-            t[0] = j; t[1] = i; t[2] = max_n; t[3] = (int)(key >> 8); t[4] = (int)end_step[0]; t[5] = (int)end_step[1];
-            t[6] = good_line; t[7] = (int)count;
-            a.trace[0] += 1;
-        }
-#endif
         // second walk: clear the set pixels up to the line ends; a good line takes their votes back
         for (int k = 0; k < 2; ++k) {
             const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
             for (unsigned base = (unsigned)k; base <= end_step[k]; base += 64) {  // (step 0 was cleared by k = 0)
-                const unsigned s = base + lane;
+                const unsigned st = base + lane;
                 int j1, i1;
-                step_pixel(xflag, x0, y0, dx, dy, s, &j1, &i1);
+                step_pixel(xflag, x0, y0, dx, dy, st, &j1, &i1);
                 bool set = false;
-                if (s <= end_step[k]) {
+                if (st <= end_step[k]) {
                     set = mask[(size_t)i1 * W + j1] != 0;
                     if (set) mask[(size_t)i1 * W + j1] = 0;
                 }
@@ -315,6 +312,89 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
                 lines[4 * n_lines + 3] = ey[1];
             }
             ++n_lines;
+        }
+    };
+
+    for (unsigned t0 = 0; t0 < N; t0 += kBlk) {
+        const unsigned nb = min((unsigned)kBlk, N - t0), c0 = N - t0;
+        // the next nb outputs of cv::RNG, one per lane
+        unsigned rv = 0;
+        for (unsigned L = 0; L < nb; ++L) {
+            rng = (unsigned long long)(unsigned)rng * 4164903690ull + (rng >> 32);
+            if ((unsigned)lane == L) rv = (unsigned)rng;
+        }
+        const bool act = (unsigned)lane < nb;
+        const unsigned cnt_l = act ? c0 - (unsigned)lane : 1u;  // list length at this lane's step
+        const unsigned idx = rv % cnt_l, lastpos = cnt_l - 1u;
+        unsigned rp = 0, rl = 0;
+        if (act) {
+            rp = nz[idx];
+            rl = nz[lastpos];
+        }
+        // swaps of the earlier steps of this block, applied in registers; `skip`: steps whose slot a later step writes again
+        unsigned long long skip = 0;
+        for (unsigned st = 0; st + 1 < nb; ++st) {
+            const unsigned is = (unsigned)__builtin_amdgcn_readlane((int)idx, (int)st);
+            const unsigned ls = (unsigned)__builtin_amdgcn_readlane((int)rl, (int)st);
+            const bool later = act && (unsigned)lane > st;
+            const bool c1 = later && idx == is, c2 = later && lastpos == is;
+            if (c1) rp = ls;
+            if (c2) rl = ls;
+            if (__ballot(c1)) skip |= 1ull << st;
+        }
+        if (act && !((skip >> lane) & 1ull)) nz[idx] = rl;   // memory ends in the sequential state
+        const unsigned pt = rp;                               // this lane's point: x | y << 16
+
+        unsigned start = 0;
+        while (start < nb) {
+            // mask bytes of the points not yet retired (a line walked meanwhile may have erased some)
+            unsigned m = 0;
+            if (act && (unsigned)lane >= start) m = mask[(size_t)(pt >> 16) * W + (pt & 0xffffu)];
+            const unsigned long long vm = __ballot(m != 0);
+            if (!vm) break;
+            // issue: every point's votes, back to back; v[p][q] = the count before this vote
+            int v[kBlk][3];
+#pragma unroll
+            for (int p = 0; p < kBlk; ++p) {
+                if ((vm >> p) & 1ull) {
+                    const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)pt, p);
+                    const float fj = (float)(q & 0xffffu), fi = (float)(q >> 16);
+#pragma unroll
+                    for (int qq = 0; qq < 3; ++qq)
+                        if (qq < 2 || has2) v[p][qq] = atomicAdd(arow[qq] + cv_round_f(fj * tc[qq] + fi * ts[qq]), 1);
+                }
+            }
+            // retire in order: key = count * 256 + (255 - angle), signed (counts go negative: a good line takes back the votes
+            // of points that have not voted yet, as in the reference): the largest count, the first angle among equals
+            int trig = -1, trig_n = 0;
+#pragma unroll
+            for (int p = 0; p < kBlk; ++p) {
+                if (((vm >> p) & 1ull) && trig < 0) {
+                    int key = INT_MIN;
+#pragma unroll
+                    for (int qq = 0; qq < 3; ++qq)
+                        if (qq < 2 || has2) key = max(key, (v[p][qq] + 1) * 256 + (255 - (lane + 64 * qq)));
+                    key = wave_max_i32(key);
+                    if ((key >> 8) >= a.threshold) {
+                        trig = p;
+                        trig_n = 255 - (key & 255);
+                    }
+                }
+            }
+            if (trig < 0) break;  // every vote of the block stands
+            // the younger points voted on speculation: take their votes back, walk the line, start over behind it
+            for (unsigned p = (unsigned)trig + 1; p < nb; ++p) {
+                if ((vm >> p) & 1ull) {
+                    const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)pt, (int)p);
+                    const float fj = (float)(q & 0xffffu), fi = (float)(q >> 16);
+#pragma unroll
+                    for (int qq = 0; qq < 3; ++qq)
+                        if (qq < 2 || has2) atomicAdd(arow[qq] + cv_round_f(fj * tc[qq] + fi * ts[qq]), -1);
+                }
+            }
+            const unsigned tq = (unsigned)__builtin_amdgcn_readlane((int)pt, trig);
+            process_line((int)(tq & 0xffffu), (int)(tq >> 16), trig_n);
+            start = (unsigned)trig + 1;
         }
     }
     if (lane == 0) a.n_lines[page] = n_lines;
@@ -533,23 +613,8 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     a.width = width; a.height = height; a.numrho = numrho; a.threshold = threshold; a.line_length = line_length; a.line_gap = line_gap;
     a.mask = d_mask; a.mask_page = mask_page; a.nz = d_nz; a.nz_off = d_nzoff; a.count = d_count; a.accum = d_accum; a.ttab = d_ttab;
     a.lines = d_lines; a.lines_off = d_lnoff; a.lines_cap = d_cap; a.n_lines = d_nlines;
-#ifdef PRL_PPHT_TRACE
-    static int* d_trace = nullptr;
-    if (!d_trace) PRL_HIP_CHECK(hipMalloc(&d_trace, 4 * 8 * 4002));
-    PRL_HIP_CHECK(hipMemsetAsync(d_trace, 0, 4 * 8 * 4002, stream));
-    a.trace = d_trace;
-#endif
     hipLaunchKernelGGL(k_ppht, dim3((unsigned)n_pages), dim3(64), 0, stream, a);
-#ifdef PRL_PPHT_TRACE
-    {
-        std::vector<int> tr(8 * 4002);
-        PRL_HIP_CHECK(hipMemcpy(tr.data(), d_trace, 4 * 8 * 4002, hipMemcpyDeviceToHost));
-        for (int t = 0; t < tr[0] && t < 60; ++t) {
-            const int* e = tr.data() + 8 + 8 * t;
-            std::fprintf(stderr, "TRACE %d: pt(%d,%d) n=%d val=%d end=(%d,%d) good=%d count=%d\n", t, e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]);
-        }
-    }
-#endif
+
     PRL_HIP_CHECK(hipGetLastError());
     std::vector<unsigned> h_nl((size_t)n_pages);
     std::vector<int> h_lines((size_t)ln_total * 4 + 4);
