@@ -51,6 +51,7 @@ constexpr int CPL = 8;                 // columns per lane
 constexpr int SW = kWave * CPL;        // padded columns per wavefront strip
 constexpr unsigned kRefineCap = 1u << 20;  // pixels the float32 test may leave undecided per call
 constexpr unsigned kWorkCap = 1u << 14;    // pixels the float64 interval test may leave undecided (more: literal page)
+constexpr size_t kSegmaxCap = 1u << 20;    // wavefronts per call whose sweep-A maxima can be kept (Wolf)
 
 struct RefItem {   // undecided after the float32 test: exact window sums travel with the pixel
     int page, y, x;
@@ -970,7 +971,8 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
 template <int METHOD>
 __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, FusedParams fp, PageGlobals* __restrict__ g,
                                                const RefItem* __restrict__ rl, WorkItem* __restrict__ wl,
-                                               unsigned* __restrict__ counters, CornerAcc* __restrict__ acc)
+                                               unsigned* __restrict__ counters, CornerAcc* __restrict__ acc,
+                                               unsigned* __restrict__ done)
 {
     const unsigned n = min(counters[0], fp.ref_cap);
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
@@ -1016,6 +1018,7 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
                 wl[idx] = w;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[idx].a[k] = 0ull;  // (instead of a 1 MB memset per call: nothing is queued as a rule)
+                done[idx] = 0u;
             } else {
                 atomicOr(&g[it.page].worklist_overflow, 1u);
             }
@@ -1079,9 +1082,16 @@ __device__ __forceinline__ void row_range_sums(const uint8_t* row, int ca, int c
     *q_out = q;
 }
 
+// FINAL: the workgroup that delivers the last of a pixel's kSplit partial sums also runs the literal evaluation
+// (k_fixup_final's body) - one launch less per call; `done` counts the arrivals per pixel (zeroed by k_refine when it
+// queues the pixel).
+__device__ __forceinline__ void literal_mq(const CornerAcc& c, double f, double* m, double* q);
+
+template <bool FINAL>
 __global__ void __launch_bounds__(256) k_corner_partial(PageSet src, FusedParams fp, const WorkItem* __restrict__ items,
                                                        const unsigned* __restrict__ counters, int which,
-                                                       CornerAcc* __restrict__ acc)
+                                                       CornerAcc* __restrict__ acc, PageSetOut dst,
+                                                       const PageGlobals* __restrict__ g, unsigned* __restrict__ done)
 {
     const ThrParams& tp = fp.tp;
     const unsigned n = min(counters[which], fp.wl_cap);
@@ -1134,6 +1144,23 @@ __global__ void __launch_bounds__(256) k_corner_partial(PageSet src, FusedParams
             const unsigned long long v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
             if (v != 0) atomicAdd(&acc[it].a[threadIdx.x], v);
         }
+        if constexpr (FINAL) {
+            __threadfence();   // this workgroup's sums are visible before its arrival is
+            __syncthreads();
+            if (threadIdx.x == 0 && atomicAdd(&done[it], 1u) == gridDim.x - 1) {
+                __threadfence();
+                CornerAcc c;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c.a[k] = atomicAdd(&acc[it].a[k], 0ull);  // (read at the L2, past this CU's caches)
+                double m, q;
+                literal_mq(c, tp.f, &m, &q);
+                const double s = dev_from(m, q);
+                const PageGlobals& pg = g[wi.page];
+                const double T = threshold_literal(tp, m, s, (double)pg.imin, pg.coeff);
+                const unsigned p = img[(size_t)wi.y * src.step + wi.x];
+                store_decision(dst, fp.bit_out, wi.page, wi.y, wi.x, decide_literal(p, T));
+            }
+        }
         __syncthreads();
     }
 }
@@ -1147,26 +1174,6 @@ __device__ __forceinline__ void literal_mq(const CornerAcc& c, double f, double*
                  DQ = (double)(t[4] + t[5] + t[6] + t[7]);
     *m = box4_literal(A, B, C, D, f);
     *q = box4_literal(AQ, BQ, CQ, DQ, f);
-}
-
-// ---- fix-up: literal evaluation of the queued pixels (prl_device_math.h) from their absolute corners ----
-__global__ void __launch_bounds__(256) k_fixup_final(PageSet src, PageSetOut dst, FusedParams fp,
-                                                    const PageGlobals* __restrict__ g,
-                                                    const WorkItem* __restrict__ wl, const CornerAcc* __restrict__ acc,
-                                                    const unsigned* __restrict__ counters)
-{
-    const ThrParams& tp = fp.tp;
-    const unsigned n = min(counters[1], fp.wl_cap);
-    for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < n; it += gridDim.x * blockDim.x) {
-        const WorkItem wi = wl[it];
-        double m, q;
-        literal_mq(acc[it], tp.f, &m, &q);
-        const double s = dev_from(m, q);
-        const PageGlobals& pg = g[wi.page];
-        const double T = threshold_literal(tp, m, s, (double)pg.imin, pg.coeff);
-        const unsigned p = src.page(wi.page)[(size_t)wi.y * src.step + wi.x];
-        store_decision(dst, fp.bit_out, wi.page, wi.y, wi.x, decide_literal(p, T));
-    }
 }
 
 // Wolf-Jolion: literal deviation of every candidate of sweep B; their maximum is exactly
@@ -1264,14 +1271,14 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     int st = launch_sweep<METHOD>(sh, stream, src, dst, fp, g, rl, cand, cnt);
     if (st != PRL_OK) return st;
     if (ev_stop) PRL_HIP_CHECK(hipEventRecord(ev_stop, stream));
-    hipLaunchKernelGGL((k_refine<METHOD>), dim3(fp.flt ? 1024 : 64), dim3(256), 0, stream, src, dst, fp, g, rl, wl, cnt, acc);
+    unsigned* done = reinterpret_cast<unsigned*>(fp.segmax + kSegmaxCap);  // arrivals per queued pixel (see fused_small_bytes)
+    hipLaunchKernelGGL((k_refine<METHOD>), dim3(fp.flt ? 256 : 64), dim3(256), 0, stream, src, dst, fp, g, rl, wl, cnt, acc, done);
     PRL_HIP_CHECK(hipGetLastError());
     if (!with_fixup) return PRL_OK;
-    // literal fix-up of what k_refine queued: both kernels read the queue length on the device and do nothing when it is
-    // empty (the usual case), so no host round trip decides whether they run; k_refine zeroed the accumulators it uses
-    hipLaunchKernelGGL(k_corner_partial, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc);
-    PRL_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_fixup_final, dim3(16), dim3(256), 0, stream, src, dst, fp, g, wl, acc, cnt);
+    // literal fix-up of what k_refine queued: the kernel reads the queue length on the device and does nothing when it is
+    // empty (the usual case), so no host round trip decides whether it runs; k_refine zeroed the accumulators it uses; the
+    // workgroup that delivers a pixel's last partial sum evaluates the pixel (no separate k_fixup_final launch)
+    hipLaunchKernelGGL(k_corner_partial<true>, dim3(kSplit, 16), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc, dst, g, done);  // (1024 workgroups: an empty queue is the rule, and its launch should cost little)
     PRL_HIP_CHECK(hipGetLastError());
     return PRL_OK;
 }
@@ -1421,13 +1428,11 @@ extern "C" int prl_hip_internal_flt_q_error(int w, double* delta_qmin_cq)
     return flt_usable(tp, 1, &delta_qmin_cq[2], &delta_qmin_cq[0], &delta_qmin_cq[1]) ? 1 : 0;
 }
 
-constexpr size_t kSegmaxCap = 1u << 20;  // wavefronts per call whose sweep-A maxima can be kept (Wolf)
-
 size_t fused_small_bytes(int)
 {
-    // [counters 256 B][refine list][fix-up list][Wolf candidate list][corner sums][Wolf per-wavefront maxima]
+    // [counters 256 B][refine list][fix-up list][Wolf candidate list][corner sums][Wolf per-wavefront maxima][arrival counters]
     return 256 + sizeof(RefItem) * (size_t)kRefineCap + 2 * sizeof(WorkItem) * (size_t)kWorkCap +
-           sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(float) * kSegmaxCap;
+           sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(float) * kSegmaxCap + sizeof(unsigned) * (size_t)kWorkCap;
 }
 
 // Pages one fused_run call may take.  Wolf-Jolion keeps one float per wavefront of the call (sweep A -> sweep B), kSegmaxCap
@@ -1445,7 +1450,8 @@ int fused_max_pages(const ThrParams& tp)
 // k_refine queued in an earlier phase-1 call with the same arguments (the caller reads PageGlobals::n_exact in between
 // and skips phase 2 - two launches and a 1 MB memset - when nothing was queued, the usual case)
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst, void* small,
-              PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool bit_out, int phase)
+              PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool bit_out, int phase,
+              bool counters_zeroed)
 {
     FusedParams fp{};
     fp.tp = tp;
@@ -1513,16 +1519,14 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     auto* cand = wl + kWorkCap;
     auto* acc = reinterpret_cast<CornerAcc*>(cand + kWorkCap);
     fp.segmax = reinterpret_cast<float*>(acc + kWorkCap);
-    if (phase == 2) {
-        PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, stream));
-        hipLaunchKernelGGL(k_corner_partial, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc);
-        PRL_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(k_fixup_final, dim3(16), dim3(256), 0, stream, src, dst, fp, d_globals, wl, acc, cnt);
+    if (phase == 2) {  // (kept for callers that split the pipeline; k_refine of phase 1 zeroed what this uses)
+        unsigned* done = reinterpret_cast<unsigned*>(fp.segmax + kSegmaxCap);
+        hipLaunchKernelGGL(k_corner_partial<true>, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc, dst, d_globals, done);
         PRL_HIP_CHECK(hipGetLastError());
         return PRL_OK;
     }
     const bool with_fixup = phase == 0;
-    PRL_HIP_CHECK(hipMemsetAsync(cnt, 0, 256, stream));
+    if (!counters_zeroed) PRL_HIP_CHECK(hipMemsetAsync(cnt, 0, 256, stream));
 
     if (tp.method == PRL_FENG) {
         int st = page_min_run(tp, src, n_pages, d_globals, stream);
@@ -1555,7 +1559,8 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         st = launch_sweep<kWolfCollect>(sh, stream, src, dst, fp, d_globals, rl, cand, cnt);
         if (st != PRL_OK) return st;
         PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, stream));
-        hipLaunchKernelGGL(k_corner_partial, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, cand, cnt, 2, acc);
+        hipLaunchKernelGGL(k_corner_partial<false>, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, cand, cnt, 2, acc, dst, d_globals,
+                           static_cast<unsigned*>(nullptr));
         PRL_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(k_wolf_final, dim3(16), dim3(256), 0, stream, fp, d_globals, cand, acc, cnt);
         PRL_HIP_CHECK(hipGetLastError());

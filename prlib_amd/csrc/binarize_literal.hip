@@ -35,9 +35,10 @@ __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v)
     return v;
 }
 
-__global__ void k_init_globals(PageGlobals* g, int n)
+__global__ void k_init_globals(PageGlobals* g, int n, unsigned* counters)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (counters && i < 64) counters[i] = 0u;  // the fused pipeline's 256-byte counter block (one launch instead of two)
     if (i < n) {
         g[i].imin = 255;
         g[i].smax_found = 0;
@@ -246,10 +247,10 @@ size_t literal_scratch_per_page(const ThrParams& tp)
     return 2 * sizeof(double) * (size_t)tp.pw * (size_t)tp.ph;
 }
 
-int init_globals_run(PageGlobals* d_globals, int n_pages, hipStream_t stream)
+int init_globals_run(PageGlobals* d_globals, int n_pages, hipStream_t stream, void* fused_counters)
 {
     hipLaunchKernelGGL(k_init_globals, dim3((n_pages + 255) / 256), dim3(256), 0, stream, d_globals,
-                       n_pages);
+                       n_pages, static_cast<unsigned*>(fused_counters));
     PRL_HIP_CHECK(hipGetLastError());
     return PRL_OK;
 }

@@ -19,7 +19,7 @@
 
 namespace prl_hip {
 
-int init_globals_run(PageGlobals* d_globals, int n_pages, hipStream_t stream);
+int init_globals_run(PageGlobals* d_globals, int n_pages, hipStream_t stream, void* fused_counters = nullptr);
 
 namespace {
 
@@ -725,7 +725,7 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         thr_dst.step = bit_mask ? bit_step : mask_step;
     }
 
-    st = init_globals_run(d_globals, n_pages, stream);
+    st = init_globals_run(d_globals, n_pages, stream, use_fused ? d_fused : nullptr);  // (+ the fused pipeline's counter block)
     if (st != PRL_OK) return st;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -742,7 +742,7 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         // threshold sweep, float64 interval test of what it left open, literal fix-up of what THAT left open: all enqueued,
         // the last two find their queues on the device and do nothing when they are empty.  Pages whose fix-up queue
         // overflowed are flagged; the flags travel to the pinned slot and are looked at in resolve_front().
-        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask, 0);
+        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask, 0, true);
         if (st != PRL_OK) return st;
         PRL_HIP_CHECK(hipMemcpyAsync(pin + 2 * sl.table_bytes, d_globals, sizeof(PageGlobals) * (size_t)n_pages,
                                      hipMemcpyDeviceToHost, stream));
