@@ -1,16 +1,39 @@
 #!/usr/bin/env python3
-"""BASELINE config 5 on one GPU: deskew -> NL-means -> backgroundNormalization -> Sauvola -> Zhang-Suen thinning on a batch
-of A4 colour scans, device resident.  Prints one JSON object: per-stage times (stages called one after the other through
-the public entry points) and the one-call chain (prl_hip_chain_pages_device)."""
+"""BASELINE config 5: deskew -> NL-means -> backgroundNormalization -> Sauvola -> Zhang-Suen thinning on a batch of A4 colour
+scans, device resident.  Prints one JSON object: per-stage times (stages called one after the other through the public entry
+points) and the one-call chain (prl_hip_chain_pages_device).
+
+    python tools/bench_chain5.py --pages 1024                 one GPU
+    python tools/bench_chain5.py --pages 1024 --gpus 8        the 1024-page list split over 8 ranks (one process per GPU, started
+                                                              here as a child torch.distributed.run; pages are independent: no
+                                                              data-path collective, RCCL only for the barrier / max of the times)
+"""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _spawn(n):
+    import socket, subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+if "--gpus" in sys.argv and "WORLD_SIZE" not in os.environ:
+    _n = int(sys.argv[sys.argv.index("--gpus") + 1])
+    if _n > 1:
+        sys.exit(_spawn(_n))   # before anything touches a GPU
+
 import numpy as np
 import torch
 import prlib_amd
-from prlib_amd import synth
+from prlib_amd import dist as pdist, synth
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--pages", type=int, default=1024)
+ap.add_argument("--pages", type=int, default=1024, help="pages in the whole list (split over the ranks)")
+ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--width", type=int, default=2480)
 ap.add_argument("--height", type=int, default=3508)
 ap.add_argument("--channels", type=int, default=3)
@@ -20,9 +43,15 @@ ap.add_argument("--stages", type=int, default=1, help="also time the stages one 
 ap.add_argument("--stage-pages", type=int, default=64)
 ap.add_argument("--check-pages", type=int, default=0, help="pages compared with the composed CPU oracle (slow: NL-means on the host)")
 a = ap.parse_args()
-dev = torch.device("cuda:0")
+world, rank, local_rank = pdist.init()
+if world != a.gpus:
+    raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+dev = torch.device("cuda", torch.cuda.current_device())
+mine = pdist.page_range(a.pages, world, rank)
+total_pages = a.pages
+a.pages = len(mine)
 t0 = time.perf_counter()
-pages, skews = synth.text_pages_torch(a.pages, a.height, a.width, dev, channels=a.channels)
+pages, skews = synth.text_pages_torch(a.pages, a.height, a.width, dev, seed=7000 + mine.start, channels=a.channels)
 torch.cuda.synchronize()
 gen_s = time.perf_counter() - t0
 px_in = a.pages * a.width * a.height
@@ -39,7 +68,7 @@ def timed(fn):
 res = {"workload": f"{a.pages} x {a.width}x{a.height}x{a.channels} synthetic text scans (skew +-4 deg, shaded), 1 GPU, device resident; "
                    f"deskew -> denoise({a.strength}) -> backgroundNormalization -> Sauvola w={a.window} k=0.34 morph=0 -> Zhang-Suen",
        "generate_s": round(gen_s, 2)}
-if a.stages:
+if a.stages and world == 1:
     n = min(a.stage_pages, a.pages)
     sub = pages[:n]
     t_desk, (outs, ang) = timed(lambda: prlib_amd.deskew(sub))
@@ -61,11 +90,15 @@ if a.stages:
                      "angle_abs_err_deg_mean": round(float(np.abs(ang - skews[:n]).mean()), 3)}
     del outs, sq, den, bg, g8, mask, inv, sk
     torch.cuda.empty_cache()
+pdist.barrier()
 t_chain, (outs, angles) = timed(lambda: prlib_amd.process_pages(pages, a.channels, prlib_amd.SAUVOLA, a.window, 0.34, 0,
                                                                 denoise_strength=a.strength, thin=0, deskew=True,
                                                                 background_normalization=True))
-res.update({"chain_one_call_s": round(t_chain, 3), "chain_input_Mpx_s": round(px_in / t_chain / 1e6, 1),
-            "pages_per_s": round(a.pages / t_chain, 2),
+t_chain = pdist.max_over_ranks(t_chain, device=dev)   # the job is done when the slowest rank is
+px_in = total_pages * a.width * a.height
+res.update({"n_gpus": world, "pages_total": total_pages, "pages_this_rank": a.pages,
+            "chain_one_call_s": round(t_chain, 3), "chain_input_Mpx_s": round(px_in / t_chain / 1e6, 1),
+            "pages_per_s": round(total_pages / t_chain, 2),
             "rotated_pages": int(sum(1 for o in outs if o.shape[0] == o.shape[1])),
             "angle_abs_err_deg_mean": round(float(np.abs(angles - skews).mean()), 3),
             "skeleton_fraction": round(float(np.mean([float((o > 0).float().mean()) for o in outs[:8]])), 5)})
@@ -82,4 +115,6 @@ if a.check_pages:
         got = outs[i].cpu().numpy()
         bad += int(got.shape != want.shape or (got != want).sum() or info["angle"] != angles[i])
     res["parity"] = {"checked_pages": int(a.check_pages), "pages_with_any_difference": bad}
-print(json.dumps(res))
+if rank == 0:
+    print(json.dumps(res))
+pdist.finish()
