@@ -36,39 +36,59 @@ struct BgGeom {
     size_t inv_page;   // elements of one page's u16 inverse maps
 };
 
+// One workgroup = one tile row (15 page rows) x 25 tiles = 250 page columns + the 3-column halo of the dilation on both
+// sides: thread t owns page column x0 - 3 + t, reads its 21 rows (15 + the 3-row halo above and below) ONCE, keeps the
+// threshold flags of those rows as a 21-bit word and the 15 rows' pixel values in registers.  The 7 x 1 dilation is the OR
+// of seven neighbouring threads' words (LDS, one word per column, conflict-free), the 1 x 7 dilation seven shifts of the
+// result - all 21 rows at once - so the foreground mask costs 7 LDS reads per column instead of the 147 byte reads of the
+// first version, and the page is read once instead of 2.4 times.
 template <int CH>
 __global__ void __launch_bounds__(256) k_bg_tiles(PageSet src, BgGeom g, uint8_t* __restrict__ maps)
 {
     constexpr int OCH = CH == 1 ? 1 : 3;
     constexpr int GCH = CH == 1 ? 0 : 1;  // pixConvertRGBToGrayFast: the green slot
-    __shared__ uint8_t flags[FLAG_ROWS][256];
+    __shared__ unsigned colbits[256 + 8];
     __shared__ unsigned short colsum[OCH][COLS_PER_BLOCK];
     __shared__ uint8_t colcnt[COLS_PER_BLOCK];
     const int page = blockIdx.z, ty = blockIdx.y, t = threadIdx.x;
     const int x0 = blockIdx.x * COLS_PER_BLOCK;
     const uint8_t* base = src.page(page);
-    {
-        const int x = x0 - 3 + t;
-        const bool xin = x >= 0 && x < g.width;
+    const int x = x0 - 3 + t;
+    const bool xin = x >= 0 && x < g.width;
+    unsigned bits = 0;          // bit r: page row ty*15 - 3 + r of this column is below the threshold
+    unsigned px[SY][OCH];       // the 15 tile rows of this column
 #pragma unroll
-        for (int r = 0; r < FLAG_ROWS; ++r) {
-            const int y = ty * SY - 3 + r;
-            uint8_t f = 0;
-            if (xin && y >= 0 && y < g.height) f = base[(size_t)y * src.step + (size_t)x * CH + GCH] < THRESH;
-            flags[r][t] = f;
+    for (int r = 0; r < FLAG_ROWS; ++r) {
+        const int y = ty * SY - 3 + r;
+        unsigned v[OCH];
+#pragma unroll
+        for (int c = 0; c < OCH; ++c) v[c] = 255;
+        if (xin && y >= 0 && y < g.height) {
+            const uint8_t* p = base + (size_t)y * src.step + (size_t)x * CH;
+#pragma unroll
+            for (int c = 0; c < OCH; ++c) v[c] = p[c];
+            bits |= (unsigned)(v[GCH] < THRESH) << r;
+        }
+        if (r >= 3 && r < 3 + SY) {
+#pragma unroll
+            for (int c = 0; c < OCH; ++c) px[r - 3][c] = v[c];
         }
     }
+    colbits[t] = bits;
+    if (t < 8) colbits[256 + t] = 0;
     __syncthreads();
-    const int x = x0 + t;
-    if (t < COLS_PER_BLOCK) {
-        unsigned hd = 0;  // bit r: horizontal dilation of flag row r at this column
+    // thread t now plays tile column x0 + t (its own pixels belong to column x0 - 3 + t: the sums below use the owner's
+    // registers, so the dilation result is computed for the OWNED column: neighbours t-3 .. t+3)
+    unsigned hd = 0;
 #pragma unroll
-        for (int r = 0; r < FLAG_ROWS; ++r) {
-            unsigned v = 0;
-#pragma unroll
-            for (int d = 0; d < 7; ++d) v |= flags[r][t + d];
-            hd |= v << r;
-        }
+    for (int d = -3; d <= 3; ++d) {
+        const int n = t + d;
+        hd |= (n >= 0 && n < 256) ? colbits[n] : 0u;
+    }
+    // vertical 1 x 7: bit k of fg = OR of hd bits k .. k+6 (rows y-3 .. y+3 of tile row k)
+    const unsigned fg = hd | (hd >> 1) | (hd >> 2) | (hd >> 3) | (hd >> 4) | (hd >> 5) | (hd >> 6);
+    const int tc = t - 3;  // index of the owned column inside the block's 250 tile columns
+    if (tc >= 0 && tc < COLS_PER_BLOCK) {
         unsigned sum[OCH];
 #pragma unroll
         for (int c = 0; c < OCH; ++c) sum[c] = 0;
@@ -76,17 +96,16 @@ __global__ void __launch_bounds__(256) k_bg_tiles(PageSet src, BgGeom g, uint8_t
         if (x < g.nx * SX) {
 #pragma unroll
             for (int k = 0; k < SY; ++k) {
-                if (((hd >> k) & 0x7fu) == 0) {  // rows k..k+6 of the flag block = page rows y-3..y+3
-                    const uint8_t* p = base + (size_t)(ty * SY + k) * src.step + (size_t)x * CH;
+                if (((fg >> k) & 1u) == 0) {
 #pragma unroll
-                    for (int c = 0; c < OCH; ++c) sum[c] += p[c];
+                    for (int c = 0; c < OCH; ++c) sum[c] += px[k][c];
                     ++cnt;
                 }
             }
         }
 #pragma unroll
-        for (int c = 0; c < OCH; ++c) colsum[c][t] = (unsigned short)sum[c];
-        colcnt[t] = (uint8_t)cnt;
+        for (int c = 0; c < OCH; ++c) colsum[c][tc] = (unsigned short)sum[c];
+        colcnt[tc] = (uint8_t)cnt;
     }
     __syncthreads();
     if (t < TILES_PER_BLOCK) {
@@ -112,12 +131,20 @@ __global__ void __launch_bounds__(256) k_bg_tiles(PageSet src, BgGeom g, uint8_t
 __global__ void __launch_bounds__(256) k_bg_maps(BgGeom g, int och, uint8_t* __restrict__ maps, unsigned short* __restrict__ inv,
                                                  int* __restrict__ page_fail)
 {
-    constexpr int MAX_MW = 8192;
+    constexpr int MAX_MW = 4096;
     __shared__ uint8_t na[MAX_MW];
     __shared__ int s_nmiss, s_goodcol;
     const int c = blockIdx.x, page = blockIdx.y, t = threadIdx.x;
     const int w = g.mw, h = g.mh, nx = g.nx, ny = g.ny;
-    volatile uint8_t* m = maps + (size_t)page * g.map_page + (size_t)c * w * h;
+    // the map itself is tiny (248 x 234 bytes for A4): work on an LDS copy when it fits (the column fills are chains of
+    // dependent accesses: 0.61 -> see DESIGN 4.9 ms for 64 maps from memory), on the global one otherwise
+    constexpr int LDS_MAP = 60000;  // an A4 map is 248 x 234 = 58 032 bytes
+    __shared__ uint8_t lmap[LDS_MAP];
+    uint8_t* gm = maps + (size_t)page * g.map_page + (size_t)c * w * h;
+    const bool in_lds = w * h <= LDS_MAP;
+    if (in_lds)
+        for (int i = t; i < w * h; i += 256) lmap[i] = gm[i];
+    uint8_t* m = in_lds ? lmap : gm;  // (phases are separated by workgroup barriers; no volatile: the memory path stays cached)
     if (t == 0) { s_nmiss = 0; s_goodcol = w; }
     __syncthreads();
     // pixFillMapHoles, columns
@@ -201,9 +228,14 @@ __global__ void __launch_bounds__(256) k_bg_apply(PageSet src, PageSetOut dst, B
                                                   const int* __restrict__ page_fail)
 {
     constexpr int OCH = CH == 1 ? 1 : 3;
-    const int page = blockIdx.z, y = blockIdx.y;
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (x0 >= g.width) return;
+    // one thread per group of 4 pixels, groups numbered row after row (a row of 2480 pixels is 2.4 workgroups: no
+    // workgroup is left two thirds empty at the end of every row, as with one grid row per page row)
+    const int page = blockIdx.y;
+    const unsigned groups = (unsigned)(g.width + 3) / 4u;
+    const unsigned gi = blockIdx.x * 256u + threadIdx.x;
+    const int y = (int)(gi / groups);
+    if (y >= g.height) return;
+    const int x0 = (int)(gi - (unsigned)y * groups) * 4;
     const int n = min(4, g.width - x0);
     const uint8_t* s = src.page(page) + (size_t)y * src.step + (size_t)x0 * CH;
     uint8_t* d = dst.page(page) + (size_t)y * dst.step + (size_t)x0 * OCH;
@@ -285,7 +317,7 @@ int bgnorm_run(int n_pages, int channels, const PageSet& src, int width, int hei
     }
     hipLaunchKernelGGL(k_bg_maps, dim3((unsigned)och, (unsigned)n_pages), dim3(256), 0, stream, g, och, maps, inv, fail);
     PRL_HIP_CHECK(hipGetLastError());
-    const dim3 agrid((unsigned)((width + 1023) / 1024), (unsigned)height, (unsigned)n_pages);
+    const dim3 agrid((unsigned)(((size_t)((width + 3) / 4) * height + 255) / 256), (unsigned)n_pages);
     if (channels == 1) hipLaunchKernelGGL(k_bg_apply<1>, agrid, dim3(256), 0, stream, src, dst, g, inv, fail);
     else if (channels == 3) hipLaunchKernelGGL(k_bg_apply<3>, agrid, dim3(256), 0, stream, src, dst, g, inv, fail);
     else hipLaunchKernelGGL(k_bg_apply<4>, agrid, dim3(256), 0, stream, src, dst, g, inv, fail);
@@ -309,7 +341,7 @@ int prl_hip_bgnorm_batch_device(int n_pages, int channels, const uint8_t* d_src,
     const int och = channels == 1 ? 1 : 3;
     if (n_pages < 0 || !d_src || !d_dst || src_step < (size_t)width * channels || dst_step < (size_t)width * och)
         return PRL_ERR_BAD_ARG;
-    if (height > 65535 || width > 81920) return PRL_ERR_BAD_ARG;  // grid.y; k_bg_maps' column flags
+    if (height > 65535 || width > 40950) return PRL_ERR_BAD_ARG;  // grid.y; k_bg_maps' column flags
     if (n_pages == 0) return PRL_OK;
     int dev;
     int st = current_device(&dev);

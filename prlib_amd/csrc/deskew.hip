@@ -408,39 +408,129 @@ struct WarpPage {
     int ow, oh;
 };
 
+// 8 bytes at any alignment (global memory takes unaligned dword accesses on gfx9+)
+__device__ __forceinline__ uint2 load8u(const uint8_t* p)
+{
+    uint2 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ unsigned byte_at(uint2 v, int i) { return ((i < 4 ? v.x : v.y) >> (8 * (i & 3))) & 0xffu; }
+
+// A workgroup produces 256 consecutive pixels of one output row; the result bytes go through LDS so that the row segment is
+// stored as dwords (byte stores of CH-byte pixels cost three to four instructions per pixel).  Pages of kind 1 / 3
+// (quarter turns) are left to k_rot90.
 template <int CH>
 __global__ void __launch_bounds__(256) k_warp(PageSet src, PageSetOut dst, int width, int height, const WarpPage* __restrict__ wp)
 {
-    const int page = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint8_t seg[256 * CH + 16];
+    const int page = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * 256, x = x0 + (int)threadIdx.x;
     const WarpPage& p = wp[page];
-    if (x >= p.ow || y >= p.oh) return;
+    if (p.kind == 1 || p.kind == 3 || x0 >= p.ow || y >= p.oh) return;
     const uint8_t* s = src.page(page);
-    uint8_t* d = dst.page(page) + (size_t)y * dst.step + (size_t)x * CH;
-    if (p.kind != 0) {
-        int sx = x, sy = y;
-        if (p.kind == 1) { sx = y; sy = height - 1 - x; }
-        else if (p.kind == 2) { sx = width - 1 - x; sy = height - 1 - y; }
-        else if (p.kind == 3) { sx = width - 1 - y; sy = x; }
-        const uint8_t* q = s + (size_t)sy * src.step + (size_t)sx * CH;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) d[c] = q[c];
-        return;
+    // the row terms of the coordinates are the same for the whole workgroup: one lane computes them (float64)
+    __shared__ int rowXY[2];
+    if (p.kind == 0) {
+        if (threadIdx.x == 0) {
+            rowXY[0] = __double2int_rn((p.M[1] * y + p.M[2]) * 1024) + 16;
+            rowXY[1] = __double2int_rn((p.M[4] * y + p.M[5]) * 1024) + 16;
+        }
+        __syncthreads();
     }
-    const int X0 = __double2int_rn((p.M[1] * y + p.M[2]) * 1024) + 16, Y0 = __double2int_rn((p.M[4] * y + p.M[5]) * 1024) + 16;
-    const int X = (X0 + __double2int_rn(p.M[0] * x * 1024)) >> 5, Y = (Y0 + __double2int_rn(p.M[3] * x * 1024)) >> 5;
-    const int sx = max(-32768, min(32767, X >> 5)), sy = max(-32768, min(32767, Y >> 5));
-    const int fx = X & 31, fy = Y & 31;
-    const int w00 = 32 * (32 - fx) * (32 - fy), w01 = 32 * fx * (32 - fy), w10 = 32 * (32 - fx) * fy, w11 = 32 * fx * fy;
-    const bool x0in = sx >= 0 && sx < width, x1in = sx + 1 >= 0 && sx + 1 < width;
-    const bool y0in = sy >= 0 && sy < height, y1in = sy + 1 >= 0 && sy + 1 < height;
-    const uint8_t* r0 = s + (size_t)sy * src.step + (size_t)sx * CH;  // only dereferenced where the flags allow
-    const uint8_t* r1 = r0 + src.step;
+    unsigned res[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        // the source is cv::bitwise_not(input); outside it the border value 0
-        const int v00 = (x0in && y0in) ? 255 - r0[c] : 0, v01 = (x1in && y0in) ? 255 - r0[CH + c] : 0;
-        const int v10 = (x0in && y1in) ? 255 - r1[c] : 0, v11 = (x1in && y1in) ? 255 - r1[CH + c] : 0;
-        d[c] = (uint8_t)(255 - ((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15));
+    for (int c = 0; c < CH; ++c) res[c] = 0;
+    if (x < p.ow) {
+        if (p.kind != 0) {  // 2: half turn; 4: copy
+            const int sx = p.kind == 2 ? width - 1 - x : x, sy = p.kind == 2 ? height - 1 - y : y;
+            const uint8_t* q = s + (size_t)sy * src.step + (size_t)sx * CH;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) res[c] = q[c];
+        } else {
+            const int X0 = rowXY[0], Y0 = rowXY[1];
+            const int X = (X0 + __double2int_rn(p.M[0] * x * 1024)) >> 5, Y = (Y0 + __double2int_rn(p.M[3] * x * 1024)) >> 5;
+            const int sx = max(-32768, min(32767, X >> 5)), sy = max(-32768, min(32767, Y >> 5));
+            const int fx = X & 31, fy = Y & 31;
+            const int w00 = 32 * (32 - fx) * (32 - fy), w01 = 32 * fx * (32 - fy), w10 = 32 * (32 - fx) * fy, w11 = 32 * fx * fy;
+            const bool x0in = sx >= 0 && sx < width, x1in = sx + 1 >= 0 && sx + 1 < width;
+            const bool y0in = sy >= 0 && sy < height, y1in = sy + 1 >= 0 && sy + 1 < height;
+            const uint8_t* r0 = s + (size_t)sy * src.step + (size_t)sx * CH;  // only dereferenced where the flags allow
+            const uint8_t* r1 = r0 + src.step;
+            // both taps of a row are 2 * CH <= 8 consecutive bytes: one 8-byte fetch per row when all four taps are inside
+            // and the fetch cannot run past the page's last row
+            const bool wide = x0in && x1in && y0in && y1in && (sy + 2 < height || sx * CH + 8 <= (int)src.step);
+            if (wide) {
+                const uint2 a = load8u(r0), b = load8u(r1);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int v00 = 255 - (int)byte_at(a, c), v01 = 255 - (int)byte_at(a, CH + c);
+                    const int v10 = 255 - (int)byte_at(b, c), v11 = 255 - (int)byte_at(b, CH + c);
+                    res[c] = (unsigned)(255 - ((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15));
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    // the source is cv::bitwise_not(input); outside it the border value 0
+                    const int v00 = (x0in && y0in) ? 255 - r0[c] : 0, v01 = (x1in && y0in) ? 255 - r0[CH + c] : 0;
+                    const int v10 = (x0in && y1in) ? 255 - r1[c] : 0, v11 = (x1in && y1in) ? 255 - r1[CH + c] : 0;
+                    res[c] = (unsigned)(255 - ((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15));
+                }
+            }
+        }
+    }
+    // the segment's bytes: [head up to the first 4-byte boundary of the destination][dwords][tail]
+    uint8_t* d0 = dst.page(page) + (size_t)y * dst.step + (size_t)x0 * CH;
+    const int nbytes = min(256, p.ow - x0) * CH;
+    const int head = min(nbytes, (int)((4 - ((size_t)d0 & 3)) & 3));
+    // the LDS image is shifted so that destination-aligned dwords are LDS-aligned dwords
+    const int shift = (4 - head) & 3;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) seg[shift + (int)threadIdx.x * CH + c] = (uint8_t)res[c];
+    __syncthreads();
+    if ((int)threadIdx.x < head) d0[threadIdx.x] = seg[shift + threadIdx.x];
+    const int ndw = (nbytes - head) / 4;
+    const unsigned* sw = reinterpret_cast<const unsigned*>(seg + shift + head);
+    unsigned* dw = reinterpret_cast<unsigned*>(d0 + head);
+    for (int i = threadIdx.x; i < ndw; i += 256) dw[i] = sw[i];
+    const int tail0 = head + ndw * 4;
+    if ((int)threadIdx.x < nbytes - tail0) d0[tail0 + threadIdx.x] = seg[shift + tail0 + threadIdx.x];
+}
+
+// Quarter turns (rotate.cpp:38-58): out(y, x) = in(height - 1 - x, y) for 90, in(x, width - 1 - y) for 270.  A 32 x 32 tile
+// is read along source rows, turned in LDS and written along destination rows (the straightforward one-thread-per-pixel
+// form reads a different source row in every lane: 7.0 ms for 64 A4 colour pages, 6 % of the roofline).
+template <int CH>
+__global__ void __launch_bounds__(256) k_rot90(PageSet src, PageSetOut dst, int width, int height, const WarpPage* __restrict__ wp)
+{
+    __shared__ uint8_t tile[32][32 * CH + 4];
+    const int page = blockIdx.z;
+    const WarpPage& p = wp[page];
+    if (p.kind != 1 && p.kind != 3) return;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * 32;  // output tile; output is height (cols) x width (rows)
+    if (ox0 >= p.ow || oy0 >= p.oh) return;
+    const uint8_t* s = src.page(page);
+    // source tile: rows sy0 .. sy0+31, cols sx0 .. sx0+31 (clipped)
+    const int sx0 = p.kind == 1 ? oy0 : width - 32 - oy0, sy0 = p.kind == 1 ? height - 32 - ox0 : ox0;
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int r = i >> 5, c = i & 31;
+        const int sy = sy0 + r, sx = sx0 + c;
+        if (sy >= 0 && sy < height && sx >= 0 && sx < width) {
+            const uint8_t* q = s + (size_t)sy * src.step + (size_t)sx * CH;
+#pragma unroll
+            for (int k = 0; k < CH; ++k) tile[r][c * CH + k] = q[k];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int oy = i >> 5, ox = i & 31;
+        const int y = oy0 + oy, x = ox0 + ox;
+        if (y >= p.oh || x >= p.ow) continue;
+        // kind 1: in(height-1-x, y): row index height-1-x - sy0 = 31 - ox, col y - sx0 = oy
+        // kind 3: in(x, width-1-y): row x - sy0 = ox, col width-1-y - sx0 = 31 - oy
+        const int r = p.kind == 1 ? 31 - ox : ox, c = p.kind == 1 ? oy : 31 - oy;
+        uint8_t* d = dst.page(page) + (size_t)y * dst.step + (size_t)x * CH;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) d[k] = tile[r][c * CH + k];
     }
 }
 
@@ -507,7 +597,7 @@ double vote_angle(const int* lines, int nb_lines)
 }
 
 int launch_warp(int channels, const PageSet& s, const PageSetOut& d, int width, int height, int n_pages, int max_ow, int max_oh,
-                const WarpPage* d_wp, hipStream_t stream)
+                const WarpPage* d_wp, hipStream_t stream, bool any_quarter = true)
 {
     const dim3 grid((unsigned)((max_ow + 255) / 256), (unsigned)max_oh, (unsigned)n_pages);
     switch (channels) {
@@ -517,6 +607,16 @@ int launch_warp(int channels, const PageSet& s, const PageSetOut& d, int width, 
     default: hipLaunchKernelGGL(k_warp<4>, grid, dim3(256), 0, stream, s, d, width, height, d_wp); break;
     }
     PRL_HIP_CHECK(hipGetLastError());
+    if (any_quarter) {
+        const dim3 g2((unsigned)((max_ow + 31) / 32), (unsigned)((max_oh + 31) / 32), (unsigned)n_pages);
+        switch (channels) {
+        case 1: hipLaunchKernelGGL(k_rot90<1>, g2, dim3(256), 0, stream, s, d, width, height, d_wp); break;
+        case 2: hipLaunchKernelGGL(k_rot90<2>, g2, dim3(256), 0, stream, s, d, width, height, d_wp); break;
+        case 3: hipLaunchKernelGGL(k_rot90<3>, g2, dim3(256), 0, stream, s, d, width, height, d_wp); break;
+        default: hipLaunchKernelGGL(k_rot90<4>, g2, dim3(256), 0, stream, s, d, width, height, d_wp); break;
+        }
+        PRL_HIP_CHECK(hipGetLastError());
+    }
     return PRL_OK;
 }
 
