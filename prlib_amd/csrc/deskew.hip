@@ -164,6 +164,7 @@ struct PphtArgs {
     int* accum;                 // per page kNumAngle * numrho, zeroed
     const float* ttab;          // kNumAngle x {cos, sin}
     int* lines; const unsigned long long* lines_off; const unsigned* lines_cap; unsigned* n_lines;
+    int prio;                   // raise the wavefront priority (PRL_HIP_PPHT_PRIO)
 };
 
 __device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }
@@ -207,6 +208,9 @@ constexpr int kBlk = 64;  // points per block of k_ppht
 // Up to 63 vector memory instructions are in flight per wavefront (the vmcnt counter), i.e. about 21 points.
 __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
 {
+    // One latency-bound wavefront per page that issues little: in the chain it shares its SIMD with the NL-means wavefronts of
+    // the previous pass (glue.hip), which saturate the vector ALU - let the arbiter pick this one first.
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
     const int page = blockIdx.x, lane = threadIdx.x;
     const int W = a.width, H = a.height, numrho = a.numrho;
     volatile uint8_t* mask = a.mask + (size_t)page * a.mask_page;
@@ -626,7 +630,7 @@ size_t r256(size_t v) { return (v + 255) / 256 * 256; }
 
 // Segments of cv::HoughLinesP(~binarized, 1, CV_PI/180, threshold, line_length, line_gap) for `n_pages` 1-channel pages
 // whose dark mask (p <= thr[page]) is the non-zero image.  `gray` pages are device resident.  Returns the segments
-// per page in `lines_out` (host).  Synchronises the stream.
+// per page in `lines_out` (host).  Synchronises the stream.  The caller holds ctx->ppht_mu (the workspace is ctx->ppht_buf).
 static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int width, int height, int threshold, int line_length,
                       int line_gap, bool otsu, int fixed_thr, std::vector<std::vector<int>>* lines_out, std::vector<int>* thr_out,
                       hipStream_t stream)
@@ -640,9 +644,9 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     const size_t b_mask = mask_page * (size_t)n_pages;
     const size_t b_accum = r256((size_t)n_pages * kNumAngle * numrho * 4);
     const size_t fixed = b_hist + b_thr + 2 * b_rows + 3 * b_cnt + 2 * b_off + b_ttab + b_mask + b_accum;
-    int st = ensure_scratch(ctx, fixed);
+    int st = ensure_buffer(&ctx->ppht_buf[0], &ctx->ppht_bytes[0], fixed);
     if (st != PRL_OK) return st;
-    uint8_t* w = static_cast<uint8_t*>(ctx->scratch);
+    uint8_t* w = static_cast<uint8_t*>(ctx->ppht_buf[0]);
     auto take = [&](size_t bytes) { uint8_t* p = w; w += bytes; return p; };
     unsigned* d_hist = reinterpret_cast<unsigned*>(take(b_hist));
     int* d_thr = reinterpret_cast<int*>(take(b_thr));
@@ -691,10 +695,12 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
         ln_total += h_cap[(size_t)i];
     }
     const size_t b_nz = r256(nz_total * 4 + 256), b_lines = r256(ln_total * 16 + 256);
-    st = ensure_mask(ctx, b_nz + b_lines);
+    // (growing synchronises the device, which would stall a chain that overlaps this search with its other stages:
+    // keep a quarter of headroom, the lists of the following passes differ by the ink on their pages)
+    if (ctx->ppht_bytes[1] < b_nz + b_lines) st = ensure_buffer(&ctx->ppht_buf[1], &ctx->ppht_bytes[1], (b_nz + b_lines) / 4 * 5);
     if (st != PRL_OK) return st;
-    unsigned* d_nz = reinterpret_cast<unsigned*>(ctx->mask);
-    int* d_lines = reinterpret_cast<int*>(static_cast<uint8_t*>(ctx->mask) + b_nz);
+    unsigned* d_nz = reinterpret_cast<unsigned*>(ctx->ppht_buf[1]);
+    int* d_lines = reinterpret_cast<int*>(static_cast<uint8_t*>(ctx->ppht_buf[1]) + b_nz);
     PRL_HIP_CHECK(hipMemcpyAsync(d_nzoff, h_nzoff.data(), (size_t)n_pages * 8, hipMemcpyHostToDevice, stream));
     PRL_HIP_CHECK(hipMemcpyAsync(d_lnoff, h_lnoff.data(), (size_t)n_pages * 8, hipMemcpyHostToDevice, stream));
     PRL_HIP_CHECK(hipMemcpyAsync(d_cap, h_cap.data(), (size_t)n_pages * 4, hipMemcpyHostToDevice, stream));
@@ -713,6 +719,7 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     a.width = width; a.height = height; a.numrho = numrho; a.threshold = threshold; a.line_length = line_length; a.line_gap = line_gap;
     a.mask = d_mask; a.mask_page = mask_page; a.nz = d_nz; a.nz_off = d_nzoff; a.count = d_count; a.accum = d_accum; a.ttab = d_ttab;
     a.lines = d_lines; a.lines_off = d_lnoff; a.lines_cap = d_cap; a.n_lines = d_nlines;
+    a.prio = env_knobs().ppht_prio;
     hipLaunchKernelGGL(k_ppht, dim3((unsigned)n_pages), dim3(64), 0, stream, a);
 
     PRL_HIP_CHECK(hipGetLastError());
@@ -736,29 +743,29 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
 static size_t ppht_bytes_per_page(int width, int height)
 {
     const size_t numrho = (size_t)(width + height) * 2 + 1;
-    return r256((size_t)width * height) + kNumAngle * numrho * 4 + (size_t)height * 8 + 2048 + (size_t)width * height / 2;
+    return 2 * r256((size_t)width * height) + kNumAngle * numrho * 4 + (size_t)height * 8 + 2048 + (size_t)width * height / 2;
 }
 
 
-size_t deskew_gray_bytes(int width, int height) { return r256((size_t)width * height); }
-
-// pages per pass of prl::deskew: bounded by a workspace budget (mask + accumulator + point lists per page)
+// pages per pass of prl::deskew: bounded by a workspace budget (mask + accumulator + point lists + gray page per page)
 int deskew_pages_per_pass(int n_pages, int width, int height)
 {
     const size_t budget = env_knobs().deskew_work_mb << 20;
     return (int)std::max<size_t>(1, std::min<size_t>({(size_t)n_pages, (size_t)16384, budget / ppht_bytes_per_page(width, height)}));
 }
 
-// prl::deskew on `cnt` pages (cnt <= deskew_pages_per_pass): gray -> Otsu -> HoughLinesP -> vote -> rotate.  gray_ws: room for
-// cnt gray pages of deskew_gray_bytes each (unused for 1-channel input).  Takes ctx->mu; the caller owns gray_ws.
-int deskew_pages(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
-                 int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, int32_t* out_wh, double* angles,
-                 uint8_t* gray_ws, hipStream_t hs)
+// First half of prl::deskew on `cnt` pages (cnt <= deskew_pages_per_pass): gray -> Otsu -> HoughLinesP -> angle vote.
+int deskew_find(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
+                int height, DeskewPlan* plan, hipStream_t hs)
 {
-    const size_t gray_page = deskew_gray_bytes(width, height);
+    const size_t gray_page = r256((size_t)width * height);
+    std::lock_guard<std::mutex> lk(ctx->ppht_mu);
     int st;
     PageSet g{};
     if (channels != 1) {  // deskew.cpp:214-217
+        st = ensure_buffer(&ctx->ppht_buf[2], &ctx->ppht_bytes[2], gray_page * (size_t)cnt);
+        if (st != PRL_OK) return st;
+        uint8_t* gray_ws = static_cast<uint8_t*>(ctx->ppht_buf[2]);
         st = prl_hip_bgr2gray_batch_device(cnt, channels, src, src_page_stride, src_step, width, height, gray_ws, gray_page,
                                            (size_t)width, hs);
         if (st != PRL_OK) return st;
@@ -767,38 +774,60 @@ int deskew_pages(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size
         g.base = src; g.page_stride = src_page_stride; g.step = src_step;
     }
     std::vector<std::vector<int>> lines;
-    std::vector<WarpPage> wp((size_t)cnt);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(hs, ctx->last_use, 0));
-    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
     // cv::threshold(..., THRESH_BINARY | THRESH_OTSU) (:224) + findAngle's bitwise_not (:146): points = (p <= otsu)
     st = ppht_pages(ctx, cnt, g, width, height, 100, (int)std::lrint((double)(width / 8.f)), (int)std::lrint(20.0), true, 0, &lines,
                     nullptr, hs);
     if (st != PRL_OK) return st;
-    int max_ow = 0, max_oh = 0;
+    plan->warp.resize(sizeof(WarpPage) * (size_t)cnt);
+    plan->wh.resize(2 * (size_t)cnt);
+    plan->angles.resize((size_t)cnt);
+    plan->max_ow = plan->max_oh = 0;
+    WarpPage* wp = reinterpret_cast<WarpPage*>(plan->warp.data());
     for (int i = 0; i < cnt; ++i) {
         const double angle = vote_angle(lines[(size_t)i].data(), (int)(lines[(size_t)i].size() / 4));
-        if (angles) angles[i] = angle;
+        plan->angles[(size_t)i] = angle;
         const bool rot = (angle != 0) && (angle <= DBL_MAX && angle >= -DBL_MAX);  // deskew.cpp:228
-        fill_warp_page(width, height, angle, !rot, &wp[(size_t)i]);
-        out_wh[2 * i] = wp[(size_t)i].ow;
-        out_wh[2 * i + 1] = wp[(size_t)i].oh;
-        max_ow = std::max(max_ow, wp[(size_t)i].ow);
-        max_oh = std::max(max_oh, wp[(size_t)i].oh);
+        fill_warp_page(width, height, angle, !rot, &wp[i]);
+        plan->wh[2 * (size_t)i] = wp[i].ow;
+        plan->wh[2 * (size_t)i + 1] = wp[i].oh;
+        plan->max_ow = std::max(plan->max_ow, wp[i].ow);
+        plan->max_oh = std::max(plan->max_oh, wp[i].oh);
     }
-    st = ensure_small(ctx, sizeof(WarpPage) * (size_t)cnt);
+    return PRL_OK;
+}
+
+// Second half: rotate.
+int deskew_apply(DeviceCtx* ctx, const DeskewPlan& plan, int cnt, int channels, const uint8_t* src, size_t src_page_stride,
+                 size_t src_step, int width, int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, hipStream_t hs)
+{
+    if (plan.warp.size() != sizeof(WarpPage) * (size_t)cnt) return PRL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(hs, ctx->last_use, 0));
+    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+    int st = ensure_small(ctx, plan.warp.size());
     if (st != PRL_OK) return st;
     ctx->lut_small[0] = ctx->lut_small[1] = nullptr;
-    PRL_HIP_CHECK(hipMemcpyAsync(ctx->small, wp.data(), sizeof(WarpPage) * (size_t)cnt, hipMemcpyHostToDevice, hs));
-    PRL_HIP_CHECK(hipStreamSynchronize(hs));
+    PRL_HIP_CHECK(hipMemcpyAsync(ctx->small, plan.warp.data(), plan.warp.size(), hipMemcpyHostToDevice, hs));
+    PRL_HIP_CHECK(hipStreamSynchronize(hs));  // pageable source
     PageSet s{};
     s.base = src; s.page_stride = src_page_stride; s.step = src_step;
     PageSetOut d{};
     d.base = dst; d.page_stride = dst_page_stride; d.step = dst_step;
-    st = launch_warp(channels, s, d, width, height, cnt, max_ow, max_oh, static_cast<const WarpPage*>(ctx->small), hs);
+    st = launch_warp(channels, s, d, width, height, cnt, plan.max_ow, plan.max_oh, static_cast<const WarpPage*>(ctx->small), hs);
     if (st != PRL_OK) return st;
     PRL_HIP_CHECK(hipEventRecord(ctx->last_use, hs));
     return PRL_OK;
+}
+
+int deskew_pages(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
+                 int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, int32_t* out_wh, double* angles, hipStream_t hs)
+{
+    DeskewPlan plan;
+    int st = deskew_find(ctx, cnt, channels, src, src_page_stride, src_step, width, height, &plan, hs);
+    if (st != PRL_OK) return st;
+    std::copy(plan.wh.begin(), plan.wh.end(), out_wh);
+    if (angles) std::copy(plan.angles.begin(), plan.angles.end(), angles);
+    return deskew_apply(ctx, plan, cnt, channels, src, src_page_stride, src_step, width, height, dst, dst_page_stride, dst_step, hs);
 }
 
 }  // namespace prl_hip
@@ -926,11 +955,10 @@ int prl_hip_houghp_device(const uint8_t* d_image, size_t step, int width, int he
     PageSet g{};
     g.base = static_cast<uint8_t*>(ctx->stage); g.page_stride = 0; g.step = (size_t)width;
     std::vector<std::vector<int>> out;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(hs, ctx->last_use, 0));
-    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
-    st = ppht_pages(ctx, 1, g, width, height, threshold, line_length, line_gap, false, 254, &out, nullptr, hs);
-    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, hs));
+    {
+        std::lock_guard<std::mutex> lk(ctx->ppht_mu);
+        st = ppht_pages(ctx, 1, g, width, height, threshold, line_length, line_gap, false, 254, &out, nullptr, hs);
+    }
     if (st != PRL_OK) return st;
     *n_lines = (int)(out[0].size() / 4);
     for (int i = 0; i < std::min(cap, *n_lines) * 4; ++i) lines[i] = out[0][(size_t)i];
@@ -958,23 +986,12 @@ int prl_hip_deskew_batch_device(int n_pages, int channels, const uint8_t* d_src,
     int st = current_device(&dev);
     if (st != PRL_OK) return st;
     DeviceCtx* ctx = device_ctx(dev);
-    std::lock_guard<std::mutex> slk(ctx->stage_mu);  // gray pages live in the staging area
     const int chunk = deskew_pages_per_pass(n_pages, width, height);
-    if (channels != 1) {
-        st = ensure_stage(ctx, deskew_gray_bytes(width, height) * (size_t)chunk);
-        if (st != PRL_OK) return st;
-    }
-    st = stage_acquire(ctx, static_cast<hipStream_t>(stream));
-    if (st != PRL_OK) return st;
-    struct Release {
-        DeviceCtx* c; hipStream_t s;
-        ~Release() { (void)stage_release(c, s); }
-    } release{ctx, static_cast<hipStream_t>(stream)};
     for (int first = 0; first < n_pages; first += chunk) {
         const int cnt = std::min(chunk, n_pages - first);
         st = deskew_pages(ctx, cnt, channels, d_src + (size_t)first * src_page_stride, src_page_stride, src_step, width, height,
                           d_dst + (size_t)first * dst_page_stride, dst_page_stride, dst_step, out_wh + 2 * first,
-                          angles ? angles + first : nullptr, static_cast<uint8_t*>(ctx->stage), static_cast<hipStream_t>(stream));
+                          angles ? angles + first : nullptr, static_cast<hipStream_t>(stream));
         if (st != PRL_OK) return st;
     }
     return PRL_OK;

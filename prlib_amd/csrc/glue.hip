@@ -16,6 +16,10 @@
 // other, each through host memory); BASELINE config 5 is this chain.
 #include <algorithm>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
+#include <thread>
+#include <string>
 #include <vector>
 
 #include "prl_internal.h"
@@ -350,8 +354,7 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
     if (st != PRL_OK) return st;
     const ChainLayout lmax = chain_layout(cp, channels, dw, dh, gmax);
     const size_t desk_page = cp->deskew ? r256((size_t)len * len * channels) : 0;
-    const size_t gray_page = (cp->deskew && channels != 1) ? deskew_gray_bytes(width, height) : 0;
-    const size_t per_page = desk_page + gray_page + lmax.total;
+    const size_t per_page = desk_page + lmax.total;
     int chunk = per_page == 0 ? n_pages : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, chain_budget() / per_page));
     chunk = std::min(chunk, 32768);
     if (cp->deskew) chunk = std::min(chunk, deskew_pages_per_pass(n_pages, width, height));
@@ -359,25 +362,73 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
         st = ensure_stage(ctx, per_page * (size_t)chunk);
         if (st != PRL_OK) return st;
     }
-    st = stage_acquire(ctx, static_cast<hipStream_t>(stream));  // another stream's chain / host call may still read the area
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    st = stage_acquire(ctx, hs);  // another stream's chain / host call may still read the area
     if (st != PRL_OK) return st;
     struct Release {   // records the area's new last use on every exit, error exits included
         DeviceCtx* c; hipStream_t s;
         ~Release() { (void)stage_release(c, s); }
-    } release{ctx, static_cast<hipStream_t>(stream)};
+    } release{ctx, hs};
+
+    // The angle search of deskew (HoughLinesP: one wavefront per page waiting on scattered atomics, seconds per pass) runs
+    // for pass k+1 on the side stream, from a helper thread, while the rotation and the other stages of pass k (NL-means:
+    // ALU / LDS work that needs no memory bandwidth) run on the caller's stream.  Both only read the source pages.
+    struct Finder {
+        std::thread th;
+        int st = PRL_OK;
+        std::string detail;
+        DeskewPlan plan;
+        void join() { if (th.joinable()) th.join(); }
+        ~Finder() { join(); }
+    } finder;
+    auto start_find = [&](int first) {
+        const int cnt = std::min(chunk, n_pages - first);
+        finder.st = PRL_OK;
+        finder.th = std::thread([&, first, cnt] {
+            if (hipSetDevice(dev) != hipSuccess) { finder.st = PRL_ERR_NO_DEVICE; return; }
+            const auto t0 = std::chrono::steady_clock::now();
+            struct Log { decltype(t0) t; int first; ~Log() { if (env_knobs().debug) std::fprintf(stderr, "[prl chain] angle search of pages %d..: %.3f s\n", first, std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); } } log{t0, first};
+            finder.st = deskew_find(ctx, cnt, channels, d_src + (size_t)first * src_page_stride, src_page_stride, src_step, width,
+                                    height, &finder.plan, ctx->side);
+            if (finder.st != PRL_OK) finder.detail = prl_hip_last_error_detail();
+        });
+    };
+    if (cp->deskew) {
+        if (!ctx->side) {
+            PRL_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+            PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
+        }
+        PRL_HIP_CHECK(hipEventRecord(ctx->side_ev, hs));  // the source pages may come from earlier work on the caller's stream
+        PRL_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
+        start_find(0);
+    }
     std::vector<int32_t> wh((size_t)chunk * 2);
+    DeskewPlan plan;
     for (int first = 0; first < n_pages; first += chunk) {
         const int cnt = std::min(chunk, n_pages - first);
         uint8_t* ws = static_cast<uint8_t*>(ctx->stage);
         const uint8_t* cur = d_src + (size_t)first * src_page_stride;
         size_t cur_ps = src_page_stride, cur_step = src_step;
+        const auto t_pass = std::chrono::steady_clock::now();
         if (cp->deskew) {
+            finder.join();
+            if (env_knobs().debug)
+                std::fprintf(stderr, "[prl chain] pass at page %d waited %.3f s for its angles\n", first,
+                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pass).count());
+            if (finder.st != PRL_OK) {
+                set_error_detail(finder.detail);
+                return finder.st;
+            }
+            plan = std::move(finder.plan);
+            finder.plan = DeskewPlan();
+            const bool overlap = env_knobs().chain_overlap != 0;
+            if (overlap && first + cnt < n_pages) start_find(first + cnt);
             uint8_t* desk = ws;
-            uint8_t* gray = ws + desk_page * (size_t)cnt;
-            ws = gray + gray_page * (size_t)cnt;
-            st = deskew_pages(ctx, cnt, channels, cur, cur_ps, cur_step, width, height, desk, desk_page, (size_t)len * channels,
-                              wh.data(), angles ? angles + first : nullptr, gray, static_cast<hipStream_t>(stream));
+            ws = desk + desk_page * (size_t)cnt;
+            st = deskew_apply(ctx, plan, cnt, channels, cur, cur_ps, cur_step, width, height, desk, desk_page, (size_t)len * channels, hs);
             if (st != PRL_OK) return st;
+            std::copy(plan.wh.begin(), plan.wh.end(), wh.begin());
+            if (angles) std::copy(plan.angles.begin(), plan.angles.end(), angles + first);
             cur = desk; cur_ps = desk_page; cur_step = (size_t)len * channels;
         } else {
             for (int i = 0; i < cnt; ++i) { wh[2 * (size_t)i] = width; wh[2 * (size_t)i + 1] = height; }
@@ -398,6 +449,16 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
                 out_wh[2 * (size_t)(first + i) + 1] = g.out_h;
             }
             r0 = r1;
+        }
+        if (cp->deskew && !env_knobs().chain_overlap && first + cnt < n_pages) {
+            PRL_HIP_CHECK(hipStreamSynchronize(hs));
+            start_find(first + cnt);
+            finder.join();
+        }
+        if (env_knobs().debug) {
+            (void)hipStreamSynchronize(hs);
+            std::fprintf(stderr, "[prl chain] pass at page %d (%d pages) done after %.3f s\n", first, cnt,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pass).count());
         }
     }
     return PRL_OK;

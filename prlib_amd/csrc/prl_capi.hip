@@ -67,7 +67,9 @@ const EnvKnobs& env_knobs()
         k.nlm_xl = (int)geti("PRL_NLM_XL", 3);
         k.nlm_glut = (int)geti("PRL_NLM_GLUT", 0);
         k.literal_scratch_mb = (size_t)std::max(64ll, geti("PRL_HIP_LITERAL_SCRATCH_MB", 8192));
-        k.deskew_work_mb = (size_t)std::max(64ll, geti("PRL_HIP_DESKEW_WORK_MB", 24576));
+        k.deskew_work_mb = (size_t)std::max(1ll, geti("PRL_HIP_DESKEW_WORK_MB", 24576));
+        k.ppht_prio = (int)geti("PRL_HIP_PPHT_PRIO", 3);
+        k.chain_overlap = (int)geti("PRL_HIP_CHAIN_OVERLAP", 1);
         k.chain_work_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_WORK_MB", 49152));
         k.host_chunk_mb = (size_t)std::max(1ll, geti("PRL_HIP_HOST_CHUNK_MB", 128));
         k.host_copy_threads = (int)std::max(1ll, std::min(32ll, geti("PRL_HIP_HOST_COPY_THREADS", 8)));
@@ -198,6 +200,20 @@ DeviceCtx* device_ctx(int dev)
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) p->cu_count = prop.multiProcessorCount;
     }
     return p.get();
+}
+
+int ensure_buffer(void** buf, size_t* have, size_t bytes)
+{
+    if (*have >= bytes) return PRL_OK;
+    if (*buf) {
+        PRL_HIP_CHECK(hipDeviceSynchronize());
+        PRL_HIP_CHECK(hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    PRL_HIP_CHECK(hipMalloc(buf, bytes));
+    *have = bytes;
+    return PRL_OK;
 }
 
 int ensure_scratch(DeviceCtx* ctx, size_t bytes)

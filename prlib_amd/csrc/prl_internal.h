@@ -61,6 +61,13 @@ struct DeviceCtx {
     bool prof_valid = false;
     hipEvent_t last_use = nullptr;  // recorded after each call; the next call's stream waits on it
     hipEvent_t stage_use = nullptr; // same for the staging area (`stage`): recorded by its last user (guarded by stage_mu)
+    // The angle search of prl::deskew has its own workspace, lock and stream: in the chain it runs for the next pass
+    // while the other stages of the current one use `scratch` / `mask` / `small` (glue.hip).
+    std::mutex ppht_mu;
+    void* ppht_buf[3] = {nullptr, nullptr, nullptr};  // fixed part (mask, accumulators ...), point / segment lists, gray pages
+    size_t ppht_bytes[3] = {0, 0, 0};
+    hipStream_t side = nullptr;     // created on first use (non-blocking)
+    hipEvent_t side_ev = nullptr;
 };
 
 // Tuning / debugging knobs of the PRL_* environment variables, read ONCE (first use) instead of on every call.
@@ -77,6 +84,8 @@ struct EnvKnobs {
     int nlm_glut = 0;             // PRL_NLM_GLUT   bit 0 / 1: L / ab plane read the weight table from memory instead of LDS
     size_t literal_scratch_mb = 8192;   // PRL_HIP_LITERAL_SCRATCH_MB
     size_t deskew_work_mb = 24576;      // PRL_HIP_DESKEW_WORK_MB
+    int ppht_prio = 3;                  // PRL_HIP_PPHT_PRIO=0   k_ppht does not raise its wavefront priority
+    int chain_overlap = 1;              // PRL_HIP_CHAIN_OVERLAP=0   angle search of the next pass not overlapped with this one
     size_t chain_work_mb = 49152;       // PRL_HIP_CHAIN_WORK_MB
     size_t host_chunk_mb = 128;         // PRL_HIP_HOST_CHUNK_MB   pages staged per buffer of prl_hip_binarize_batch_host
     int host_copy_threads = 8;          // PRL_HIP_HOST_COPY_THREADS  host threads per device copying pages in / out of pinned memory (bounded by cores / devices)
@@ -181,12 +190,23 @@ int fused_max_pages(const ThrParams& tp);  // pages one fused_run call can take 
 int thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step, int width,
                       int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream, bool invert_input);
 
-// ---- deskew (deskew.hip): one pass over `cnt` pages with the gray workspace supplied by the caller (chain glue) ------
-size_t deskew_gray_bytes(int width, int height);
+// ---- deskew (deskew.hip): one pass over `cnt` pages, as its two halves (the chain overlaps them) or in one go ------
 int deskew_pages_per_pass(int n_pages, int width, int height);
+struct DeskewPlan {                   // what the angle search of a pass hands to its rotation
+    std::vector<unsigned char> warp;  // one WarpPage record per page (deskew.hip)
+    std::vector<int32_t> wh;          // result size per page
+    std::vector<double> angles;       // findAngle's degrees per page
+    int max_ow = 0, max_oh = 0;
+};
+// gray -> Otsu -> HoughLinesP -> vote on `hs` (synchronises it); own workspace, takes ctx->ppht_mu only
+int deskew_find(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
+                int height, DeskewPlan* plan, hipStream_t hs);
+// prl::rotate of every page by its angle (copy where none was found); takes ctx->mu
+int deskew_apply(DeviceCtx* ctx, const DeskewPlan& plan, int cnt, int channels, const uint8_t* src, size_t src_page_stride,
+                 size_t src_step, int width, int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, hipStream_t hs);
 int deskew_pages(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
-                 int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, int32_t* out_wh, double* angles,
-                 uint8_t* gray_ws, hipStream_t hs);
+                 int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, int32_t* out_wh, double* angles, hipStream_t hs);
+int ensure_buffer(void** buf, size_t* have, size_t bytes);  // grow-only device buffer (synchronises the device when it grows)
 
 // ---- morphology (morph.hip) ------------------------------------------------------------------
 int morph_run(int iterations, const PageSet& src, int n_pages, int width, int height,

@@ -1,6 +1,9 @@
 """GPU parity of the channel adapters and the device-resident chain against the CPU oracle."""
+import os
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -180,6 +183,47 @@ def test_config5_chain_matches_the_composed_oracle(prl, oracle, cuda_device, cha
         assert np.array_equal(got, want), f"page {i}: {int((got != want).sum())} mismatching pixels"
         sizes.add(got.shape)
     assert len(sizes) >= 2 and angles[-1] == 0.0
+
+
+def test_config5_chain_in_several_passes(prl, oracle, cuda_device, tmp_path):
+    """With more pages than one pass of the angle search takes, the chain searches the angles of pass k+1 on a side stream
+    (helper thread) while pass k is rotated, denoised and binarized.  PRL_HIP_DESKEW_WORK_MB (read once per process) is
+    shrunk in a child process so that 5 small pages need 5 passes; the result must equal the one-pass result, which the
+    test above compares with the oracle page by page."""
+    import subprocess
+    import sys
+    import torch
+    from prlib_amd import synth
+
+    h, w = 150, 208
+    pages = []
+    for i, skew in enumerate((2.0, 0.0, -3.0, 1.0)):
+        g = synth.text_page_numpy(h, w, 60 + i, skew_deg=skew, shading=0.3)
+        pages.append(np.repeat(g[..., None], 3, axis=2))
+    pages.append(np.full((h, w, 3), 228, np.uint8))
+    batch = np.stack(pages)
+    np.save(tmp_path / "in.npy", batch)
+    outs, angles = prl.process_pages(torch.from_numpy(batch).to(cuda_device), 3, prl.SAUVOLA, 31, 0.34, 0,
+                                     denoise_strength=10.0, thin=0, deskew=True, background_normalization=True)
+    want0, ang0 = _oracle_chain5(oracle, batch[0], 3, 31, 0.34, 0, 10.0, 0)
+    assert angles[0] == ang0 and np.array_equal(outs[0].cpu().numpy(), want0)
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import prlib_amd
+batch = np.load(%r)
+outs, angles = prlib_amd.process_pages(torch.from_numpy(batch).cuda(), 3, prlib_amd.SAUVOLA, 31, 0.34, 0,
+                                       denoise_strength=10.0, thin=0, deskew=True, background_normalization=True)
+np.savez(%r, angles=np.asarray(angles), **{"p%%d" %% i: o.cpu().numpy() for i, o in enumerate(outs)})
+print("DONE")
+''' % (ROOT, str(tmp_path / "in.npy"), str(tmp_path / "out.npz"))
+    env = dict(os.environ, PRL_HIP_DESKEW_WORK_MB="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
+    z = np.load(tmp_path / "out.npz")
+    assert np.array_equal(z["angles"], np.asarray(angles))
+    for i in range(len(pages)):
+        assert np.array_equal(z["p%d" % i], outs[i].cpu().numpy()), i
 
 
 def test_chain_stage_subsets(prl, oracle, cuda_device):

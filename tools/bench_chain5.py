@@ -41,6 +41,7 @@ ap.add_argument("--window", type=int, default=31)
 ap.add_argument("--strength", type=float, default=10.0)
 ap.add_argument("--stages", type=int, default=1, help="also time the stages one by one on the first --stage-pages pages")
 ap.add_argument("--stage-pages", type=int, default=64)
+ap.add_argument("--repeat", type=int, default=1, help="run the one-call chain this many times (the first call allocates the workspaces)")
 ap.add_argument("--check-pages", type=int, default=0, help="pages compared with the composed CPU oracle (slow: NL-means on the host)")
 a = ap.parse_args()
 world, rank, local_rank = pdist.init()
@@ -57,12 +58,17 @@ gen_s = time.perf_counter() - t0
 px_in = a.pages * a.width * a.height
 
 
-def timed(fn):
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    r = fn()
-    torch.cuda.synchronize()
-    return time.perf_counter() - t, r
+def timed(fn, reps=1):
+    best = None
+    for _ in range(reps):
+        r = None
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    return best, r
 
 
 res = {"workload": f"{a.pages} x {a.width}x{a.height}x{a.channels} synthetic text scans (skew +-4 deg, shaded), 1 GPU, device resident; "
@@ -71,16 +77,16 @@ res = {"workload": f"{a.pages} x {a.width}x{a.height}x{a.channels} synthetic tex
 if a.stages and world == 1:
     n = min(a.stage_pages, a.pages)
     sub = pages[:n]
-    t_desk, (outs, ang) = timed(lambda: prlib_amd.deskew(sub))
+    t_desk, (outs, ang) = timed(lambda: prlib_amd.deskew(sub), 2)
     sq = torch.stack([o for o in outs if o.shape[0] == o.shape[1] == max(a.width, a.height)]) if any(o.shape[0] == o.shape[1] for o in outs) else sub
     m = sq.shape[0]
     px_sq = m * sq.shape[1] * sq.shape[2]
-    t_den, den = timed(lambda: prlib_amd.denoise(sq, a.strength))
-    t_bg, bg = timed(lambda: prlib_amd.backgroundNormalization(den))
-    t_gray, g8 = timed(lambda: prlib_amd.cvtColorBGR2GRAY(bg))
-    t_bin, mask = timed(lambda: prlib_amd.binarizeSauvola(g8, a.window, 0.34, 0))
-    t_inv, inv = timed(lambda: prlib_amd.bitwise_not(mask))
-    t_thin, sk = timed(lambda: prlib_amd.thinZhangSuen(inv))
+    t_den, den = timed(lambda: prlib_amd.denoise(sq, a.strength), 2)
+    t_bg, bg = timed(lambda: prlib_amd.backgroundNormalization(den), 2)
+    t_gray, g8 = timed(lambda: prlib_amd.cvtColorBGR2GRAY(bg), 2)
+    t_bin, mask = timed(lambda: prlib_amd.binarizeSauvola(g8, a.window, 0.34, 0), 2)
+    t_inv, inv = timed(lambda: prlib_amd.bitwise_not(mask), 2)
+    t_thin, sk = timed(lambda: prlib_amd.thinZhangSuen(inv), 2)
     res["stages"] = {"pages": n, "rotated_pages": m, "deskew_ms": round(t_desk * 1e3, 1),
                      "deskew_Mpx_s": round(n * a.width * a.height / t_desk / 1e6, 1),
                      "denoise_ms": round(t_den * 1e3, 1), "denoise_Mpx_s": round(px_sq / t_den / 1e6, 1),
@@ -94,10 +100,17 @@ pdist.barrier()
 t_chain, (outs, angles) = timed(lambda: prlib_amd.process_pages(pages, a.channels, prlib_amd.SAUVOLA, a.window, 0.34, 0,
                                                                 denoise_strength=a.strength, thin=0, deskew=True,
                                                                 background_normalization=True))
+t_first = t_chain
+for _ in range(a.repeat - 1):
+    del outs
+    t2, (outs, angles) = timed(lambda: prlib_amd.process_pages(pages, a.channels, prlib_amd.SAUVOLA, a.window, 0.34, 0,
+                                                               denoise_strength=a.strength, thin=0, deskew=True,
+                                                               background_normalization=True))
+    t_chain = min(t_chain, t2)
 t_chain = pdist.max_over_ranks(t_chain, device=dev)   # the job is done when the slowest rank is
 px_in = total_pages * a.width * a.height
 res.update({"n_gpus": world, "pages_total": total_pages, "pages_this_rank": a.pages,
-            "chain_one_call_s": round(t_chain, 3), "chain_input_Mpx_s": round(px_in / t_chain / 1e6, 1),
+            "chain_one_call_s": round(t_chain, 3), "chain_first_call_s": round(t_first, 3), "chain_input_Mpx_s": round(px_in / t_chain / 1e6, 1),
             "pages_per_s": round(total_pages / t_chain, 2),
             "rotated_pages": int(sum(1 for o in outs if o.shape[0] == o.shape[1])),
             "angle_abs_err_deg_mean": round(float(np.abs(angles - skews).mean()), 3),
