@@ -191,17 +191,22 @@ __device__ __forceinline__ int wave_max_i32(int x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
-constexpr int kBlk = 64;  // points per block of k_ppht
+#ifndef PRL_PPHT_BLK
+#define PRL_PPHT_BLK 32
+#endif
+// Points per block of k_ppht.  32: 96 returned counts in registers (136 VGPRs); 64 (234 VGPRs) measured 3 % slower on 256+
+// pages - the batch keeps the memory system busy either way - and 24 / 16 the same as 32 (profiles/r02/chain_overlap.txt).
+constexpr int kBlk = PRL_PPHT_BLK;
 
-// HoughLinesP stage 2, one wavefront per page, BLOCKS OF 64 POINTS (round 2, second version).  The first version walked the
+// HoughLinesP stage 2, one wavefront per page, BLOCKS OF kBlk POINTS (round 2, second version).  The first version walked the
 // points one by one: list fetch -> mask byte -> 180 voting atomics -> decision, three dependent memory round trips per
 // point (1.9 us).  Two facts allow overlapping them without changing a single result:
 //  * the visiting order does not depend on the data (cv::RNG draws idx_t = next() % (N - t) and the list swap
-//    nz[idx_t] = nz[N - t - 1] happens whatever the point does), so 64 steps of it are taken at once: lane L fetches the list
+//    nz[idx_t] = nz[N - t - 1] happens whatever the point does), so kBlk steps of it are taken at once: lane L fetches the list
 //    entries of step t0 + L, and the swaps of the earlier steps of the same block are applied to its values in registers
-//    (a 64-step loop of readlane / compare / select), duplicates resolved so that memory ends in the sequential state;
+//    (a kBlk-step loop of readlane / compare / select), duplicates resolved so that memory ends in the sequential state;
 //  * a vote only matters when its cell reaches the threshold, which a fraction of a percent of the points do: the votes of
-//    all points of the block are ISSUED back to back (atomics with return into 192 registers; a lane owns its angles' rows, so
+//    all points of the block are ISSUED back to back (atomics with return into 3 kBlk registers; a lane owns its angles' rows, so
 //    successive points hitting one cell arrive in order) and then RETIRED in order; the first point that triggers a line has
 //    the votes of the younger points taken back, its line is walked exactly as before, and the rest of the block starts
 //    over (masks re-read: the walk may have erased some of them).

@@ -387,7 +387,7 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
         finder.th = std::thread([&, first, cnt] {
             if (hipSetDevice(dev) != hipSuccess) { finder.st = PRL_ERR_NO_DEVICE; return; }
             const auto t0 = std::chrono::steady_clock::now();
-            struct Log { decltype(t0) t; int first; ~Log() { if (env_knobs().debug) std::fprintf(stderr, "[prl chain] angle search of pages %d..: %.3f s\n", first, std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); } } log{t0, first};
+            struct Log { decltype(t0) t; int first; ~Log() { if (env_knobs().debug) std::fprintf(stderr, "[prl chain %.3f] angle search of pages %d..: %.3f s\n", std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(), first, std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); } } log{t0, first};
             finder.st = deskew_find(ctx, cnt, channels, d_src + (size_t)first * src_page_stride, src_page_stride, src_step, width,
                                     height, &finder.plan, ctx->side);
             if (finder.st != PRL_OK) finder.detail = prl_hip_last_error_detail();
@@ -413,7 +413,7 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
         if (cp->deskew) {
             finder.join();
             if (env_knobs().debug)
-                std::fprintf(stderr, "[prl chain] pass at page %d waited %.3f s for its angles\n", first,
+                std::fprintf(stderr, "[prl chain %.3f] pass at page %d waited %.3f s for its angles\n", std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(), first,
                              std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pass).count());
             if (finder.st != PRL_OK) {
                 set_error_detail(finder.detail);
@@ -457,7 +457,7 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
         }
         if (env_knobs().debug) {
             (void)hipStreamSynchronize(hs);
-            std::fprintf(stderr, "[prl chain] pass at page %d (%d pages) done after %.3f s\n", first, cnt,
+            std::fprintf(stderr, "[prl chain %.3f] pass at page %d (%d pages) done after %.3f s\n", std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(), first, cnt,
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pass).count());
         }
     }

@@ -174,20 +174,41 @@ __global__ void __launch_bounds__(256) k_nlm_y(PageSet src, PageSetOut dst, NlmP
     const int W = np.width, H = np.height;
     const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
 
-    // raw tile with its reflect-101 halo (copyMakeBorder(BORDER_DEFAULT) by 13), zero padded rows
-    for (int i = threadIdx.x; i < EXT_H * EXT_W; i += blockDim.x) {
-        const int r = i / EXT_W, c = i - r * EXT_W;
-        const int sy = reflect101(y0 - kBorder + r, H), sx = reflect101(x0 - kBorder + c, W);
-        const uint8_t* s = img + (size_t)sy * src.step + (size_t)sx * CH;
+    // raw tile with its reflect-101 halo (copyMakeBorder(BORDER_DEFAULT) by 13), zero padded rows.  Every fetch of the
+    // tile is issued before the first one is used: ONE memory round trip per workgroup.  (In the config-5 chain this kernel
+    // runs beside the angle search of the next pass, which keeps the memory system saturated with scattered atomics;
+    // a round trip then takes tens of microseconds, and the eight dependent batches the plain loop compiled to doubled the
+    // kernel's time.)
+    {
+        using Px = typename std::conditional<CH == 1, uint8_t, unsigned short>::type;   // 2 channels: aligned 16-bit pixels
+        static_assert(CH <= 2, "k_nlm_y filters the L and the ab plane");
+        constexpr int kIt = (EXT_H * EXT_W + 255) / 256;
+        Px px[kIt];
 #pragma unroll
-        for (int k = 0; k < CH; ++k) raw[r * RAWP + c * CH + k] = s[k];
+        for (int it = 0; it < kIt; ++it) {
+            const int i = (int)threadIdx.x + it * 256;
+            px[it] = 0;
+            if (i < EXT_H * EXT_W) {
+                const int r = i / EXT_W, c = i - r * EXT_W;
+                const int sy = reflect101(y0 - kBorder + r, H), sx = reflect101(x0 - kBorder + c, W);
+                px[it] = *reinterpret_cast<const Px*>(img + (size_t)sy * src.step + (size_t)sx * CH);
+            }
+        }
+        for (int i = threadIdx.x; i < EXT_H * (RAWP - EXT_W * CH); i += blockDim.x) {
+            const int r = i / (RAWP - EXT_W * CH), c = i - r * (RAWP - EXT_W * CH);
+            raw[r * RAWP + EXT_W * CH + c] = 0;
+        }
+        if (LUT_LDS)
+            for (int i = threadIdx.x; i <= kLutN; i += blockDim.x) lut_s[i] = (i < np.n_lut) ? np.lut[i] : 0;
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int i = (int)threadIdx.x + it * 256;
+            if (i < EXT_H * EXT_W) {
+                const int r = i / EXT_W, c = i - r * EXT_W;
+                *reinterpret_cast<Px*>(raw + r * RAWP + c * CH) = px[it];
+            }
+        }
     }
-    for (int i = threadIdx.x; i < EXT_H * (RAWP - EXT_W * CH); i += blockDim.x) {
-        const int r = i / (RAWP - EXT_W * CH), c = i - r * (RAWP - EXT_W * CH);
-        raw[r * RAWP + EXT_W * CH + c] = 0;
-    }
-    if (LUT_LDS)
-        for (int i = threadIdx.x; i <= kLutN; i += blockDim.x) lut_s[i] = (i < np.n_lut) ? np.lut[i] : 0;
     __syncthreads();
 
     // expand: element (r, k) = raw bytes [k*CH, k*CH + 8) of row r (XL: 4 bytes)
