@@ -299,6 +299,16 @@ int prl_hip_chain_pages_device(const prl_chain_params* params, int n_pages, int 
                                size_t src_page_stride, size_t src_step, int width, int height, uint8_t* d_dst,
                                size_t dst_page_stride, size_t dst_step, int32_t* out_wh, double* angles, void* stream);
 
+/* The same chain on a list of HOST pages of one size (the cv::Mats of a caller that loops over prl::deskew, prl::denoise,
+ * prl::backgroundNormalization, prl::binarizeSauvola, prl::thinZhangSuen page by page, BASELINE config 5), sharded over the
+ * first n_devices GPUs (0 = all visible) in contiguous blocks (prl_hip_page_range), no collective.  Per device: a worker
+ * thread, chunks of PRL_HIP_CHAIN_HOST_PAGES pages, the upload of chunk k+1 and the download of chunk k-1 overlapped with the
+ * chain on chunk k.  dst[i]: room for prl_hip_chain_max_out_size at dst_step >= that width; out_wh[2i], out_wh[2i+1]: the
+ * size of page i's result; angles: optional.  Returns when every page is in the caller's memory. */
+int prl_hip_chain_batch_host(const prl_chain_params* params, int n_pages, int channels, const uint8_t* const* src,
+                             size_t src_step, int width, int height, uint8_t* const* dst, size_t dst_step, int32_t* out_wh,
+                             double* angles, int n_devices);
+
 /* ---- background normalisation (prl::backgroundNormalization) ------------------------------ */
 
 /*

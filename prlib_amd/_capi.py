@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = [
     "prl_hip_rotate_out_size", "prl_hip_rotate_batch_device", "prl_hip_houghp_device", "prl_hip_deskew_batch_device",
     "prl_hip_rotate_host", "prl_hip_deskew_host", "prl_hip_chain_max_out_size", "prl_hip_chain_pages_device",
     "prl_hip_binarize_batch_host", "prl_hip_page_range", "prl_hip_binarize_lv_batch_device", "prl_hip_binarize_lv_host",
+    "prl_hip_chain_batch_host",
 ]
 
 
@@ -146,6 +147,7 @@ def lib() -> C.CDLL:
         L.prl_hip_chain_max_out_size.argtypes = [P(ChainParams), i, i, P(C.c_int), P(C.c_int)]
         L.prl_hip_chain_pages_device.argtypes = [P(ChainParams), i, i, vp, sz, sz, i, i, vp, sz, sz, vp, vp, vp]
         L.prl_hip_binarize_batch_host.argtypes = [P(BinarizeParams), i, P(vp), sz, i, i, P(vp), sz, i]
+        L.prl_hip_chain_batch_host.argtypes = [P(ChainParams), i, i, P(vp), sz, i, i, P(vp), sz, vp, vp, i]
         L.prl_hip_page_range.argtypes = [i, i, i, P(C.c_int), P(C.c_int)]
         L.prl_hip_binarize_lv_batch_device.argtypes = [i, i, C.c_double, i, C.c_double, vp, sz, sz, i, i, vp, sz, sz, vp]
         L.prl_hip_binarize_lv_host.argtypes = [i, C.c_double, i, C.c_double, vp, sz, i, i, vp, sz]

@@ -143,3 +143,43 @@ def process_pages(pages, channels: int, method: int = 0, windowSize: int = 101, 
     _capi.check(L.prl_hip_chain_batch_device(C.byref(cp), n, channels, t.data_ptr(), t.stride(0), t.stride(1), w, h,
                                             o.data_ptr(), o.stride(0), o.stride(1), _stream(t)))
     return o[0] if squeeze else o
+
+
+def process_pages_host(pages, method: int = 0, windowSize: int = 101, k: float = 0.01, morphIterationCount: int = 2,
+                       denoise_strength=None, thin: int = NO_THINNING, deskew: bool = False,
+                       background_normalization: bool = False, n_devices: int = 0, **feng):
+    """prl_hip_chain_batch_host: the chain of process_pages on a list (or array) of equal-size uint8 HOST pages, H x W or
+    H x W x 3|4, sharded over the node's GPUs by the library.  Returns (list of per-page numpy results, angles)."""
+    import numpy as np
+
+    pages = [np.ascontiguousarray(p) for p in pages]
+    n = len(pages)
+    if n == 0:
+        return [], np.zeros(0)
+    shape = pages[0].shape
+    if any(p.shape != shape or p.dtype != np.uint8 for p in pages) or len(shape) not in (2, 3):
+        raise TypeError("expected equal-size uint8 pages")
+    h, w = shape[0], shape[1]
+    channels = 1 if len(shape) == 2 else shape[2]
+    L = _capi.lib()
+    cp = _capi.ChainParams()
+    L.prl_hip_default_chain_params(C.byref(cp))
+    cp.denoise = 0 if denoise_strength is None else 1
+    cp.denoise_strength = 5.5 if denoise_strength is None else float(denoise_strength)
+    cp.binarize = make_params(method, windowSize, k, morphIterationCount, **feng)
+    cp.thin = int(thin)
+    cp.deskew = 1 if deskew else 0
+    cp.background_normalization = 1 if background_normalization else 0
+    mw, mh = C.c_int(0), C.c_int(0)
+    st = L.prl_hip_chain_max_out_size(C.byref(cp), w, h, C.byref(mw), C.byref(mh))
+    if st in (_capi.PRL_ERR_EMPTY, _capi.PRL_ERR_BAD_WINDOW):
+        raise ValueError(L.prl_hip_strerror(st).decode())
+    _capi.check(st)
+    out = np.empty((n, mh.value, mw.value), dtype=np.uint8)
+    wh = np.zeros((n, 2), dtype=np.int32)
+    angles = np.zeros(n, dtype=np.float64)
+    src = (C.c_void_p * n)(*[p.ctypes.data for p in pages])
+    dst = (C.c_void_p * n)(*[out[i].ctypes.data for i in range(n)])
+    _capi.check(L.prl_hip_chain_batch_host(C.byref(cp), n, channels, src, pages[0].strides[0], w, h, dst, out.strides[1],
+                                           wh.ctypes.data, angles.ctypes.data, n_devices))
+    return [out[i, : wh[i, 1], : wh[i, 0]] for i in range(n)], angles

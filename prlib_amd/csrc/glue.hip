@@ -327,6 +327,32 @@ int chain_check(const prl_chain_params* cp, int n_pages, int channels, const uin
 
 }  // namespace
 
+extern "C++" {
+namespace prl_hip {
+// Pages per pass of the chain on n_pages pages of one size (workspace budgets of the chain and of the angle search), and the
+// workspace bytes per page.  host_batch.hip sizes its device chunks in whole passes with it.
+int chain_pass_layout(const prl_chain_params* cp, int n_pages, int channels, int width, int height, int* pass_pages, size_t* per_page_out,
+                      size_t* desk_page_out)
+{
+    const int len = std::max(width, height);
+    const int dw = cp->deskew ? len : width, dh = cp->deskew ? len : height;  // largest page the later stages can see
+    prl_binarize_geometry gmax;
+    int st = prl_hip_binarize_geometry(&cp->binarize, dw, dh, &gmax);
+    if (st != PRL_OK) return st;
+    const ChainLayout lmax = chain_layout(cp, channels, dw, dh, gmax);
+    const size_t desk_page = cp->deskew ? r256((size_t)len * len * channels) : 0;
+    const size_t per_page = desk_page + lmax.total;
+    int chunk = per_page == 0 ? n_pages : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, chain_budget() / per_page));
+    chunk = std::min(chunk, 32768);
+    if (cp->deskew) chunk = std::min(chunk, deskew_pages_per_pass(n_pages, width, height));
+    *pass_pages = std::max(1, chunk);
+    if (per_page_out) *per_page_out = per_page;
+    if (desk_page_out) *desk_page_out = desk_page;
+    return PRL_OK;
+}
+}  // namespace prl_hip
+}  // extern "C++"
+
 // The chain on pages whose results may differ in size (deskew): out_wh (host, 2 ints per page) receives each page's
 // result size; d_dst pages need room for the largest possible result (prl_hip_chain_max_out_size) at dst_step bytes per row.
 int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int channels, const uint8_t* d_src, size_t src_page_stride,
@@ -348,16 +374,10 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
     std::lock_guard<std::mutex> slk(ctx->stage_mu);  // the staging workspace holds the intermediates
 
     const int len = std::max(width, height);
-    const int dw = cp->deskew ? len : width, dh = cp->deskew ? len : height;  // largest page the later stages can see
-    prl_binarize_geometry gmax;
-    st = prl_hip_binarize_geometry(&cp->binarize, dw, dh, &gmax);
+    size_t per_page = 0, desk_page = 0;
+    int chunk = 0;
+    st = chain_pass_layout(cp, n_pages, channels, width, height, &chunk, &per_page, &desk_page);
     if (st != PRL_OK) return st;
-    const ChainLayout lmax = chain_layout(cp, channels, dw, dh, gmax);
-    const size_t desk_page = cp->deskew ? r256((size_t)len * len * channels) : 0;
-    const size_t per_page = desk_page + lmax.total;
-    int chunk = per_page == 0 ? n_pages : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, chain_budget() / per_page));
-    chunk = std::min(chunk, 32768);
-    if (cp->deskew) chunk = std::min(chunk, deskew_pages_per_pass(n_pages, width, height));
     if (per_page) {
         st = ensure_stage(ctx, per_page * (size_t)chunk);
         if (st != PRL_OK) return st;

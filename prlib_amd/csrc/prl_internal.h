@@ -66,6 +66,13 @@ struct DeviceCtx {
     std::mutex ppht_mu;
     void* ppht_buf[3] = {nullptr, nullptr, nullptr};  // fixed part (mask, accumulators ...), point / segment lists, gray pages
     size_t ppht_bytes[3] = {0, 0, 0};
+    hipStream_t host_run = nullptr; // stream of prl_hip_chain_batch_host's device work (kept: its per-stream workspaces persist)
+    // page buffers and pinned bounce slots of prl_hip_chain_batch_host, kept between calls (allocating and freeing tens of
+    // gigabytes per call cost two seconds); one such call at a time per device
+    std::mutex host_mu;
+    void* host_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // in 0 / 1, out 0 / 1
+    size_t host_buf_bytes[4] = {0, 0, 0, 0};
+    void* host_slots[2] = {nullptr, nullptr};   // PinSlots of host_batch.hip (replaced when they grow, never freed at exit)
     hipStream_t side = nullptr;     // created on first use (non-blocking)
     hipEvent_t side_ev = nullptr;
 };
@@ -88,6 +95,8 @@ struct EnvKnobs {
     int chain_overlap = 1;              // PRL_HIP_CHAIN_OVERLAP=0   angle search of the next pass not overlapped with this one
     size_t chain_work_mb = 49152;       // PRL_HIP_CHAIN_WORK_MB
     size_t host_chunk_mb = 128;         // PRL_HIP_HOST_CHUNK_MB   pages staged per buffer of prl_hip_binarize_batch_host
+    int chain_host_pages = 0;           // PRL_HIP_CHAIN_HOST_PAGES   pages per device chunk of prl_hip_chain_batch_host (0: from the budget)
+    size_t chain_host_mb = 65536;       // PRL_HIP_CHAIN_HOST_MB      device memory for the page buffers of prl_hip_chain_batch_host
     int host_copy_threads = 8;          // PRL_HIP_HOST_COPY_THREADS  host threads per device copying pages in / out of pinned memory (bounded by cores / devices)
     unsigned segmax_cap = 1u << 20;     // PRL_HIP_SEGMAX_CAP   wavefronts per Wolf-Jolion call (tests shrink it)
     int literal_mode = 0;         // PRL_HIP_MODE=literal
@@ -206,6 +215,9 @@ int deskew_apply(DeviceCtx* ctx, const DeskewPlan& plan, int cnt, int channels, 
                  size_t src_step, int width, int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, hipStream_t hs);
 int deskew_pages(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
                  int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, int32_t* out_wh, double* angles, hipStream_t hs);
+// glue.hip: pages per pass of the chain and its workspace bytes per page (host_batch.hip sizes device chunks in whole passes)
+int chain_pass_layout(const prl_chain_params* cp, int n_pages, int channels, int width, int height, int* pass_pages,
+                      size_t* per_page_out, size_t* desk_page_out);
 int ensure_buffer(void** buf, size_t* have, size_t bytes);  // grow-only device buffer (synchronises the device when it grows)
 
 // ---- morphology (morph.hip) ------------------------------------------------------------------

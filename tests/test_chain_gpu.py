@@ -226,6 +226,59 @@ print("DONE")
         assert np.array_equal(z["p%d" % i], outs[i].cpu().numpy()), i
 
 
+def test_chain_on_host_pages(prl, oracle, cuda_device):
+    """prl_hip_chain_batch_host: the caller's host pages through upload -> chain -> download, in device chunks of two pages
+    (PRL_HIP_CHAIN_HOST_PAGES=2 in a child process) so that upload, chain and download of different chunks overlap; equal
+    to the device-resident entry page by page, page 0 also to the composed oracle."""
+    import subprocess
+    import sys
+    import torch
+    from prlib_amd import synth
+
+    h, w = 150, 208
+    pages = []
+    for i, skew in enumerate((2.0, 0.0, -3.0, 1.0, -1.5)):
+        g = synth.text_page_numpy(h, w, 80 + i, skew_deg=skew, shading=0.3)
+        pages.append(np.repeat(g[..., None], 3, axis=2))
+    batch = np.stack(pages)
+    outs, angles = prl.process_pages(torch.from_numpy(batch).to(cuda_device), 3, prl.SAUVOLA, 31, 0.34, 0,
+                                     denoise_strength=10.0, thin=0, deskew=True, background_normalization=True)
+    got, ang = prl.process_pages_host(list(batch), prl.SAUVOLA, 31, 0.34, 0, denoise_strength=10.0, thin=0, deskew=True,
+                                      background_normalization=True, n_devices=1)
+    assert np.array_equal(ang, np.asarray(angles))
+    for i in range(len(pages)):
+        assert np.array_equal(got[i], outs[i].cpu().numpy()), i
+    want0, ang0 = _oracle_chain5(oracle, batch[0], 3, 31, 0.34, 0, 10.0, 0)
+    assert ang[0] == ang0 and np.array_equal(got[0], want0)
+    # gray pages without deskew: uniform result size through the same entry
+    gray = [np.ascontiguousarray(p[..., 0]) for p in pages]
+    got2, ang2 = prl.process_pages_host(gray, prl.NICK, 21, -0.1, 1, background_normalization=True)
+    ref2 = prl.process_pages(torch.from_numpy(np.stack(gray)).to(cuda_device), 1, prl.NICK, 21, -0.1, 1,
+                             background_normalization=True).cpu().numpy()
+    assert all(np.array_equal(got2[i], ref2[i]) for i in range(len(gray))) and not ang2.any()
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+import prlib_amd
+batch = np.load(%r)
+outs, angles = prlib_amd.process_pages_host(list(batch), prlib_amd.SAUVOLA, 31, 0.34, 0, denoise_strength=10.0, thin=0, deskew=True,
+                                            background_normalization=True, n_devices=1)
+np.savez(%r, angles=angles, **{"p%%d" %% i: o for i, o in enumerate(outs)})
+print("DONE")
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.save(os.path.join(td, "in.npy"), batch)
+        env = dict(os.environ, PRL_HIP_CHAIN_HOST_PAGES="2")
+        r = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(td, "in.npy"), os.path.join(td, "out.npz"))],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
+        z = np.load(os.path.join(td, "out.npz"))
+        assert np.array_equal(z["angles"], ang)
+        for i in range(len(pages)):
+            assert np.array_equal(z["p%d" % i], got[i]), i
+
+
 def test_chain_stage_subsets(prl, oracle, cuda_device):
     import torch
     from prlib_amd import synth

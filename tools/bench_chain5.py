@@ -42,6 +42,7 @@ ap.add_argument("--strength", type=float, default=10.0)
 ap.add_argument("--stages", type=int, default=1, help="also time the stages one by one on the first --stage-pages pages")
 ap.add_argument("--stage-pages", type=int, default=64)
 ap.add_argument("--repeat", type=int, default=1, help="run the one-call chain this many times (the first call allocates the workspaces)")
+ap.add_argument("--host", type=int, default=0, help="also time prl_hip_chain_batch_host on the same pages in host memory (end to end)")
 ap.add_argument("--check-pages", type=int, default=0, help="pages compared with the composed CPU oracle (slow: NL-means on the host)")
 a = ap.parse_args()
 world, rank, local_rank = pdist.init()
@@ -115,6 +116,18 @@ res.update({"n_gpus": world, "pages_total": total_pages, "pages_this_rank": a.pa
             "rotated_pages": int(sum(1 for o in outs if o.shape[0] == o.shape[1])),
             "angle_abs_err_deg_mean": round(float(np.abs(angles - skews).mean()), 3),
             "skeleton_fraction": round(float(np.mean([float((o > 0).float().mean()) for o in outs[:8]])), 5)})
+if a.host and world == 1:
+    host_pages = [pg for pg in pages.cpu().numpy()]
+    t_host = None
+    for _ in range(max(1, a.repeat)):
+        t0 = time.perf_counter()
+        h_out, h_ang = prlib_amd.process_pages_host(host_pages, prlib_amd.SAUVOLA, a.window, 0.34, 0, denoise_strength=a.strength, thin=0,
+                                                    deskew=True, background_normalization=True, n_devices=1)
+        dt = time.perf_counter() - t0
+        t_host = dt if t_host is None else min(t_host, dt)
+    same = bool(np.array_equal(h_ang, angles)) and all(np.array_equal(h_out[i], outs[i].cpu().numpy()) for i in range(0, a.pages, max(1, a.pages // 8)))
+    res["host_pages_end_to_end"] = {"s": round(t_host, 3), "pages_per_s": round(a.pages / t_host, 2),
+                                    "input_Mpx_s": round(px_in / t_host / 1e6, 1), "equals_device_entry": same}
 if a.check_pages:
     from oracle import capi as oc
     bad = 0
