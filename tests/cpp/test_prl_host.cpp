@@ -272,6 +272,52 @@ static void test_gpu_round2()
         cv::Mat gray1 = synth_page(20, 20, 3, 1);
         CHECK(throws_invalid_argument([&] { prl::binarizeByLocalVariances(gray1, out); }));
     }
+    // BASELINE config 5 the way a PRLib user writes it (one prl:: call per stage and page, through host Mats) against the
+    // one-call chain on the same host pages (prl_hip_chain_batch_host): identical bytes, sizes and angles
+    {
+        const int n = 3, W = 260, H = 180;
+        std::vector<cv::Mat> scans;
+        scans.push_back(text_page(H, W, 0.035, 3));
+        scans.push_back(text_page(H, W, 0.0, 3));
+        scans.push_back(text_page(H, W, -0.05, 3));
+        std::vector<cv::Mat> want(n);
+        for (int i = 0; i < n; ++i) {
+            cv::Mat a, b, c, d, e;
+            prl::deskew(scans[i], a);
+            prl::denoise(a, b, 10);
+            prl::backgroundNormalization(b, c);
+            prl::binarizeSauvola(c, d, 31, 0.34, 0);
+            e.create(d.rows, d.cols, CV_8UC1);
+            for (int y = 0; y < d.rows; ++y)
+                for (int x = 0; x < d.cols; ++x) e.ptr(y)[x] = (unsigned char)(255 - d.ptr(y)[x]);   // cv::bitwise_not
+            prl::thinZhangSuen(e, want[i]);
+        }
+        prl_chain_params cp;
+        prl_hip_default_chain_params(&cp);
+        cp.deskew = 1;
+        cp.denoise = 1; cp.denoise_strength = 10.f;
+        cp.background_normalization = 1;
+        cp.binarize.window_size = 31; cp.binarize.k = 0.34; cp.binarize.morph_iterations = 0;
+        cp.thin = PRL_THIN_ZHANGSUEN;
+        int mw = 0, mh = 0;
+        CHECK(prl_hip_chain_max_out_size(&cp, W, H, &mw, &mh) == PRL_OK);
+        std::vector<cv::Mat> out(n);
+        std::vector<const uint8_t*> src(n);
+        std::vector<uint8_t*> dst(n);
+        for (int i = 0; i < n; ++i) { src[i] = scans[i].data; out[i].create(mh, mw, CV_8UC1); dst[i] = out[i].data; }
+        std::vector<int32_t> wh(2 * n);
+        std::vector<double> angle(n);
+        CHECK(prl_hip_chain_batch_host(&cp, n, 3, src.data(), scans[0].step, W, H, dst.data(), out[0].step, wh.data(), angle.data(), 0) == PRL_OK);
+        int rotated = 0;
+        for (int i = 0; i < n; ++i) {
+            CHECK(wh[2 * i] == want[i].cols && wh[2 * i + 1] == want[i].rows);
+            size_t bad = 0;
+            for (int y = 0; y < want[i].rows && wh[2 * i] == want[i].cols; ++y) bad += std::memcmp(out[i].ptr(y), want[i].ptr(y), (size_t)want[i].cols) != 0;
+            CHECK(bad == 0);
+            rotated += angle[i] != 0.0;
+        }
+        CHECK(rotated >= 2);
+    }
     cv::Mat blank(60, 90, CV_8UC1), bout;
     std::memset(blank.data, 230, 60 * 90);
     CHECK(prl::deskew(blank, bout) && bout.rows == 60 && bout.cols == 90 && std::memcmp(bout.data, blank.data, 60 * 90) == 0);
