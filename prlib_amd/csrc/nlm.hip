@@ -156,7 +156,7 @@ __device__ __forceinline__ unsigned sub_keep(unsigned a, unsigned b)
 constexpr int kLutMaxXL = 639;  // the 4-byte-element variant keeps a shorter LDS table (40 KB per workgroup in all)
 
 template <int CH, bool LUT_LDS, bool XL = false>
-__global__ void __launch_bounds__(256) k_nlm_y(PageSet src, PageSetOut dst, NlmParams np)
+__device__ __forceinline__ void nlm_y_body(const PageSet& src, const PageSetOut& dst, const NlmParams& np)
 {
     using G = YGeo<CH>;
     using Elt = typename std::conditional<XL, unsigned, uint2>::type;
@@ -325,14 +325,108 @@ __global__ void __launch_bounds__(256) k_nlm_y(PageSet src, PageSetOut dst, NlmP
             }
         }
     };
-    // offsets in flight per wavefront.  8-byte elements (2 wavefronts per SIMD): 3 / 2 measured best.  XL runs 4
-    // wavefronts per SIMD at <= 128 VGPRs: 1 and 2 measure the same (22.5 ms L-plane, 8 x 4K pages) - the kernel
-    // then sits at SQ_LDS_IDX_ACTIVE 88 % with the vector ALU saturated (profiles/r01/pmc_nlm_xl.txt)
-    constexpr int kPair = XL ? 1 : (CH == 1 ? 3 : 2);
+    // XL layout: GROUPS of offsets that share their LDS reads.  The neighbourhoods of offsets dx, dx + S, dx + 2S (S = 4
+    // elements for one channel, 2 for two) overlap in whole dwords - elements P, P+4 | P+4, P+8 | P+8, P+12 - so a group of
+    // three fetches 4 (6) dwords per template row instead of 6 (12): the kernel is bound by LDS cycles, and these reads are
+    // 60 % (75 %) of them.  The three dot chains are independent, as before.
+    auto group = [&](int dy, int dx, auto ng_tag) {
+        constexpr int NG = decltype(ng_tag)::value;
+        constexpr int S = 4 / CH, NE = CH == 1 ? NG + 1 : NG + 3, NR = ROWS + kT - 1;
+        const unsigned* bb = reinterpret_cast<const unsigned*>(abase) + dy * YP + dx;
+        const int* sbb = sa_base + dy * SB_W + dx;
+        unsigned P[NG][NR], cen[NG][NR], acc[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) acc[j] = 0;
+        // Software pipeline (the compiler on its own issues every LDS read right before its first use and waits for it):
+        // the elements of template row r+1 and the SB of this row's output are requested before the dots of row r, and a
+        // weight read from the table is only accumulated after the dots of the following row.  sched_barrier pins the order.
+        unsigned nxt[NE], wpend[NG], cpend[NG];
+        int sbn[NG];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) nxt[k] = bb[S * k];
+#pragma unroll
+        for (int r = 0; r <= NR; ++r) {
+            unsigned e[NE];
+            int sbv[NG];
+            if (r < NR) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) e[k] = nxt[k];
+#pragma unroll
+                for (int j = 0; j < NG; ++j) sbv[j] = sbn[j];
+                if (r + 1 < NR) {
+#pragma unroll
+                    for (int k = 0; k < NE; ++k) nxt[k] = bb[(r + 1) * YP + S * k];
+                    if (r + 1 >= kT - 1) {
+#pragma unroll
+                        for (int j = 0; j < NG; ++j) sbn[j] = sbb[j * S + (r + 1 - (kT - 1)) * SB_W];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    NbY<CH> b;
+                    b.e[0] = make_uint2(e[j], e[j + 1]);
+                    if constexpr (CH == 2) b.e[1] = make_uint2(e[j + 2], e[j + 3]);
+                    acc[j] = y_dot<CH>(A[r], b, acc[j]);
+                    P[j][r] = acc[j];
+                    cen[j][r] = CH == 1 ? b.e[0].x : b.e[0].y;
+                }
+            }
+            if (r >= kT) {  // the weights requested one row ago
+                const int i = r - kT;
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    wsum[i] += wpend[j];
+                    if (CH == 1) {
+                        est[i][0] += __umul24(wpend[j], cpend[j] >> 24);
+                    } else {
+                        est[i][0] += __umul24(wpend[j], (cpend[j] >> 16) & 0xffu);
+                        est[i][CH - 1] += __umul24(wpend[j], cpend[j] >> 24);
+                    }
+                }
+            }
+            if (r >= kT - 1 && r < NR) {
+                const int i = r - (kT - 1);
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    const unsigned AB = i == 0 ? P[j][r] : P[j][r] - P[j][i - 1];
+                    unsigned D = (unsigned)(SA[i] + sbv[j]);
+                    D = sub_keep(D, AB);
+                    D = sub_keep(D, AB);
+                    D = min(D, dmax);
+                    const unsigned boff = (D >> 4) & ~3u;
+                    wpend[j] = LUT_LDS ? *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(lut_s) + boff)
+                                       : *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(np.lut) + boff);
+                    cpend[j] = cen[j][r - 3];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    if constexpr (XL) {
 #pragma unroll 1
-    for (int o = 0; o + kPair <= kS * kS; o += kPair) offsets(o, std::integral_constant<int, kPair>{});
+        for (int dy = -kSH; dy <= kSH; ++dy) {
+            if constexpr (CH == 1) {
+                // dx index 0..20: {0,4,8} {1,5,9} {2,6,10} {3,7,11} {12,16,20} | {13,17} {14,18} {15,19}
 #pragma unroll 1
-    for (int o = (kS * kS) / kPair * kPair; o < kS * kS; ++o) offsets(o, std::integral_constant<int, 1>{});
+                for (int g = 0; g < 5; ++g) group(dy, (g < 4 ? g : 12) - kSH, std::integral_constant<int, 3>{});
+#pragma unroll 1
+                for (int g = 0; g < 3; ++g) group(dy, 13 + g - kSH, std::integral_constant<int, 2>{});
+            } else {
+                // pairs {0,2} {1,3} {4,6} {5,7} ... {16,18} {17,19} | {20}   (triples need ~150 registers: spills at 168)
+#pragma unroll 1
+                for (int g = 0; g < 10; ++g) group(dy, (g >> 1) * 4 + (g & 1) - kSH, std::integral_constant<int, 2>{});
+                group(dy, 20 - kSH, std::integral_constant<int, 1>{});
+            }
+        }
+    } else {
+        // offsets in flight per wavefront, 8-byte elements (2 wavefronts per SIMD): 3 / 2 measured best
+        constexpr int kPair = CH == 1 ? 3 : 2;
+#pragma unroll 1
+        for (int o = 0; o + kPair <= kS * kS; o += kPair) offsets(o, std::integral_constant<int, kPair>{});
+#pragma unroll 1
+        for (int o = (kS * kS) / kPair * kPair; o < kS * kS; ++o) offsets(o, std::integral_constant<int, 1>{});
+    }
 
     // divByWeightsSum + saturate_cast<uchar>
     const int gx = x0 + lane;
@@ -347,6 +441,20 @@ __global__ void __launch_bounds__(256) k_nlm_y(PageSet src, PageSetOut dst, NlmP
             }
         }
     }
+}
+
+// The 8-byte-element variant runs 2 wavefronts per SIMD (LDS), the 4-byte one (XL) 3-4: its two-channel instantiation keeps
+// three offsets in flight and needs ~150 registers - pinned to 3 wavefronts per SIMD (168) instead of the 241 the scheduler
+// takes when left alone.
+template <int CH, bool LUT_LDS, bool XL = false>
+__global__ void __launch_bounds__(256) k_nlm_y(PageSet src, PageSetOut dst, NlmParams np)
+{
+    nlm_y_body<CH, LUT_LDS, false>(src, dst, np);
+}
+template <int CH, bool LUT_LDS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) k_nlm_y_xl(PageSet src, PageSetOut dst, NlmParams np)
+{
+    nlm_y_body<CH, LUT_LDS, true>(src, dst, np);
 }
 
 // ---- generic kernel (3 interleaved channels; fastNlMeansDenoising on a colour image, not on the prl::denoise
@@ -667,8 +775,8 @@ int launch_nlm(const PageSet& src_all, const PageSetOut& dst_all, int n_pages, c
             const int xl_env = env_knobs().nlm_xl;
             const bool xl = np.n_lut <= kLutMaxXL && ((xl_env >> (C - 1)) & 1);
             const bool glut = (env_knobs().nlm_glut >> (C - 1)) & 1;  // weight table from memory (L1) instead of LDS
-            if (xl && glut) hipLaunchKernelGGL((k_nlm_y<C, false, true>), grid, dim3(256), 0, stream, src, dst, np);
-            else if (xl) hipLaunchKernelGGL((k_nlm_y<C, true, true>), grid, dim3(256), 0, stream, src, dst, np);
+            if (xl && glut) hipLaunchKernelGGL((k_nlm_y_xl<C, false>), grid, dim3(256), 0, stream, src, dst, np);
+            else if (xl) hipLaunchKernelGGL((k_nlm_y_xl<C, true>), grid, dim3(256), 0, stream, src, dst, np);
             else if (lds_lut) hipLaunchKernelGGL((k_nlm_y<C, true>), grid, dim3(256), 0, stream, src, dst, np);
             else hipLaunchKernelGGL((k_nlm_y<C, false>), grid, dim3(256), 0, stream, src, dst, np);
         } else {

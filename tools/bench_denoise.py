@@ -29,19 +29,23 @@ px = a.pages * a.size * a.size
 res = {"workload": f"prl::denoise strength={a.strength} on {a.pages} x {a.size}^2 x 3", "ms_per_batch": round(dt * 1e3, 2),
        "Mpixels/s": round(px / dt / 1e6, 1), "algorithmic_GB/s (6 B/px)": round(6 * px / dt / 1e9, 2),
        "frac_of_8TB/s": round(6 * px / dt / 8e12, 5)}
-# NL-means is not HBM-bound: the roofs that matter are vector-ALU issue and the LDS pipe.  Instruction counts per pixel from the
-# committed counter profile of these kernels (profiles/r01/pmc_nlm_xl.txt, 8 x 4096^2: SQ_INSTS_VALU 7.03e9 + 9.60e9 wave
-# instructions for the L and ab planes, SQ_INSTS_LDS 1.52e9 + 2.34e9; SQ_LDS_IDX_ACTIVE 88 % of the CU cycles); peak issue =
-# one wave64 vector instruction per 4 cycles and SIMD (what k_fused's counters show on this chip), 1024 SIMDs, 2.4 GHz.
-VALU_WAVE_INSTR_PER_PX = (7.02791e9 + 9.60183e9) / (8 * 4096 * 4096)
-LDS_WAVE_INSTR_PER_PX = (1.51867e9 + 2.3356e9) / (8 * 4096 * 4096)
+# NL-means is not HBM-bound: the roofs that matter are the LDS pipe and vector-ALU issue.  Counts from the committed counter
+# profile of these kernels (profiles/r02/pmc_nlm.txt, 8 x 4096^2, summed over the chip): SQ_INSTS_VALU 1.241e10 + 1.697e10
+# wavefront instructions for the L and ab planes, SQ_INSTS_LDS 2.75e9 + 3.86e9, SQ_LDS_IDX_ACTIVE 9.90e9 + 1.33e10 cycles =
+# 87 % / 78 % of each kernel's cycles on every CU; peak issue = one wave64 vector instruction per 4 cycles and SIMD (what
+# k_fused's counters show on this chip), 1024 SIMDs, 2.4 GHz; LDS roof = every CU's LDS busy every cycle.
+VALU_WAVE_INSTR_PER_PX = (1.2414e10 + 1.6972e10) / (8 * 4096 * 4096)
+LDS_WAVE_INSTR_PER_PX = (2.7452e9 + 3.8617e9) / (8 * 4096 * 4096)
+LDS_ACTIVE_CYCLES_PER_PX = (9.8972e9 + 1.3287e10) / (8 * 4096 * 4096)
 peak_valu = 1024 * 2.4e9 / 4
-res["alu_roofline"] = {"bound": "valu_issue+lds", "valu_wave_instr_per_px": round(VALU_WAVE_INSTR_PER_PX, 1),
+res["alu_roofline"] = {"bound": "lds", "valu_wave_instr_per_px": round(VALU_WAVE_INSTR_PER_PX, 1),
                        "lds_wave_instr_per_px": round(LDS_WAVE_INSTR_PER_PX, 1),
                        "achieved_valu_Ginstr_s": round(VALU_WAVE_INSTR_PER_PX * px / dt / 1e9, 1),
                        "peak_valu_Ginstr_s": round(peak_valu / 1e9, 1),
                        "valu_frac": round(VALU_WAVE_INSTR_PER_PX * px / dt / peak_valu, 3),
-                       "lds_idx_active_frac_of_cu_cycles": 0.88, "source": "profiles/r01/pmc_nlm_xl.txt"}
+                       "lds_active_cycles_per_px": round(LDS_ACTIVE_CYCLES_PER_PX, 1),
+                       "lds_frac": round(LDS_ACTIVE_CYCLES_PER_PX * px / dt / (256 * 2.4e9), 3),   # of 256 CUs x 2.4 GHz
+                       "source": "profiles/r02/pmc_nlm.txt"}
 if a.check:
     from oracle import capi as oc
     sub = img[0, :256, :256].cpu().numpy().copy()
