@@ -198,6 +198,11 @@ __device__ __forceinline__ int wave_max_i32(int x)
 // pages - the batch keeps the memory system busy either way - and 24 / 16 the same as 32 (profiles/r02/chain_overlap.txt).
 constexpr int kBlk = PRL_PPHT_BLK;
 
+// A vote.  A lane is the only one that ever touches its cells, but a narrower scope buys nothing: wavefront, workgroup and agent
+// scope compile to the same `global_atomic_add ... sc0`; where it executes is decided by the memory type (hipMalloc: behind the
+// L2s, profiles/r02/pmc_ppht.txt).
+__device__ __forceinline__ int vote(int* cell, int d) { return __hip_atomic_fetch_add(cell, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // HoughLinesP stage 2, one wavefront per page, BLOCKS OF kBlk POINTS (round 2, second version).  The first version walked the
 // points one by one: list fetch -> mask byte -> 180 voting atomics -> decision, three dependent memory round trips per
 // point (1.9 us).  Two facts allow overlapping them without changing a single result:
@@ -308,7 +313,7 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
                         step_pixel(xflag, x0, y0, dx, dy, base + (unsigned)q, &jq, &iq);
 #pragma unroll
                         for (int qq = 0; qq < 3; ++qq)
-                            if (qq < 2 || has2) atomicAdd(arow[qq] + cv_round_f((float)jq * tc[qq] + (float)iq * ts[qq]), -1);
+                            if (qq < 2 || has2) vote(arow[qq] + cv_round_f((float)jq * tc[qq] + (float)iq * ts[qq]), -1);
                     }
                 }
             }
@@ -370,7 +375,7 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
                     const float fj = (float)(q & 0xffffu), fi = (float)(q >> 16);
 #pragma unroll
                     for (int qq = 0; qq < 3; ++qq)
-                        if (qq < 2 || has2) v[p][qq] = atomicAdd(arow[qq] + cv_round_f(fj * tc[qq] + fi * ts[qq]), 1);
+                        if (qq < 2 || has2) v[p][qq] = vote(arow[qq] + cv_round_f(fj * tc[qq] + fi * ts[qq]), 1);
                 }
             }
             // retire in order: key = count * 256 + (255 - angle), signed (counts go negative: a good line takes back the votes
@@ -398,7 +403,7 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
                     const float fj = (float)(q & 0xffffu), fi = (float)(q >> 16);
 #pragma unroll
                     for (int qq = 0; qq < 3; ++qq)
-                        if (qq < 2 || has2) atomicAdd(arow[qq] + cv_round_f(fj * tc[qq] + fi * ts[qq]), -1);
+                        if (qq < 2 || has2) vote(arow[qq] + cv_round_f(fj * tc[qq] + fi * ts[qq]), -1);
                 }
             }
             const unsigned tq = (unsigned)__builtin_amdgcn_readlane((int)pt, trig);
