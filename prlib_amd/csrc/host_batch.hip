@@ -340,6 +340,14 @@ int chain_worker(int dev, const prl_chain_params* cp, int channels, int first, i
 }
 
 }  // namespace
+
+void host_slots_free(DeviceCtx* ctx)
+{
+    for (int i = 0; i < 2; ++i) {
+        delete static_cast<PinSlots*>(ctx->host_slots[i]);
+        ctx->host_slots[i] = nullptr;
+    }
+}
 }  // namespace prl_hip
 
 using namespace prl_hip;

@@ -933,14 +933,27 @@ int prl_hip_release_workspace(void)
     int st = current_device(&dev);
     if (st != PRL_OK) return st;
     DeviceCtx* ctx = device_ctx(dev);
-    std::lock_guard<std::mutex> slk(ctx->stage_mu);  // lock order everywhere: stage_mu, then mu
+    std::lock_guard<std::mutex> hlk(ctx->host_mu);   // lock order everywhere: host_mu, stage_mu, mu, ppht_mu
+    std::lock_guard<std::mutex> slk(ctx->stage_mu);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> plk(ctx->ppht_mu);
     std::lock_guard<std::mutex> mlk(ctx->streams_mu);
     for (auto& kv : ctx->streams) {
         std::lock_guard<std::mutex> wl(kv.second->mu);
         (void)resolve_all(kv.second.get());
     }
     PRL_HIP_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < 3; ++i) {
+        if (ctx->ppht_buf[i]) PRL_HIP_CHECK(hipFree(ctx->ppht_buf[i]));
+        ctx->ppht_buf[i] = nullptr;
+        ctx->ppht_bytes[i] = 0;
+    }
+    for (int i = 0; i < 4; ++i) {
+        if (ctx->host_buf[i]) PRL_HIP_CHECK(hipFree(ctx->host_buf[i]));
+        ctx->host_buf[i] = nullptr;
+        ctx->host_buf_bytes[i] = 0;
+    }
+    host_slots_free(ctx);
     for (auto& kv : ctx->streams) {
         std::lock_guard<std::mutex> wl(kv.second->mu);
         ws_free(kv.second.get());

@@ -218,7 +218,8 @@ int deskew_pages(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size
 // glue.hip: pages per pass of the chain and its workspace bytes per page (host_batch.hip sizes device chunks in whole passes)
 int chain_pass_layout(const prl_chain_params* cp, int n_pages, int channels, int width, int height, int* pass_pages,
                       size_t* per_page_out, size_t* desk_page_out);
-int ensure_buffer(void** buf, size_t* have, size_t bytes);  // grow-only device buffer (synchronises the device when it grows)
+int ensure_buffer(void** buf, size_t* have, size_t bytes);
+void host_slots_free(DeviceCtx* ctx);  // host_batch.hip: the pinned bounce slots of prl_hip_chain_batch_host (caller holds host_mu)  // grow-only device buffer (synchronises the device when it grows)
 
 // ---- morphology (morph.hip) ------------------------------------------------------------------
 int morph_run(int iterations, const PageSet& src, int n_pages, int width, int height,

@@ -279,6 +279,26 @@ print("DONE")
             assert np.array_equal(z["p%d" % i], got[i]), i
 
 
+def test_release_workspace_between_calls(prl, cuda_device):
+    """prl_hip_release_workspace frees every cached buffer (stage area, angle-search workspace, host page buffers and pinned
+    slots, per-stream workspaces); the next calls allocate again and give the same results."""
+    import torch
+    from prlib_amd import synth, _capi
+
+    pages = [np.repeat(synth.text_page_numpy(120, 176, 90 + i, skew_deg=s, shading=0.2)[..., None], 3, axis=2) for i, s in enumerate((1.5, -2.0))]
+    kw = dict(denoise_strength=10.0, thin=0, deskew=True, background_normalization=True)
+    a, ang_a = prl.process_pages_host(pages, prl.SAUVOLA, 31, 0.34, 0, n_devices=1, **kw)
+    d, ang_d = prl.process_pages(torch.from_numpy(np.stack(pages)).to(cuda_device), 3, prl.SAUVOLA, 31, 0.34, 0, **kw)
+    d = [x.cpu().numpy() for x in d]
+    torch.cuda.synchronize()
+    _capi.check(_capi.lib().prl_hip_release_workspace())
+    b, ang_b = prl.process_pages_host(pages, prl.SAUVOLA, 31, 0.34, 0, n_devices=1, **kw)
+    e, ang_e = prl.process_pages(torch.from_numpy(np.stack(pages)).to(cuda_device), 3, prl.SAUVOLA, 31, 0.34, 0, **kw)
+    assert np.array_equal(ang_a, ang_b) and np.array_equal(np.asarray(ang_d), np.asarray(ang_e)) and np.array_equal(ang_a, np.asarray(ang_d))
+    for i in range(len(pages)):
+        assert np.array_equal(a[i], b[i]) and np.array_equal(d[i], e[i].cpu().numpy()) and np.array_equal(a[i], d[i])
+
+
 def test_chain_stage_subsets(prl, oracle, cuda_device):
     import torch
     from prlib_amd import synth
