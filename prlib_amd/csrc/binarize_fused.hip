@@ -100,7 +100,15 @@ struct FusedParams {
     int nt_store;      // non-temporal mask stores (on unless PRL_HIP_NT=0)
     int bit_out;       // the mask is written as a bit plane (1 bit per pixel) for the bit-domain morphology pass
     int flt;           // interior strips run the float32 pipeline (typed loads, float sums): w - 1 <= 30, see strip_loop_f
+    // Epilogue of the call (small batches: a launch costs ~4 us, which is what the flag copy and the next call's
+    // k_init_globals cost each): the last workgroup of the last kernel (k_corner_partial<true>) writes the per-page flags
+    // straight into the caller's pinned slot and leaves globals and counters in their initial state.  ep_host == null: off.
+    PageGlobals* ep_host;
+    PageGlobals* ep_dev;
+    unsigned* ep_counters;
+    int ep_pages;
 };
+constexpr int kEpArrive = 60;  // counter word counting the workgroups of the last kernel that are done
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -1163,6 +1171,32 @@ __global__ void __launch_bounds__(256) k_corner_partial(PageSet src, FusedParams
         }
         __syncthreads();
     }
+    if constexpr (FINAL) {
+        if (fp.ep_host) {   // (uniform over the grid)
+            // Empty queue (the rule): no workgroup touches the globals or needs the counters to be anything but zero, so
+            // workgroup (0, 0) can run the epilogue without waiting for anybody.  Otherwise the last one to finish runs it
+            // (1024 arrivals on one word cost ~50 us: acceptable for the rare page that reaches the literal fix-up).
+            __shared__ unsigned s_last;
+            if (n == 0) {
+                if (threadIdx.x == 0) s_last = (blockIdx.x == 0 && blockIdx.y == 0) ? 1u : 0u;
+            } else {
+                __threadfence();
+                __syncthreads();
+                if (threadIdx.x == 0) s_last = atomicAdd(&fp.ep_counters[kEpArrive], 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+            }
+            __syncthreads();
+            if (s_last) {   // every other workgroup has finished: nothing reads the counters or the globals any more
+                for (int i = threadIdx.x; i < fp.ep_pages; i += blockDim.x) {
+                    fp.ep_host[i] = fp.ep_dev[i];
+                    PageGlobals z;
+                    z.imin = 255; z.smax_found = 0; z.smax_bits = 0ull; z.coeff = 0.0;
+                    z.n_refined = 0; z.n_exact = 0; z.worklist_overflow = 0; z.v32max_bits = 0;
+                    fp.ep_dev[i] = z;   // = k_init_globals
+                }
+                if (threadIdx.x < 64) fp.ep_counters[threadIdx.x] = 0u;
+            }
+        }
+    }
 }
 
 __device__ __forceinline__ void literal_mq(const CornerAcc& c, double f, double* m, double* q)
@@ -1451,7 +1485,7 @@ int fused_max_pages(const ThrParams& tp)
 // and skips phase 2 - two launches and a 1 MB memset - when nothing was queued, the usual case)
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst, void* small,
               PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool bit_out, int phase,
-              bool counters_zeroed)
+              bool counters_zeroed, PageGlobals* host_globals)
 {
     FusedParams fp{};
     fp.tp = tp;
@@ -1514,6 +1548,12 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
 
     // [0] refine-list length, [1] fix-up-list length, [2] Wolf candidate-list length
     auto* cnt = static_cast<unsigned*>(small);
+    if (host_globals && phase == 0) {
+        fp.ep_host = host_globals;
+        fp.ep_dev = d_globals;
+        fp.ep_counters = cnt;
+        fp.ep_pages = n_pages;
+    }
     auto* rl = reinterpret_cast<RefItem*>(static_cast<uint8_t*>(small) + 256);
     auto* wl = reinterpret_cast<WorkItem*>(static_cast<uint8_t*>(small) + 256 + sizeof(RefItem) * (size_t)kRefineCap);
     auto* cand = wl + kWorkCap;

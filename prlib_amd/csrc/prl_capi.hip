@@ -122,7 +122,11 @@ struct StreamWs {
     CallStats last;           // the most recent call whose numbers are known
     hipEvent_t prof_start = nullptr, prof_stop = nullptr;
     bool prof_valid = false;
+    // The last call's final kernel left the first `clean_pages` PageGlobals and the counter block of `small` in their
+    // initial state (FusedParams::ep_host): a following call with the same page count needs no k_init_globals.
+    int clean_pages = 0;
 };
+constexpr int kEpilogueMaxPages = 256;  // beyond that a launch or two per call no longer matter and one workgroup copying flags would
 
 int ws_grow(void** p, size_t* cur, size_t need, hipStream_t stream, size_t floor_bytes = 0)
 {
@@ -166,6 +170,7 @@ void ws_free(StreamWs* ws)
     ws->prof_valid = false;
     ws->pending.clear();
     ws->next_slot = 0;
+    ws->clean_pages = 0;
 }
 
 DeviceCtx::~DeviceCtx() = default;  // (process teardown: the driver reclaims device memory)
@@ -674,8 +679,11 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
     // small device area: [PageGlobals x n][src table][dst table][fused work area]
     const SlotLayout sl = slot_layout(n_pages);
     const size_t fused_bytes = fused_small_bytes(n_pages);
+    const void* small_before = ws->small;
     st = ws_grow(&ws->small, &ws->small_bytes, sl.globals_bytes + 2 * sl.table_bytes + fused_bytes, stream, 1 << 20);
     if (st != PRL_OK) return st;
+    const bool was_clean = ws->small == small_before && ws->clean_pages == n_pages;
+    ws->clean_pages = 0;   // unknown until this call's own epilogue is enqueued
     auto* small = static_cast<uint8_t*>(ws->small);
     auto* d_globals = reinterpret_cast<PageGlobals*>(small);
     auto* d_src_tab = reinterpret_cast<const uint8_t**>(small + sl.globals_bytes);
@@ -743,8 +751,12 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         thr_dst.step = bit_mask ? bit_step : mask_step;
     }
 
-    st = init_globals_run(d_globals, n_pages, stream, use_fused ? d_fused : nullptr);  // (+ the fused pipeline's counter block)
-    if (st != PRL_OK) return st;
+    // small batches: the fused pipeline's last kernel delivers the flags and re-initialises globals and counters itself
+    const bool epilogue = use_fused && n_pages <= kEpilogueMaxPages;
+    if (!(epilogue && was_clean)) {
+        st = init_globals_run(d_globals, n_pages, stream, use_fused ? d_fused : nullptr);  // (+ the fused pipeline's counter block)
+        if (st != PRL_OK) return st;
+    }
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ws->prof_valid = false;
@@ -760,10 +772,11 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         // threshold sweep, float64 interval test of what it left open, literal fix-up of what THAT left open: all enqueued,
         // the last two find their queues on the device and do nothing when they are empty.  Pages whose fix-up queue
         // overflowed are flagged; the flags travel to the pinned slot and are looked at in resolve_front().
-        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask, 0, true);
+        auto* h_globals = reinterpret_cast<PageGlobals*>(pin + 2 * sl.table_bytes);
+        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask, 0, true, epilogue ? h_globals : nullptr);
         if (st != PRL_OK) return st;
-        PRL_HIP_CHECK(hipMemcpyAsync(pin + 2 * sl.table_bytes, d_globals, sizeof(PageGlobals) * (size_t)n_pages,
-                                     hipMemcpyDeviceToHost, stream));
+        if (epilogue) ws->clean_pages = n_pages;
+        else PRL_HIP_CHECK(hipMemcpyAsync(h_globals, d_globals, sizeof(PageGlobals) * (size_t)n_pages, hipMemcpyDeviceToHost, stream));
     } else {
         if (tp.method == PRL_WOLFJOLION || tp.method == PRL_FENG) {
             st = page_min_run(tp, src, n_pages, d_globals, stream);

@@ -257,6 +257,24 @@ def test_wolf_runs_fused(prl, oracle, cuda_device):
     assert st.literal_pages == 1
 
 
+def test_back_to_back_calls_reuse_the_self_cleaned_state(prl, oracle, cuda_device):
+    """Small batches: the last kernel of a call writes the flags into the pinned slot and re-initialises the per-page globals
+    and the counter block, and the next call with the same page count skips k_init_globals.  Every transition of that state
+    machine - same count twice, another count, literal mode in between, Wolf-Jolion and Feng (which need imin = 255 and the
+    maxima zeroed), pages that reach the literal fix-up (the epilogue then waits for every workgroup) - against the oracle."""
+    docs3 = _pages((300, 520), ["doc", "doc", "noise"], seed=51)
+    docs5 = _pages((300, 520), ["doc", "noise", "doc", "binary", "doc"], seed=52)
+    w, c = 15, 200
+    ties = [np.full((260, 300), c, np.uint8), _pages((260, 300), ["doc"], seed=53)[0], np.full((260, 300), c, np.uint8)]
+    k_tie = _flat_boundary_k(c, w, c)
+    seq = [(docs3, SAUVOLA, 31, 0.34, 0, None), (docs3, SAUVOLA, 31, 0.34, 0, None), (docs5, NICK, 21, -0.1, 0, None),
+           (docs3, WOLFJOLION, 31, 0.3, 0, None), (docs3, WOLFJOLION, 31, 0.3, 0, None), (docs3, SAUVOLA, 15, 0.2, 2, 1),
+           (docs3, FENG, 31, 0.2, 0, None), (docs3, FENG, 31, 0.2, 0, None), (ties, SAUVOLA, w, k_tie, 0, None),
+           (ties, SAUVOLA, w, k_tie, 0, None), (docs3, NIBLACK, 31, -0.2, 1, None), (docs3, WOLFJOLION, 101, 0.01, 2, None)]
+    for pages, method, win, k, morph, mode in seq:
+        _check(prl, oracle, cuda_device, pages, method, win, k, morph, mode=mode)
+
+
 @pytest.mark.parametrize("n", [1, 2, -2, 5, 8, -8])
 def test_public_morph_entry_on_gray_and_binary(prl, oracle, cuda_device, n):
     import torch
