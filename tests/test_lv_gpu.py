@@ -19,7 +19,7 @@ def _colour(h, w, seed, skew=0.0, shading=0.2):
     return np.clip(g[..., None].astype(np.int32) + rng.normal(0, 5, (h, w, 3)), 0, 255).round().astype(np.uint8)
 
 
-@pytest.mark.parametrize("shape", [(200, 260), (97, 131), (33, 40), (8, 32), (1, 1), (257, 65)])
+@pytest.mark.parametrize("shape", [(200, 260), (97, 131), (33, 40), (8, 32), (1, 1), (257, 65), (530, 777), (18, 3000)])
 def test_without_filters_is_bit_exact(prl, oracle, cuda_device, shape):
     import torch
 
@@ -31,7 +31,7 @@ def test_without_filters_is_bit_exact(prl, oracle, cuda_device, shape):
             assert np.array_equal(got[i], want), (shape, coeff, mv, int((got[i] != want).sum()))
 
 
-@pytest.mark.parametrize("shape", [(200, 260), (97, 131), (64, 48), (300, 411)])
+@pytest.mark.parametrize("shape", [(200, 260), (97, 131), (64, 48), (300, 411), (140, 700)])
 def test_with_filters_within_tolerance(prl, oracle, cuda_device, shape):
     import torch
 
