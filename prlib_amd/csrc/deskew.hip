@@ -431,83 +431,94 @@ __device__ __forceinline__ uint2 load8u(const uint8_t* p)
 }
 __device__ __forceinline__ unsigned byte_at(uint2 v, int i) { return ((i < 4 ? v.x : v.y) >> (8 * (i & 3))) & 0xffu; }
 
-// A workgroup produces 256 consecutive pixels of one output row; the result bytes go through LDS so that the row segment is
-// stored as dwords (byte stores of CH-byte pixels cost three to four instructions per pixel).  Pages of kind 1 / 3
-// (quarter turns) are left to k_rot90.
+// A workgroup produces 256 consecutive pixels of kWarpRows output rows; the result bytes go through LDS so that a row segment is
+// stored as dwords (byte stores of CH-byte pixels cost three to four instructions per pixel).  The column terms of the source
+// coordinates (warpAffine's adelta / bdelta tables, float64) are formed once per thread and reused for its rows, the row terms
+// once per row by one lane.  Pages of kind 1 / 3 (quarter turns) are left to k_rot90.
+constexpr int kWarpRows = 4;
 template <int CH>
 __global__ void __launch_bounds__(256) k_warp(PageSet src, PageSetOut dst, int width, int height, const WarpPage* __restrict__ wp)
 {
     __shared__ __attribute__((aligned(16))) uint8_t seg[256 * CH + 16];
-    const int page = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * 256, x = x0 + (int)threadIdx.x;
+    __shared__ int rowXY[kWarpRows][2];
+    const int page = blockIdx.z, y0 = blockIdx.y * kWarpRows, x0 = blockIdx.x * 256, x = x0 + (int)threadIdx.x;
     const WarpPage& p = wp[page];
-    if (p.kind == 1 || p.kind == 3 || x0 >= p.ow || y >= p.oh) return;
+    if (p.kind == 1 || p.kind == 3 || x0 >= p.ow || y0 >= p.oh) return;
     const uint8_t* s = src.page(page);
-    // the row terms of the coordinates are the same for the whole workgroup: one lane computes them (float64)
-    __shared__ int rowXY[2];
+    int adelta = 0, bdelta = 0;
     if (p.kind == 0) {
-        if (threadIdx.x == 0) {
-            rowXY[0] = __double2int_rn((p.M[1] * y + p.M[2]) * 1024) + 16;
-            rowXY[1] = __double2int_rn((p.M[4] * y + p.M[5]) * 1024) + 16;
+        if (threadIdx.x < kWarpRows) {
+            const int y = y0 + (int)threadIdx.x;
+            rowXY[threadIdx.x][0] = __double2int_rn((p.M[1] * y + p.M[2]) * 1024) + 16;
+            rowXY[threadIdx.x][1] = __double2int_rn((p.M[4] * y + p.M[5]) * 1024) + 16;
         }
+        adelta = __double2int_rn(p.M[0] * x * 1024);
+        bdelta = __double2int_rn(p.M[3] * x * 1024);
         __syncthreads();
     }
-    unsigned res[CH];
+    const int nrows = min(kWarpRows, p.oh - y0);
+    for (int ry = 0; ry < nrows; ++ry) {
+        const int y = y0 + ry;
+        unsigned res[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) res[c] = 0;
-    if (x < p.ow) {
-        if (p.kind != 0) {  // 2: half turn; 4: copy
-            const int sx = p.kind == 2 ? width - 1 - x : x, sy = p.kind == 2 ? height - 1 - y : y;
-            const uint8_t* q = s + (size_t)sy * src.step + (size_t)sx * CH;
+        for (int c = 0; c < CH; ++c) res[c] = 0;
+        if (x < p.ow) {
+            if (p.kind != 0) {  // 2: half turn; 4: copy
+                const int sx = p.kind == 2 ? width - 1 - x : x, sy = p.kind == 2 ? height - 1 - y : y;
+                const uint8_t* q = s + (size_t)sy * src.step + (size_t)sx * CH;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) res[c] = q[c];
-        } else {
-            const int X0 = rowXY[0], Y0 = rowXY[1];
-            const int X = (X0 + __double2int_rn(p.M[0] * x * 1024)) >> 5, Y = (Y0 + __double2int_rn(p.M[3] * x * 1024)) >> 5;
-            const int sx = max(-32768, min(32767, X >> 5)), sy = max(-32768, min(32767, Y >> 5));
-            const int fx = X & 31, fy = Y & 31;
-            const int w00 = 32 * (32 - fx) * (32 - fy), w01 = 32 * fx * (32 - fy), w10 = 32 * (32 - fx) * fy, w11 = 32 * fx * fy;
-            const bool x0in = sx >= 0 && sx < width, x1in = sx + 1 >= 0 && sx + 1 < width;
-            const bool y0in = sy >= 0 && sy < height, y1in = sy + 1 >= 0 && sy + 1 < height;
-            const uint8_t* r0 = s + (size_t)sy * src.step + (size_t)sx * CH;  // only dereferenced where the flags allow
-            const uint8_t* r1 = r0 + src.step;
-            // both taps of a row are 2 * CH <= 8 consecutive bytes: one 8-byte fetch per row when all four taps are inside
-            // and the fetch cannot run past the page's last row
-            const bool wide = x0in && x1in && y0in && y1in && (sy + 2 < height || sx * CH + 8 <= (int)src.step);
-            if (wide) {
-                const uint2 a = load8u(r0), b = load8u(r1);
-#pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    const int v00 = 255 - (int)byte_at(a, c), v01 = 255 - (int)byte_at(a, CH + c);
-                    const int v10 = 255 - (int)byte_at(b, c), v11 = 255 - (int)byte_at(b, CH + c);
-                    res[c] = (unsigned)(255 - ((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15));
-                }
+                for (int c = 0; c < CH; ++c) res[c] = q[c];
             } else {
+                const int X = (rowXY[ry][0] + adelta) >> 5, Y = (rowXY[ry][1] + bdelta) >> 5;
+                const int sx = max(-32768, min(32767, X >> 5)), sy = max(-32768, min(32767, Y >> 5));
+                const int fx = X & 31, fy = Y & 31;
+                const int w00 = 32 * (32 - fx) * (32 - fy), w01 = 32 * fx * (32 - fy), w10 = 32 * (32 - fx) * fy, w11 = 32 * fx * fy;
+                const bool x0in = sx >= 0 && sx < width, x1in = sx + 1 >= 0 && sx + 1 < width;
+                const bool y0in = sy >= 0 && sy < height, y1in = sy + 1 >= 0 && sy + 1 < height;
+                const uint8_t* r0 = s + (size_t)sy * src.step + (size_t)sx * CH;  // only dereferenced where the flags allow
+                const uint8_t* r1 = r0 + src.step;
+                // both taps of a row are 2 * CH <= 8 consecutive bytes: one 8-byte fetch per row when all four taps are inside
+                // and the fetch cannot run past the page's last row
+                const bool wide = x0in && x1in && y0in && y1in && (sy + 2 < height || sx * CH + 8 <= (int)src.step);
+                if (wide) {
+                    const uint2 a = load8u(r0), b = load8u(r1);
 #pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    // the source is cv::bitwise_not(input); outside it the border value 0
-                    const int v00 = (x0in && y0in) ? 255 - r0[c] : 0, v01 = (x1in && y0in) ? 255 - r0[CH + c] : 0;
-                    const int v10 = (x0in && y1in) ? 255 - r1[c] : 0, v11 = (x1in && y1in) ? 255 - r1[CH + c] : 0;
-                    res[c] = (unsigned)(255 - ((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15));
+                    for (int c = 0; c < CH; ++c) {
+                        // the source is cv::bitwise_not(input) and the weights add up to 2^15:
+                        // sum w (255 - v) = 255 * 2^15 - sum w v
+                        const int wv = (int)byte_at(a, c) * w00 + (int)byte_at(a, CH + c) * w01 + (int)byte_at(b, c) * w10 +
+                                       (int)byte_at(b, CH + c) * w11;
+                        res[c] = (unsigned)(255 - ((255 * 32768 - wv + (1 << 14)) >> 15));
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        // outside the (inverted) source the border value 0
+                        const int v00 = (x0in && y0in) ? 255 - r0[c] : 0, v01 = (x1in && y0in) ? 255 - r0[CH + c] : 0;
+                        const int v10 = (x0in && y1in) ? 255 - r1[c] : 0, v11 = (x1in && y1in) ? 255 - r1[CH + c] : 0;
+                        res[c] = (unsigned)(255 - ((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15));
+                    }
                 }
             }
         }
-    }
-    // the segment's bytes: [head up to the first 4-byte boundary of the destination][dwords][tail]
-    uint8_t* d0 = dst.page(page) + (size_t)y * dst.step + (size_t)x0 * CH;
-    const int nbytes = min(256, p.ow - x0) * CH;
-    const int head = min(nbytes, (int)((4 - ((size_t)d0 & 3)) & 3));
-    // the LDS image is shifted so that destination-aligned dwords are LDS-aligned dwords
-    const int shift = (4 - head) & 3;
+        // the segment's bytes: [head up to the first 4-byte boundary of the destination][dwords][tail]
+        uint8_t* d0 = dst.page(page) + (size_t)y * dst.step + (size_t)x0 * CH;
+        const int nbytes = min(256, p.ow - x0) * CH;
+        const int head = min(nbytes, (int)((4 - ((size_t)d0 & 3)) & 3));
+        // the LDS image is shifted so that destination-aligned dwords are LDS-aligned dwords
+        const int shift = (4 - head) & 3;
+        if (ry) __syncthreads();  // the previous row's segment has been stored
 #pragma unroll
-    for (int c = 0; c < CH; ++c) seg[shift + (int)threadIdx.x * CH + c] = (uint8_t)res[c];
-    __syncthreads();
-    if ((int)threadIdx.x < head) d0[threadIdx.x] = seg[shift + threadIdx.x];
-    const int ndw = (nbytes - head) / 4;
-    const unsigned* sw = reinterpret_cast<const unsigned*>(seg + shift + head);
-    unsigned* dw = reinterpret_cast<unsigned*>(d0 + head);
-    for (int i = threadIdx.x; i < ndw; i += 256) dw[i] = sw[i];
-    const int tail0 = head + ndw * 4;
-    if ((int)threadIdx.x < nbytes - tail0) d0[tail0 + threadIdx.x] = seg[shift + tail0 + threadIdx.x];
+        for (int c = 0; c < CH; ++c) seg[shift + (int)threadIdx.x * CH + c] = (uint8_t)res[c];
+        __syncthreads();
+        if ((int)threadIdx.x < head) d0[threadIdx.x] = seg[shift + threadIdx.x];
+        const int ndw = (nbytes - head) / 4;
+        const unsigned* sw = reinterpret_cast<const unsigned*>(seg + shift + head);
+        unsigned* dw = reinterpret_cast<unsigned*>(d0 + head);
+        for (int i = threadIdx.x; i < ndw; i += 256) dw[i] = sw[i];
+        const int tail0 = head + ndw * 4;
+        if ((int)threadIdx.x < nbytes - tail0) d0[tail0 + threadIdx.x] = seg[shift + tail0 + threadIdx.x];
+    }
 }
 
 // Quarter turns (rotate.cpp:38-58): out(y, x) = in(height - 1 - x, y) for 90, in(x, width - 1 - y) for 270.  A 32 x 32 tile
@@ -613,7 +624,7 @@ double vote_angle(const int* lines, int nb_lines)
 int launch_warp(int channels, const PageSet& s, const PageSetOut& d, int width, int height, int n_pages, int max_ow, int max_oh,
                 const WarpPage* d_wp, hipStream_t stream, bool any_quarter = true)
 {
-    const dim3 grid((unsigned)((max_ow + 255) / 256), (unsigned)max_oh, (unsigned)n_pages);
+    const dim3 grid((unsigned)((max_ow + 255) / 256), (unsigned)((max_oh + kWarpRows - 1) / kWarpRows), (unsigned)n_pages);
     switch (channels) {
     case 1: hipLaunchKernelGGL(k_warp<1>, grid, dim3(256), 0, stream, s, d, width, height, d_wp); break;
     case 2: hipLaunchKernelGGL(k_warp<2>, grid, dim3(256), 0, stream, s, d, width, height, d_wp); break;
