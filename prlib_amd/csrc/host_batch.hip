@@ -382,6 +382,8 @@ int prl_hip_binarize_batch_host(const prl_binarize_params* p, int n_pages, const
         set_error_detail("no HIP device");
         return PRL_ERR_NO_DEVICE;
     }
+    const int real = visible;
+    visible = std::max(visible, env_knobs().fake_devices);   // tests on a one-GPU box: several workers, all on the real device(s)
     const int devs = std::min(n_pages, n_devices == 0 ? visible : std::min(n_devices, visible));
     // host threads copying pages in / out of pinned memory, per device worker: the knob, bounded by the cores there are
     const unsigned hw = std::thread::hardware_concurrency();
@@ -393,7 +395,7 @@ int prl_hip_binarize_batch_host(const prl_binarize_params* p, int n_pages, const
         int first = 0, count = 0;
         prl_hip_page_range(n_pages, devs, d, &first, &count);
         workers.emplace_back([=, &status, &detail]() {
-            status[(size_t)d] = device_worker(d, p, g, first, count, src, src_step, width, height, dst, dst_step, copy_threads);
+            status[(size_t)d] = device_worker(d % real, p, g, first, count, src, src_step, width, height, dst, dst_step, copy_threads);
             if (status[(size_t)d] != PRL_OK) detail[(size_t)d] = prl_hip_last_error_detail();
         });
     }
@@ -433,6 +435,8 @@ int prl_hip_chain_batch_host(const prl_chain_params* cp, int n_pages, int channe
         set_error_detail("no HIP device");
         return PRL_ERR_NO_DEVICE;
     }
+    const int real = visible;
+    visible = std::max(visible, env_knobs().fake_devices);
     const int devs = std::min(n_pages, n_devices == 0 ? visible : std::min(n_devices, visible));
     const unsigned hw = std::thread::hardware_concurrency();
     const int copy_threads = std::max(1, std::min(env_knobs().host_copy_threads, hw ? (int)(hw / (unsigned)devs) : 1));
@@ -443,7 +447,7 @@ int prl_hip_chain_batch_host(const prl_chain_params* cp, int n_pages, int channe
         int first = 0, count = 0;
         prl_hip_page_range(n_pages, devs, d, &first, &count);
         workers.emplace_back([=, &status, &detail]() {
-            status[(size_t)d] = chain_worker(d, cp, channels, first, count, src, src_step, width, height, dst, dst_step, out_wh, angles,
+            status[(size_t)d] = chain_worker(d % real, cp, channels, first, count, src, src_step, width, height, dst, dst_step, out_wh, angles,
                                              max_w, max_h, copy_threads);
             if (status[(size_t)d] != PRL_OK) detail[(size_t)d] = prl_hip_last_error_detail();
         });

@@ -71,6 +71,7 @@ const EnvKnobs& env_knobs()
         k.ppht_prio = (int)geti("PRL_HIP_PPHT_PRIO", 3);
         k.chain_host_pages = (int)std::max(0ll, geti("PRL_HIP_CHAIN_HOST_PAGES", 0));
         k.chain_host_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_HOST_MB", 65536));
+        k.fake_devices = (int)std::max(0ll, geti("PRL_HIP_FAKE_DEVICES", 0));
         k.chain_overlap = (int)geti("PRL_HIP_CHAIN_OVERLAP", 1);
         k.chain_work_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_WORK_MB", 49152));
         k.host_chunk_mb = (size_t)std::max(1ll, geti("PRL_HIP_HOST_CHUNK_MB", 128));

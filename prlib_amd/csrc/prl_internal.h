@@ -97,6 +97,7 @@ struct EnvKnobs {
     size_t host_chunk_mb = 128;         // PRL_HIP_HOST_CHUNK_MB   pages staged per buffer of prl_hip_binarize_batch_host
     int chain_host_pages = 0;           // PRL_HIP_CHAIN_HOST_PAGES   pages per device chunk of prl_hip_chain_batch_host (0: from the budget)
     size_t chain_host_mb = 65536;       // PRL_HIP_CHAIN_HOST_MB      device memory for the page buffers of prl_hip_chain_batch_host
+    int fake_devices = 0;               // PRL_HIP_FAKE_DEVICES   (tests) logical devices of the *_batch_host entries, mapped onto the real ones
     int host_copy_threads = 8;          // PRL_HIP_HOST_COPY_THREADS  host threads per device copying pages in / out of pinned memory (bounded by cores / devices)
     unsigned segmax_cap = 1u << 20;     // PRL_HIP_SEGMAX_CAP   wavefronts per Wolf-Jolion call (tests shrink it)
     int literal_mode = 0;         // PRL_HIP_MODE=literal

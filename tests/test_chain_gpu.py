@@ -279,6 +279,42 @@ print("DONE")
             assert np.array_equal(z["p%d" % i], got[i]), i
 
 
+def test_host_entries_with_several_device_workers(prl, cuda_device, tmp_path):
+    """The *_batch_host entries start one worker thread per device, each on its block of the page list.  A one-GPU box has
+    one worker; PRL_HIP_FAKE_DEVICES=3 (child process) starts three, all on the real device: blocks of 3 + 2 + 2 (binarize)
+    and 2 + 2 + 1 (chain) pages, results in the caller's order and equal to the one-worker results."""
+    import subprocess
+    import sys
+    from prlib_amd import synth
+
+    gray = np.stack([synth.page_numpy(300, 520, index=70 + i) for i in range(7)])
+    col = np.stack([np.repeat(synth.text_page_numpy(150, 208, 95 + i, skew_deg=s, shading=0.3)[..., None], 3, axis=2)
+                    for i, s in enumerate((2.0, -1.0, 0.0, 3.0, -2.5))])
+    np.save(tmp_path / "gray.npy", gray)
+    np.save(tmp_path / "col.npy", col)
+    want_b = prl.binarize_pages_host(list(gray), prl.make_params(prl.NICK, 31, -0.1, 1), n_devices=1)
+    want_c, want_a = prl.process_pages_host(list(col), prl.SAUVOLA, 31, 0.34, 0, denoise_strength=10.0, thin=0, deskew=True,
+                                            background_normalization=True, n_devices=1)
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+import prlib_amd
+gray, col = np.load(%r), np.load(%r)
+b = prlib_amd.binarize_pages_host(list(gray), prlib_amd.make_params(prlib_amd.NICK, 31, -0.1, 1))
+c, a = prlib_amd.process_pages_host(list(col), prlib_amd.SAUVOLA, 31, 0.34, 0, denoise_strength=10.0, thin=0, deskew=True,
+                                    background_normalization=True)
+np.savez(%r, b=b, a=a, **{"c%%d" %% i: x for i, x in enumerate(c)})
+print("DONE")
+''' % (ROOT, str(tmp_path / "gray.npy"), str(tmp_path / "col.npy"), str(tmp_path / "out.npz"))
+    env = dict(os.environ, PRL_HIP_FAKE_DEVICES="3")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
+    z = np.load(tmp_path / "out.npz")
+    assert np.array_equal(z["b"], want_b) and np.array_equal(z["a"], want_a)
+    for i in range(len(col)):
+        assert np.array_equal(z["c%d" % i], want_c[i]), i
+
+
 def test_release_workspace_between_calls(prl, cuda_device):
     """prl_hip_release_workspace frees every cached buffer (stage area, angle-search workspace, host page buffers and pinned
     slots, per-stream workspaces); the next calls allocate again and give the same results."""
