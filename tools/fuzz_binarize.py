@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the binarizers against the CPU oracle (not part of the test suite: a confidence run).
+
+    python tools/fuzz_binarize.py --seconds 120 [--seed 1]
+
+Random method, window, k, morphology, page size, batch size, page content (document, noise, flat, saturated, binary, gradients,
+ties on the threshold) and exec mode; consecutive calls share the stream's workspace, so the self-cleaning state of small calls
+(StreamWs::clean_pages) sees every transition.  Prints one JSON line; exit code 1 on any mismatch."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import prlib_amd
+from prlib_amd import synth
+from oracle import capi as oc
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=120.0)
+ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+dev = torch.device("cuda:0")
+METHODS = [prlib_amd.SAUVOLA, prlib_amd.NIBLACK, prlib_amd.WOLFJOLION, prlib_amd.NICK, prlib_amd.FENG]
+
+
+def page(h, w, kind, i):
+    if kind == 0:
+        return synth.page_numpy(h, w, index=int(rng.integers(0, 1 << 20)))
+    if kind == 1:
+        return rng.integers(0, 256, (h, w), dtype=np.uint8)
+    if kind == 2:
+        return np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+    if kind == 3:
+        return (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+    if kind == 4:
+        g = np.add.outer(np.arange(h), np.arange(w)) * (255.0 / max(1, h + w - 2))
+        return np.clip(g + rng.normal(0, 2, (h, w)), 0, 255).astype(np.uint8)
+    p = synth.page_numpy(h, w, index=i)
+    p[rng.integers(0, h):, :] = 255 if rng.integers(0, 2) else 0     # saturated band
+    return p
+
+
+t_end = time.time() + a.seconds
+calls = pixels = bad_calls = 0
+first_bad = None
+stats = {"refined": 0, "exact": 0, "literal_pages": 0}
+while time.time() < t_end:
+    method = METHODS[int(rng.integers(0, 5))]
+    win = int(rng.choice([3, 5, 9, 15, 21, 31, 41, 63, 101])) if rng.random() < 0.9 else int(rng.integers(1, 60)) * 2 + 1
+    h = int(rng.integers(win + 2, 700)); w = int(rng.integers(win + 2, 1500))
+    n = int(rng.choice([1, 1, 2, 3, 5, 8]))
+    k = float(rng.choice([0.34, 0.2, -0.2, 0.01, -0.1, 0.5, 0.0])) if rng.random() < 0.8 else float(rng.normal(0, 0.4))
+    morph = int(rng.choice([0, 0, 0, 1, 2, -1, -2, 3]))
+    pages = np.stack([page(h, w, int(rng.integers(0, 6)), i) for i in range(n)])
+    mode = 1 if rng.random() < 0.05 else 0
+    p = prlib_amd.make_params(method, win, k, morph)
+    if mode:
+        prlib_amd.set_exec_mode(1)
+    try:
+        got = prlib_amd.binarize(torch.from_numpy(pages).to(dev), p).cpu().numpy()
+    finally:
+        if mode:
+            prlib_amd.set_exec_mode(0)
+    st = prlib_amd.last_stats()
+    stats["refined"] += int(st.refined_pixels); stats["exact"] += int(st.exact_pixels); stats["literal_pages"] += int(st.literal_pages)
+    po = oc.make_params(method, win, k, morph)
+    bad = sum(int((got[i] != oc.binarize(pages[i], po)).sum()) for i in range(n))
+    calls += 1
+    pixels += int(got.size)
+    if bad:
+        bad_calls += 1
+        first_bad = first_bad or {"method": int(method), "window": win, "k": k, "morph": morph, "shape": [n, h, w], "mode": mode, "bad": bad}
+print(json.dumps({"seconds": a.seconds, "seed": a.seed, "calls": calls, "Mpixels": round(pixels / 1e6, 1), "mismatching_calls": bad_calls,
+                  "first_mismatch": first_bad, **stats}))
+sys.exit(1 if bad_calls else 0)
