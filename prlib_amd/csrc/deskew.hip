@@ -414,6 +414,221 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
     if (lane == 0) a.n_lines[page] = n_lines;
 }
 
+// The same transform with THREE wavefronts per page (small batches: a single wavefront per page is bound by its own memory
+// round trips - 0.7 s for an A4 page whatever the batch size up to ~64 pages - while the chip idles).  Wavefront v, lane l
+// owns angle 64 v + l: a point's 180 votes are one instruction per wavefront, a block's votes are all in flight at once, and
+// un-votes and roll-backs split three ways.  Everything that decides the visiting order (cv::RNG, the list swaps, the masks)
+// is computed by all three wavefronts identically; what WRITES shared state is done by wavefront 0 alone (list stores, mask
+// clearing, the segment list) and handed on through LDS / a barrier: the per-point maxima (keys, double-buffered), the set
+// pixels of the clearing walk (one ballot per 64 steps).  Results are identical to k_ppht's by construction and by
+// tests/test_deskew_gpu.py, which runs its cases through both kernels (PRL_HIP_PPHT_MW=0 in a child process).
+constexpr int kMwWaves = 3;
+#ifndef PRL_PPHT_BLK_MW
+#define PRL_PPHT_BLK_MW 32
+#endif
+constexpr int kBlkMw = PRL_PPHT_BLK_MW;
+constexpr int kPphtMwMaxPages = 1 << 30;   // never slower than one wavefront per page (1 .. 512 pages measured: DESIGN.md 4.10)
+constexpr int kMwMaxGroups = 2 * (32768 / 64 + 2);
+__global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
+{
+    __shared__ int s_keys[2][kMwWaves][kBlkMw];
+    __shared__ unsigned long long s_ballot[kMwMaxGroups];
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    const int page = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int W = a.width, H = a.height, numrho = a.numrho;
+    volatile uint8_t* mask = a.mask + (size_t)page * a.mask_page;
+    volatile unsigned* nz = a.nz + a.nz_off[page];
+    int* accum = a.accum + (size_t)page * kNumAngle * numrho;
+    int* lines = a.lines + a.lines_off[page] * 4;
+    const unsigned cap = a.lines_cap[page];
+    const int ang = wv * 64 + lane;
+    const bool has = ang < kNumAngle;
+    const int angc = min(ang, kNumAngle - 1);
+    const float tc = a.ttab[2 * angc], ts = a.ttab[2 * angc + 1];
+    int* arow = accum + (size_t)angc * numrho + (numrho - 1) / 2;
+    unsigned long long rng = ~0ull;
+    unsigned n_lines = 0;
+    const unsigned N = a.count[page];
+    int kbuf = 0;
+
+    auto process_line = [&](int j, int i, int max_n) {
+        const float fa = -a.ttab[2 * max_n + 1], fb = a.ttab[2 * max_n];
+        unsigned x0 = (unsigned)j, y0 = (unsigned)i;
+        int dx0, dy0, xflag;
+        if (fabs((double)fa) > fabs((double)fb)) {
+            xflag = 1;
+            dx0 = fa > 0 ? 1 : -1;
+            dy0 = __double2int_rn((double)(fb * 65536.f) / fabs((double)fa));
+            y0 = (y0 << 16) + (1u << 15);
+        } else {
+            xflag = 0;
+            dy0 = fb > 0 ? 1 : -1;
+            dx0 = __double2int_rn((double)(fa * 65536.f) / fabs((double)fb));
+            x0 = (x0 << 16) + (1u << 15);
+        }
+        // first walk (read only): every wavefront for itself, the results are identical
+        unsigned end_step[2];
+        for (int k = 0; k < 2; ++k) {
+            const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+            unsigned endk = 0;
+            int gap = 0;
+            bool stop = false;
+            for (unsigned base = 0; !stop; base += 64) {
+                int j1, i1;
+                step_pixel(xflag, x0, y0, dx, dy, base + lane, &j1, &i1);
+                const bool inb = j1 >= 0 && j1 < W && i1 >= 0 && i1 < H;
+                const bool set = inb && mask[(size_t)i1 * W + j1] != 0;
+                const unsigned long long oob = __ballot(!inb);
+                unsigned long long nzb = __ballot(set);
+                const int limit = oob ? __ffsll((long long)oob) - 1 : 64;
+                int prev = -1 - gap;
+                while (nzb) {
+                    const int q = __ffsll((long long)nzb) - 1;
+                    nzb &= nzb - 1;
+                    if (q >= limit || q - prev - 1 > a.line_gap) { stop = true; break; }
+                    endk = base + (unsigned)q;
+                    prev = q;
+                }
+                if (!stop) {
+                    if (limit - 1 - prev > a.line_gap || limit < 64) stop = true;
+                    else gap = 63 - prev;
+                }
+            }
+            end_step[k] = endk;
+        }
+        int ex[2], ey[2];
+        step_pixel(xflag, x0, y0, dx0, dy0, end_step[0], &ex[0], &ey[0]);
+        step_pixel(xflag, x0, y0, -dx0, -dy0, end_step[1], &ex[1], &ey[1]);
+        const bool good_line = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
+        __syncthreads();  // nobody clears a pixel before everybody has finished the read-only walk
+        // second walk: wavefront 0 clears the set pixels and publishes which ones they were
+        if (wv == 0) {
+            int gidx = 0;
+            for (int k = 0; k < 2; ++k) {
+                const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+                for (unsigned base = (unsigned)k; base <= end_step[k]; base += 64, ++gidx) {  // (step 0 was cleared by k = 0)
+                    const unsigned st = base + lane;
+                    int j1, i1;
+                    step_pixel(xflag, x0, y0, dx, dy, st, &j1, &i1);
+                    bool set = false;
+                    if (st <= end_step[k]) {
+                        set = mask[(size_t)i1 * W + j1] != 0;
+                        if (set) mask[(size_t)i1 * W + j1] = 0;
+                    }
+                    const unsigned long long nzb = __ballot(set);
+                    if (lane == 0) s_ballot[gidx] = nzb;
+                }
+            }
+        }
+        __syncthreads();
+        if (good_line) {  // a good line takes the votes of its pixels back: every wavefront its own angles
+            int gidx = 0;
+            for (int k = 0; k < 2; ++k) {
+                const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
+                for (unsigned base = (unsigned)k; base <= end_step[k]; base += 64, ++gidx) {
+                    unsigned long long nzb = s_ballot[gidx];
+                    while (nzb) {
+                        const int q = __ffsll((long long)nzb) - 1;
+                        nzb &= nzb - 1;
+                        int jq, iq;
+                        step_pixel(xflag, x0, y0, dx, dy, base + (unsigned)q, &jq, &iq);
+                        if (has) vote(arow + cv_round_f((float)jq * tc + (float)iq * ts), -1);
+                    }
+                }
+            }
+            if (wv == 0 && lane == 0 && n_lines < cap) {
+                lines[4 * n_lines] = ex[0];
+                lines[4 * n_lines + 1] = ey[0];
+                lines[4 * n_lines + 2] = ex[1];
+                lines[4 * n_lines + 3] = ey[1];
+            }
+            ++n_lines;
+        }
+        __syncthreads();  // s_ballot is free again; the cleared pixels are visible to everybody's next mask reads
+    };
+
+    for (unsigned t0 = 0; t0 < N; t0 += kBlkMw) {
+        const unsigned nb = min((unsigned)kBlkMw, N - t0), c0 = N - t0;
+        unsigned rv = 0;
+        for (unsigned L = 0; L < nb; ++L) {
+            rng = (unsigned long long)(unsigned)rng * 4164903690ull + (rng >> 32);
+            if ((unsigned)lane == L) rv = (unsigned)rng;
+        }
+        const bool act = (unsigned)lane < nb;
+        const unsigned cnt_l = act ? c0 - (unsigned)lane : 1u;
+        const unsigned idx = rv % cnt_l, lastpos = cnt_l - 1u;
+        unsigned rp = 0, rl = 0;
+        if (act) {
+            rp = nz[idx];
+            rl = nz[lastpos];
+        }
+        unsigned long long skip = 0;
+        for (unsigned st = 0; st + 1 < nb; ++st) {
+            const unsigned is = (unsigned)__builtin_amdgcn_readlane((int)idx, (int)st);
+            const unsigned ls = (unsigned)__builtin_amdgcn_readlane((int)rl, (int)st);
+            const bool later = act && (unsigned)lane > st;
+            const bool c1 = later && idx == is, c2 = later && lastpos == is;
+            if (c1) rp = ls;
+            if (c2) rl = ls;
+            if (__ballot(c1)) skip |= 1ull << st;
+        }
+        __syncthreads();  // every wavefront has read this block's list entries before the list moves on.  All three store the
+        // same values: a wavefront's own store then orders its own reads of the next block (a block without a live point has
+        // no further barrier)
+        if (act && !((skip >> lane) & 1ull)) nz[idx] = rl;
+        const unsigned pt = rp;
+
+        unsigned start = 0;
+        while (start < nb) {
+            unsigned m = 0;
+            if (act && (unsigned)lane >= start) m = mask[(size_t)(pt >> 16) * W + (pt & 0xffffu)];
+            const unsigned long long vm = __ballot(m != 0);
+            if (!vm) break;
+            int v[kBlkMw];
+#pragma unroll
+            for (int p = 0; p < kBlkMw; ++p) {
+                if ((vm >> p) & 1ull) {
+                    const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)pt, p);
+                    const float fj = (float)(q & 0xffffu), fi = (float)(q >> 16);
+                    if (has) v[p] = vote(arow + cv_round_f(fj * tc + fi * ts), 1);
+                }
+            }
+            // this wavefront's maximum per point into lane p, then the three of them through LDS
+            int mine = INT_MIN;
+#pragma unroll
+            for (int p = 0; p < kBlkMw; ++p) {
+                if ((vm >> p) & 1ull) {
+                    const int key = wave_max_i32(has ? (v[p] + 1) * 256 + (255 - ang) : INT_MIN);
+                    if (lane == p) mine = key;
+                }
+            }
+            if (lane < kBlkMw) s_keys[kbuf][wv][lane] = mine;
+            __syncthreads();
+            int kk = INT_MIN;
+            if (lane < kBlkMw) {
+#pragma unroll
+                for (int u = 0; u < kMwWaves; ++u) kk = max(kk, s_keys[kbuf][u][lane]);
+            }
+            kbuf ^= 1;
+            const unsigned long long tb = __ballot(lane < kBlkMw && ((vm >> lane) & 1ull) && (kk >> 8) >= a.threshold);
+            if (!tb) break;  // every vote of the block stands
+            const int trig = __ffsll((long long)tb) - 1;
+            const int trig_n = 255 - (__builtin_amdgcn_readlane(kk, trig) & 255);
+            for (unsigned p = (unsigned)trig + 1; p < nb; ++p) {
+                if ((vm >> p) & 1ull) {
+                    const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)pt, (int)p);
+                    const float fj = (float)(q & 0xffffu), fi = (float)(q >> 16);
+                    if (has) vote(arow + cv_round_f(fj * tc + fi * ts), -1);
+                }
+            }
+            const unsigned tq = (unsigned)__builtin_amdgcn_readlane((int)pt, trig);
+            process_line((int)(tq & 0xffffu), (int)(tq >> 16), trig_n);
+            start = (unsigned)trig + 1;
+        }
+    }
+    if (wv == 0 && lane == 0) a.n_lines[page] = n_lines;
+}
+
 // ---- rotate --------------------------------------------------------------------------------------------------------
 
 struct WarpPage {
@@ -741,7 +956,10 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     a.mask = d_mask; a.mask_page = mask_page; a.nz = d_nz; a.nz_off = d_nzoff; a.count = d_count; a.accum = d_accum; a.ttab = d_ttab;
     a.lines = d_lines; a.lines_off = d_lnoff; a.lines_cap = d_cap; a.n_lines = d_nlines;
     a.prio = env_knobs().ppht_prio;
-    hipLaunchKernelGGL(k_ppht, dim3((unsigned)n_pages), dim3(64), 0, stream, a);
+    // three wavefronts per page (shorter critical path per page; equal to one per page once the memory system is the limit)
+    const int mw_env = env_knobs().ppht_mw;
+    if (mw_env == 1 || (mw_env < 0 && n_pages <= kPphtMwMaxPages)) hipLaunchKernelGGL(k_ppht_mw, dim3((unsigned)n_pages), dim3(64 * kMwWaves), 0, stream, a);
+    else hipLaunchKernelGGL(k_ppht, dim3((unsigned)n_pages), dim3(64), 0, stream, a);
 
     PRL_HIP_CHECK(hipGetLastError());
     std::vector<unsigned> h_nl((size_t)n_pages);

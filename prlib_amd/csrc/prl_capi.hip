@@ -68,6 +68,7 @@ const EnvKnobs& env_knobs()
         k.nlm_glut = (int)geti("PRL_NLM_GLUT", 0);
         k.literal_scratch_mb = (size_t)std::max(64ll, geti("PRL_HIP_LITERAL_SCRATCH_MB", 8192));
         k.deskew_work_mb = (size_t)std::max(1ll, geti("PRL_HIP_DESKEW_WORK_MB", 24576));
+        k.ppht_mw = (int)geti("PRL_HIP_PPHT_MW", -1);
         k.ppht_prio = (int)geti("PRL_HIP_PPHT_PRIO", 3);
         k.chain_host_pages = (int)std::max(0ll, geti("PRL_HIP_CHAIN_HOST_PAGES", 0));
         k.chain_host_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_HOST_MB", 65536));

@@ -91,6 +91,7 @@ struct EnvKnobs {
     int nlm_glut = 0;             // PRL_NLM_GLUT   bit 0 / 1: L / ab plane read the weight table from memory instead of LDS
     size_t literal_scratch_mb = 8192;   // PRL_HIP_LITERAL_SCRATCH_MB
     size_t deskew_work_mb = 24576;      // PRL_HIP_DESKEW_WORK_MB
+    int ppht_mw = -1;                   // PRL_HIP_PPHT_MW   1 / 0: always / never three wavefronts per page (default: by batch size)
     int ppht_prio = 3;                  // PRL_HIP_PPHT_PRIO=0   k_ppht does not raise its wavefront priority
     int chain_overlap = 1;              // PRL_HIP_CHAIN_OVERLAP=0   angle search of the next pass not overlapped with this one
     size_t chain_work_mb = 49152;       // PRL_HIP_CHAIN_WORK_MB

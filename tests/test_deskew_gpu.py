@@ -77,6 +77,37 @@ def test_deskew_matches_oracle(prl, oracle, cuda_device, c):
     assert angles[-1] == 0.0 and outs[-1].shape[:2] == (390, 300)
 
 
+def test_single_wavefront_kernel_gives_the_same_segments():
+    """k_ppht (one wavefront per page, PRL_HIP_PPHT_MW=0: read once per process, hence the child) against the oracle on the
+    cases above; the default is k_ppht_mw (three wavefronts per page)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import prlib_amd
+from prlib_amd import synth
+from oracle import capi as oc
+bad = 0
+img = np.zeros((200, 300), np.uint8); img[50, 20:280] = 255; img[20:190, 150] = 255
+rng = np.random.default_rng(1); img[rng.integers(0, 200, 900), rng.integers(0, 300, 900)] = 128
+for thr, ll, gap in ((100, 100, 5), (60, 40, 3)):
+    bad += not np.array_equal(prlib_amd.houghp(torch.from_numpy(img).cuda(), thr, ll, gap), oc.houghp(img, thr, ll, gap))
+pages = np.stack([synth.text_page_numpy(390, 300, 20 + i, skew_deg=s, shading=0.2) for i, s in enumerate((2.5, -4.0, 0.0, 1.0))])
+outs, angles = prlib_amd.deskew(torch.from_numpy(pages).cuda())
+for i in range(len(pages)):
+    want, info = oc.deskew(pages[i])
+    bad += angles[i] != info["angle"] or not np.array_equal(outs[i].cpu().numpy(), want)
+print("BAD", bad)
+''' % root
+    env = dict(os.environ, PRL_HIP_PPHT_MW="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "BAD 0" in r.stdout, r.stdout + r.stderr
+
+
 def test_deskew_argument_errors(prl, cuda_device):
     import torch
 
