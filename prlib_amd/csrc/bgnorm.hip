@@ -14,8 +14,8 @@
 //   k_bg_maps       per (page, channel), one workgroup: pixFillMapHoles (column fill, column replication, last column),
 //                   pixBlockconv(2, 1) with blockconvLow's edge rule and float32 rescaling, 16-bit inverse map.  The maps
 //                   are tiny (248 x 234 for A4) and live in L2.
-//   k_bg_apply<CH>  out = min(255, p * inv[y/15][x/10] >> 8), 4 pixels per thread; a page whose map could not be made is
-//                   copied (Leptonica returns a copy of the source).  HBM-bound: 1 B read + 1 B written per channel byte.
+//   k_bg_apply<CH>  out = min(255, p * inv[y/15][x/10] >> 8), 16 pixels per thread; a page whose map could not be made is
+//                   copied (Leptonica returns a copy of the source).  1 B read + 1 B written per channel byte.
 // Integer throughout except blockconvLow's float32 factors (one rounding per operation, -ffp-contract=off): bit-exact
 // against the oracle.
 #include <algorithm>
@@ -223,53 +223,60 @@ __global__ void __launch_bounds__(256) k_bg_maps(BgGeom g, int och, uint8_t* __r
     }
 }
 
+// out = min(255, p * inv[y / 15][x / 10] >> 8).  One thread per group of 16 pixels, groups numbered row after row (no
+// workgroup is left mostly empty at the end of every row).  A group touches at most three map columns (16 pixels, 10 per tile):
+// their multipliers are fetched once and picked per pixel by two comparisons; bytes are unpacked from and packed into dwords at
+// compile-time positions.  (First version: 4 pixels per thread with a map fetch and an integer division per pixel - 26 vector
+// instructions per pixel, profiles/r02/pmc_stages.txt.)  A page whose map could not be made is copied: multiplier 256.
+template <int CH>
+struct ApplyGeo { static constexpr int APX = CH == 1 ? 16 : 8; };   // pixels per thread (3 / 4 channels: 8 measured better than 16)
 template <int CH>
 __global__ void __launch_bounds__(256) k_bg_apply(PageSet src, PageSetOut dst, BgGeom g, const unsigned short* __restrict__ inv,
                                                   const int* __restrict__ page_fail)
 {
-    constexpr int OCH = CH == 1 ? 1 : 3;
-    // one thread per group of 4 pixels, groups numbered row after row (a row of 2480 pixels is 2.4 workgroups: no
-    // workgroup is left two thirds empty at the end of every row, as with one grid row per page row)
+    constexpr int OCH = CH == 1 ? 1 : 3, APX = ApplyGeo<CH>::APX;
     const int page = blockIdx.y;
-    const unsigned groups = (unsigned)(g.width + 3) / 4u;
+    const unsigned groups = (unsigned)(g.width + APX - 1) / (unsigned)APX;
     const unsigned gi = blockIdx.x * 256u + threadIdx.x;
     const int y = (int)(gi / groups);
     if (y >= g.height) return;
-    const int x0 = (int)(gi - (unsigned)y * groups) * 4;
-    const int n = min(4, g.width - x0);
+    const int x0 = (int)(gi - (unsigned)y * groups) * APX;
+    const int n = min(APX, g.width - x0);
     const uint8_t* s = src.page(page) + (size_t)y * src.step + (size_t)x0 * CH;
     uint8_t* d = dst.page(page) + (size_t)y * dst.step + (size_t)x0 * OCH;
     const bool fail = page_fail[page] != 0;
     const unsigned short* iv = inv + (size_t)page * g.inv_page + (size_t)(y / SY) * g.mw;
     const size_t plane = (size_t)g.mw * g.mh;
-    unsigned in[4 * CH], out[4 * OCH];
-    if (n == 4 && (((size_t)s) & 3) == 0) {
-        const unsigned* q = reinterpret_cast<const unsigned*>(s);
+    const int tx0 = x0 / SX, rem0 = x0 - tx0 * SX;
+    unsigned m[OCH][3];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const unsigned wv = q[i];
-            in[4 * i] = wv & 0xff; in[4 * i + 1] = (wv >> 8) & 0xff; in[4 * i + 2] = (wv >> 16) & 0xff; in[4 * i + 3] = wv >> 24;
+    for (int c = 0; c < OCH; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) m[c][k] = fail ? 256u : (unsigned)iv[(size_t)c * plane + min(tx0 + k, g.mw - 1)];
+    if (n == APX) {
+        unsigned in[APX * CH / 4], out[APX * OCH / 4];
+#pragma unroll
+        for (int i = 0; i < APX * CH / 4; ++i) __builtin_memcpy(&in[i], s + 4 * i, 4);   // (any alignment)
+#pragma unroll
+        for (int i = 0; i < APX * OCH / 4; ++i) out[i] = 0;
+#pragma unroll
+        for (int px = 0; px < APX; ++px) {
+            const int sel = rem0 + px;   // 0 .. 24: map column tx0 + sel / 10
+#pragma unroll
+            for (int c = 0; c < OCH; ++c) {
+                const unsigned mm = sel < SX ? m[c][0] : (sel < 2 * SX ? m[c][1] : m[c][2]);
+                const int bi = px * CH + c, bo = px * OCH + c;
+                const unsigned p = (in[bi / 4] >> (8 * (bi % 4))) & 0xffu;
+                out[bo / 4] |= min(255u, (p * mm) >> 8) << (8 * (bo % 4));
+            }
         }
+#pragma unroll
+        for (int i = 0; i < APX * OCH / 4; ++i) __builtin_memcpy(d + 4 * i, &out[i], 4);
     } else {
-        for (int i = 0; i < 4 * CH; ++i) in[i] = i < n * CH ? s[i] : 0;
-    }
-#pragma unroll
-    for (int px = 0; px < 4; ++px) {
-        const int tx = (x0 + px) / SX;
-#pragma unroll
-        for (int c = 0; c < OCH; ++c) {
-            const unsigned p = in[px * CH + c];
-            unsigned v = p;
-            if (!fail && px < n) v = min(255u, (p * (unsigned)iv[(size_t)c * plane + tx]) >> 8);
-            out[px * OCH + c] = v;
+        for (int px = 0; px < n; ++px) {
+            const int k = (rem0 + px) / SX;
+            for (int c = 0; c < OCH; ++c) d[px * OCH + c] = (uint8_t)min(255u, ((unsigned)s[px * CH + c] * m[c][k]) >> 8);
         }
-    }
-    if (n == 4 && (((size_t)d) & 3) == 0) {
-        unsigned* q = reinterpret_cast<unsigned*>(d);
-#pragma unroll
-        for (int i = 0; i < OCH; ++i) q[i] = out[4 * i] | (out[4 * i + 1] << 8) | (out[4 * i + 2] << 16) | (out[4 * i + 3] << 24);
-    } else {
-        for (int i = 0; i < n * OCH; ++i) d[i] = (uint8_t)out[i];
     }
 }
 
@@ -317,7 +324,8 @@ int bgnorm_run(int n_pages, int channels, const PageSet& src, int width, int hei
     }
     hipLaunchKernelGGL(k_bg_maps, dim3((unsigned)och, (unsigned)n_pages), dim3(256), 0, stream, g, och, maps, inv, fail);
     PRL_HIP_CHECK(hipGetLastError());
-    const dim3 agrid((unsigned)(((size_t)((width + 3) / 4) * height + 255) / 256), (unsigned)n_pages);
+    const int apx = channels == 1 ? ApplyGeo<1>::APX : ApplyGeo<3>::APX;
+    const dim3 agrid((unsigned)(((size_t)((width + apx - 1) / apx) * height + 255) / 256), (unsigned)n_pages);
     if (channels == 1) hipLaunchKernelGGL(k_bg_apply<1>, agrid, dim3(256), 0, stream, src, dst, g, inv, fail);
     else if (channels == 3) hipLaunchKernelGGL(k_bg_apply<3>, agrid, dim3(256), 0, stream, src, dst, g, inv, fail);
     else hipLaunchKernelGGL(k_bg_apply<4>, agrid, dim3(256), 0, stream, src, dst, g, inv, fail);
