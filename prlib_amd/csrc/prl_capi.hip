@@ -73,6 +73,8 @@ const EnvKnobs& env_knobs()
         k.chain_host_pages = (int)std::max(0ll, geti("PRL_HIP_CHAIN_HOST_PAGES", 0));
         k.chain_host_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_HOST_MB", 65536));
         k.fake_devices = (int)std::max(0ll, geti("PRL_HIP_FAKE_DEVICES", 0));
+        k.chain_pass = (int)std::max(0ll, geti("PRL_HIP_CHAIN_PASS", 0));
+        k.chain_first_pass = (int)std::max(0ll, geti("PRL_HIP_CHAIN_FIRST_PASS", 0));
         k.chain_overlap = (int)geti("PRL_HIP_CHAIN_OVERLAP", 1);
         k.chain_work_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_WORK_MB", 49152));
         k.host_chunk_mb = (size_t)std::max(1ll, geti("PRL_HIP_HOST_CHUNK_MB", 128));

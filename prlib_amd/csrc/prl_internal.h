@@ -93,6 +93,7 @@ struct EnvKnobs {
     size_t deskew_work_mb = 24576;      // PRL_HIP_DESKEW_WORK_MB
     int ppht_mw = -1;                   // PRL_HIP_PPHT_MW   1 / 0: always / never three wavefronts per page (default: by batch size)
     int ppht_prio = 3;                  // PRL_HIP_PPHT_PRIO=0   k_ppht does not raise its wavefront priority
+    int chain_pass = 0, chain_first_pass = 0;   // PRL_HIP_CHAIN_PASS / PRL_HIP_CHAIN_FIRST_PASS   pages per pass of the chain with deskew (0: 256 / 64)
     int chain_overlap = 1;              // PRL_HIP_CHAIN_OVERLAP=0   angle search of the next pass not overlapped with this one
     size_t chain_work_mb = 49152;       // PRL_HIP_CHAIN_WORK_MB
     size_t host_chunk_mb = 128;         // PRL_HIP_HOST_CHUNK_MB   pages staged per buffer of prl_hip_binarize_batch_host
