@@ -378,8 +378,29 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
     int chunk = 0;
     st = chain_pass_layout(cp, n_pages, channels, width, height, &chunk, &per_page, &desk_page);
     if (st != PRL_OK) return st;
+    // Pass schedule.  The angle search of the FIRST pass has nothing to hide behind, so with deskew the first pass is small
+    // (its search costs about what a single page costs), the following ones are as large as the search needs to run at its
+    // full rate (256 pages; larger passes only lengthen the last pass's exposed tail), the rest is the last pass.
+    std::vector<int> pass_first, pass_cnt;
+    {
+        int first_sz = chunk, main_sz = chunk;
+        if (cp->deskew && env_knobs().chain_overlap) {
+            const int want_main = env_knobs().chain_pass > 0 ? env_knobs().chain_pass : 256;
+            const int want_first = env_knobs().chain_first_pass > 0 ? env_knobs().chain_first_pass : 64;
+            main_sz = std::min(chunk, want_main);
+            first_sz = n_pages >= 3 * want_first ? std::min(main_sz, want_first) : main_sz;
+        }
+        for (int first = 0; first < n_pages;) {
+            int cnt = std::min(first == 0 ? first_sz : main_sz, n_pages - first);
+            if (n_pages - first - cnt > 0 && n_pages - first - cnt < main_sz / 8 && n_pages - first <= chunk) cnt = n_pages - first;  // no tiny last pass
+            pass_first.push_back(first);
+            pass_cnt.push_back(cnt);
+            first += cnt;
+        }
+    }
+    const int max_cnt = *std::max_element(pass_cnt.begin(), pass_cnt.end());
     if (per_page) {
-        st = ensure_stage(ctx, per_page * (size_t)chunk);
+        st = ensure_stage(ctx, per_page * (size_t)max_cnt);
         if (st != PRL_OK) return st;
     }
     hipStream_t hs = static_cast<hipStream_t>(stream);
@@ -401,26 +422,6 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
         void join() { if (th.joinable()) th.join(); }
         ~Finder() { join(); }
     } finder;
-    // Pass schedule.  The angle search of the FIRST pass has nothing to hide behind, so with deskew the first pass is small
-    // (its search costs about what a single page costs), the following ones are as large as the search needs to run at its
-    // full rate (256 pages; larger passes only lengthen the last pass's exposed tail), the rest is the last pass.
-    std::vector<int> pass_first, pass_cnt;
-    {
-        int first_sz = chunk, main_sz = chunk;
-        if (cp->deskew && env_knobs().chain_overlap) {
-            const int want_main = env_knobs().chain_pass > 0 ? env_knobs().chain_pass : 256;
-            const int want_first = env_knobs().chain_first_pass > 0 ? env_knobs().chain_first_pass : 64;
-            main_sz = std::min(chunk, want_main);
-            first_sz = n_pages >= 3 * want_first ? std::min(main_sz, want_first) : main_sz;
-        }
-        for (int first = 0; first < n_pages;) {
-            int cnt = std::min(first == 0 ? first_sz : main_sz, n_pages - first);
-            if (n_pages - first - cnt > 0 && n_pages - first - cnt < main_sz / 8 && n_pages - first <= chunk) cnt = n_pages - first;  // no tiny last pass
-            pass_first.push_back(first);
-            pass_cnt.push_back(cnt);
-            first += cnt;
-        }
-    }
     auto cnt_at = [&](int first) { return pass_cnt[(size_t)(std::lower_bound(pass_first.begin(), pass_first.end(), first) - pass_first.begin())]; };
     auto start_find = [&](int first) {
         const int cnt = cnt_at(first);
@@ -443,7 +444,7 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
         PRL_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
         start_find(0);
     }
-    std::vector<int32_t> wh((size_t)chunk * 2);
+    std::vector<int32_t> wh((size_t)max_cnt * 2);
     DeskewPlan plan;
     for (size_t pi = 0; pi < pass_first.size(); ++pi) {
         const int first = pass_first[pi], cnt = pass_cnt[pi];
