@@ -265,25 +265,44 @@ ChainLayout chain_layout(const prl_chain_params* cp, int channels, int width, in
     return l;
 }
 
-// the stages after deskew on `cnt` pages of one size; ws: cnt * layout.total bytes
-int chain_uniform(const prl_chain_params* cp, int cnt, int channels, const uint8_t* src, size_t src_ps, size_t src_step, int width,
-                  int height, uint8_t* out, size_t dst_ps, size_t dst_step, uint8_t* ws, void* stream)
+// The stages after deskew on `cnt` pages of one size; ws: cnt * layout.total bytes.  Two halves: chain_uniform_a is the
+// denoise stage (NL-means: compute), chain_uniform_b the streaming stages that follow; the chain may run all first halves of
+// a pass before its second halves (see the pass loop).  RunState: where the pages stand after the first half.
+struct RunState {
+    const uint8_t* cur;
+    size_t cur_ps, cur_step;
+    uint8_t* w;
+};
+
+int chain_uniform_a(const prl_chain_params* cp, int cnt, int channels, const uint8_t* src, size_t src_ps, size_t src_step, int width,
+                    int height, uint8_t* ws, void* stream, RunState* rs)
 {
     prl_binarize_geometry g;
     int st = prl_hip_binarize_geometry(&cp->binarize, width, height, &g);
     if (st != PRL_OK) return st;
     const ChainLayout l = chain_layout(cp, channels, width, height, g);
-    const uint8_t* cur = src;
-    size_t cur_ps = src_ps, cur_step = src_step;
-    int ch = channels;
-    uint8_t* w = ws;
+    rs->cur = src; rs->cur_ps = src_ps; rs->cur_step = src_step; rs->w = ws;
     if (cp->denoise) {
-        st = prl_hip_denoise_batch_device(cnt, ch, cp->denoise_strength, cur, cur_ps, cur_step, width, height, w, l.denoised,
-                                          (size_t)width * ch, stream);
+        st = prl_hip_denoise_batch_device(cnt, channels, cp->denoise_strength, src, src_ps, src_step, width, height, ws, l.denoised,
+                                          (size_t)width * channels, stream);
         if (st != PRL_OK) return st;
-        cur = w; cur_ps = l.denoised; cur_step = (size_t)width * ch;
-        w += l.denoised * (size_t)cnt;
+        rs->cur = ws; rs->cur_ps = l.denoised; rs->cur_step = (size_t)width * channels;
+        rs->w = ws + l.denoised * (size_t)cnt;
     }
+    return PRL_OK;
+}
+
+int chain_uniform_b(const prl_chain_params* cp, int cnt, int channels, const RunState& rs, int width, int height, uint8_t* out,
+                    size_t dst_ps, size_t dst_step, void* stream)
+{
+    prl_binarize_geometry g;
+    int st = prl_hip_binarize_geometry(&cp->binarize, width, height, &g);
+    if (st != PRL_OK) return st;
+    const ChainLayout l = chain_layout(cp, channels, width, height, g);
+    const uint8_t* cur = rs.cur;
+    size_t cur_ps = rs.cur_ps, cur_step = rs.cur_step;
+    int ch = channels;
+    uint8_t* w = rs.w;
     if (cp->background_normalization) {
         const int och = prl_hip_bgnorm_out_channels(ch);
         st = prl_hip_bgnorm_batch_device(cnt, ch, cur, cur_ps, cur_step, width, height, w, l.normalised, (size_t)width * och, stream);
@@ -464,7 +483,13 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
             plan = std::move(finder.plan);
             finder.plan = DeskewPlan();
             const bool overlap = env_knobs().chain_overlap != 0;
-            if (overlap && first + cnt < n_pages) start_find(first + cnt);
+            const bool later = env_knobs().chain_overlap == 2 && cp->denoise;   // split mode starts it after the streaming head of the pass
+            if (overlap && !later && first + cnt < n_pages) {
+                start_find(first + cnt);
+                // the first part of a search (every point still votes) saturates the memory system and everything beside it
+                // crawls; this pass's own work fits into the rest of the search, so it can start a little later
+                if (env_knobs().chain_lag_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(env_knobs().chain_lag_ms));
+            }
             uint8_t* desk = ws;
             ws = desk + desk_page * (size_t)cnt;
             st = deskew_apply(ctx, plan, cnt, channels, cur, cur_ps, cur_step, width, height, desk, desk_page, (size_t)len * channels, hs);
@@ -476,21 +501,84 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
             for (int i = 0; i < cnt; ++i) { wh[2 * (size_t)i] = width; wh[2 * (size_t)i + 1] = height; }
             if (angles) for (int i = 0; i < cnt; ++i) angles[first + i] = 0.0;
         }
-        for (int r0 = 0; r0 < cnt;) {  // runs of equal page size
-            int r1 = r0 + 1;
-            while (r1 < cnt && wh[2 * (size_t)r1] == wh[2 * (size_t)r0] && wh[2 * (size_t)r1 + 1] == wh[2 * (size_t)r0 + 1]) ++r1;
-            const int pw = wh[2 * (size_t)r0], ph = wh[2 * (size_t)r0 + 1];
-            prl_binarize_geometry g;
-            st = prl_hip_binarize_geometry(&cp->binarize, pw, ph, &g);
-            if (st != PRL_OK) return st;
-            st = chain_uniform(cp, r1 - r0, channels, cur + (size_t)r0 * cur_ps, cur_ps, cur_step, pw, ph,
-                               d_dst + (size_t)(first + r0) * dst_page_stride, dst_page_stride, dst_step, ws, stream);
-            if (st != PRL_OK) return st;
-            for (int i = r0; i < r1; ++i) {
-                out_wh[2 * (size_t)(first + i)] = g.out_w;
-                out_wh[2 * (size_t)(first + i) + 1] = g.out_h;
+        // runs of equal page size, each with its own slice of the workspace
+        struct Run { int r0, r1, pw, ph; RunState rs; uint8_t* ws; uint8_t* planes; };
+        std::vector<Run> runs;
+        // chain_overlap == 2 (with deskew and denoise): a pass is cut in three.  HEAD - rotation and BGR->Lab, streaming kernels -
+        // runs before the search of the next pass is started; BODY - the NL-means kernels, compute - beside that search;
+        // TAIL - Lab->BGR and the stages after denoise, streaming again - after it.  Streaming kernels get a fraction of their
+        // bandwidth while a search's atomics are in flight (16-50x their time in its first second) and hold up whatever is
+        // queued behind them, and a search that starts beside them is slowed for good.
+        const bool split = cp->deskew && cp->denoise && env_knobs().chain_overlap == 2;
+        size_t planes_need = 0;
+        {
+            uint8_t* wsr = ws;
+            for (int r0 = 0; r0 < cnt;) {
+                int r1 = r0 + 1;
+                while (r1 < cnt && wh[2 * (size_t)r1] == wh[2 * (size_t)r0] && wh[2 * (size_t)r1 + 1] == wh[2 * (size_t)r0 + 1]) ++r1;
+                Run run{r0, r1, wh[2 * (size_t)r0], wh[2 * (size_t)r0 + 1], {}, wsr, nullptr};
+                prl_binarize_geometry g;
+                st = prl_hip_binarize_geometry(&cp->binarize, run.pw, run.ph, &g);
+                if (st != PRL_OK) return st;
+                wsr += chain_layout(cp, channels, run.pw, run.ph, g).total * (size_t)(r1 - r0);
+                planes_need += denoise_plane_bytes(run.pw, run.ph) * (size_t)(r1 - r0);
+                for (int i = r0; i < r1; ++i) {
+                    out_wh[2 * (size_t)(first + i)] = g.out_w;
+                    out_wh[2 * (size_t)(first + i) + 1] = g.out_h;
+                }
+                runs.push_back(run);
+                r0 = r1;
             }
-            r0 = r1;
+        }
+        if (!split) {
+            for (Run& run : runs) {
+                st = chain_uniform_a(cp, run.r1 - run.r0, channels, cur + (size_t)run.r0 * cur_ps, cur_ps, cur_step, run.pw, run.ph, run.ws, stream,
+                                     &run.rs);
+                if (st == PRL_OK)
+                    st = chain_uniform_b(cp, run.r1 - run.r0, channels, run.rs, run.pw, run.ph, d_dst + (size_t)(first + run.r0) * dst_page_stride,
+                                         dst_page_stride, dst_step, stream);
+                if (st != PRL_OK) return st;
+            }
+        } else {
+            st = ensure_buffer(&ctx->chain_planes, &ctx->chain_planes_bytes, planes_need);
+            if (st != PRL_OK) return st;
+            uint8_t* pl = static_cast<uint8_t*>(ctx->chain_planes);
+            for (Run& run : runs) {   // HEAD (the rotation was enqueued above)
+                run.planes = pl;
+                pl += denoise_plane_bytes(run.pw, run.ph) * (size_t)(run.r1 - run.r0);
+                st = denoise_convert_in(ctx, run.r1 - run.r0, channels, cur + (size_t)run.r0 * cur_ps, cur_ps, cur_step, run.pw, run.ph, run.planes, hs);
+                if (st != PRL_OK) return st;
+            }
+            if (first + cnt < n_pages) {
+                PRL_HIP_CHECK(hipStreamSynchronize(hs));   // the head is through before the next search takes the memory system
+                start_find(first + cnt);
+                if (env_knobs().chain_lag_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(env_knobs().chain_lag_ms));
+            }
+            for (Run& run : runs) {   // BODY
+                st = denoise_nlm(ctx, run.r1 - run.r0, cp->denoise_strength, run.planes, run.pw, run.ph, hs);
+                if (st != PRL_OK) return st;
+            }
+            finder.join();
+            if (env_knobs().debug) {
+                const auto tj = std::chrono::steady_clock::now();
+                (void)hipStreamSynchronize(hs);
+                std::fprintf(stderr, "[prl chain] pass at page %d: NL-means ran %.3f s past the search\n", first,
+                             std::chrono::duration<double>(std::chrono::steady_clock::now() - tj).count());
+            }
+            for (Run& run : runs) {   // TAIL
+                prl_binarize_geometry g;
+                st = prl_hip_binarize_geometry(&cp->binarize, run.pw, run.ph, &g);
+                if (st != PRL_OK) return st;
+                const ChainLayout l = chain_layout(cp, channels, run.pw, run.ph, g);
+                const int rc = run.r1 - run.r0;
+                st = denoise_convert_out(ctx, rc, channels, run.planes, run.pw, run.ph, run.ws, l.denoised, (size_t)run.pw * channels, hs);
+                if (st != PRL_OK) return st;
+                run.rs.cur = run.ws; run.rs.cur_ps = l.denoised; run.rs.cur_step = (size_t)run.pw * channels;
+                run.rs.w = run.ws + l.denoised * (size_t)rc;
+                st = chain_uniform_b(cp, rc, channels, run.rs, run.pw, run.ph, d_dst + (size_t)(first + run.r0) * dst_page_stride, dst_page_stride,
+                                     dst_step, stream);
+                if (st != PRL_OK) return st;
+            }
         }
         if (cp->deskew && !env_knobs().chain_overlap && first + cnt < n_pages) {
             PRL_HIP_CHECK(hipStreamSynchronize(hs));

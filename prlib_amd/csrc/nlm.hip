@@ -808,6 +808,117 @@ int nlm_planes_locked(DeviceCtx* ctx, int slot, int n_pages, int channels, float
 }  // namespace
 }  // namespace prl_hip
 
+namespace prl_hip {
+// prl::denoise in its three parts, on `cnt` pages whose planes live at `planes` (denoise_plane_bytes per page: L, ab, L', ab' -
+// 1 + 2 + 1 + 2 bytes per pixel, all pages' L first, then all ab, ...).  The chain runs the first and the last part (streaming
+// kernels) away from the angle search of the next pass and only the middle one beside it (glue.hip).
+size_t denoise_plane_bytes(int width, int height) { return 6 * (size_t)width * height; }
+
+static int lab_tables(DeviceCtx* ctx, hipStream_t s, LabTables* lt)
+{
+    const size_t cbrt_off = 2 * kLutSlot;
+    int st = ensure_small(ctx, cbrt_off + 64 * 1024);
+    if (st != PRL_OK) return st;
+    const HostLab& hl = host_lab();
+    auto* d_cbrt = reinterpret_cast<unsigned short*>(static_cast<uint8_t*>(ctx->small) + cbrt_off);
+    PRL_HIP_CHECK(hipMemcpyAsync(d_cbrt, hl.cbrt_tab.data(), hl.cbrt_tab.size() * sizeof(unsigned short), hipMemcpyHostToDevice, s));
+    std::copy(hl.fwd, hl.fwd + 9, lt->fwd);
+    std::copy(hl.inv, hl.inv + 9, lt->inv);
+    lt->cbrt_tab = d_cbrt;
+    return PRL_OK;
+}
+
+static int convert_in_locked(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
+                             int height, uint8_t* planes, hipStream_t s)
+{
+    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(s, ctx->last_use, 0));
+    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+    LabTables lt{};
+    int st = lab_tables(ctx, s, &lt);
+    if (st != PRL_OK) return st;
+    const size_t px = (size_t)width * height;
+    uint8_t* L = planes;
+    uint8_t* AB = L + px * (size_t)cnt;
+    PageSet ps{};
+    ps.base = src; ps.page_stride = src_page_stride; ps.step = src_step;
+    const dim3 grid((width + 255) / 256, height, cnt);
+    hipLaunchKernelGGL(k_lbgr2lab, grid, dim3(256), 0, s, ps, channels, width, height, lt, L, AB, px);
+    PRL_HIP_CHECK(hipGetLastError());
+    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, s));
+    return PRL_OK;
+}
+
+static int nlm_locked(DeviceCtx* ctx, int cnt, float strength, uint8_t* planes, int width, int height, hipStream_t s)
+{
+    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(s, ctx->last_use, 0));
+    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+    const size_t px = (size_t)width * height;
+    uint8_t* L = planes;
+    uint8_t* AB = L + px * (size_t)cnt;
+    uint8_t* L2 = AB + 2 * px * (size_t)cnt;
+    uint8_t* AB2 = L2 + px * (size_t)cnt;
+    PageSet sl{}, sab{};
+    sl.base = L; sl.page_stride = px; sl.step = (size_t)width;
+    sab.base = AB; sab.page_stride = 2 * px; sab.step = 2 * (size_t)width;
+    PageSetOut dl{}, dab{};
+    dl.base = L2; dl.page_stride = px; dl.step = (size_t)width;
+    dab.base = AB2; dab.page_stride = 2 * px; dab.step = 2 * (size_t)width;
+    int st = nlm_planes_locked(ctx, 0, cnt, 1, strength, sl, width, height, dl, s);
+    if (st != PRL_OK) return st;
+    st = nlm_planes_locked(ctx, 1, cnt, 2, 3.0f, sab, width, height, dab, s);  // hForColorComponents = 3
+    if (st != PRL_OK) return st;
+    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, s));
+    return PRL_OK;
+}
+
+static int convert_out_locked(DeviceCtx* ctx, int cnt, int channels, const uint8_t* planes, int width, int height, uint8_t* dst,
+                              size_t dst_page_stride, size_t dst_step, hipStream_t s)
+{
+    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(s, ctx->last_use, 0));
+    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
+    LabTables lt{};
+    int st = lab_tables(ctx, s, &lt);
+    if (st != PRL_OK) return st;
+    const size_t px = (size_t)width * height;
+    const uint8_t* L2 = planes + 3 * px * (size_t)cnt;
+    const uint8_t* AB2 = L2 + px * (size_t)cnt;
+    PageSetOut pd{};
+    pd.base = dst; pd.page_stride = dst_page_stride; pd.step = dst_step;
+    const dim3 grid((width + 255) / 256, height, cnt);
+    hipLaunchKernelGGL(k_lab2lbgr, grid, dim3(256), 0, s, L2, AB2, px, channels, width, height, lt, pd);
+    PRL_HIP_CHECK(hipGetLastError());
+    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, s));
+    return PRL_OK;
+}
+
+int denoise_convert_in(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
+                       int height, uint8_t* planes, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return convert_in_locked(ctx, cnt, channels, src, src_page_stride, src_step, width, height, planes, s);
+}
+int denoise_nlm(DeviceCtx* ctx, int cnt, float strength, uint8_t* planes, int width, int height, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return nlm_locked(ctx, cnt, strength, planes, width, height, s);
+}
+int denoise_convert_out(DeviceCtx* ctx, int cnt, int channels, const uint8_t* planes, int width, int height, uint8_t* dst,
+                        size_t dst_page_stride, size_t dst_step, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return convert_out_locked(ctx, cnt, channels, planes, width, height, dst, dst_page_stride, dst_step, s);
+}
+// the whole stage on pages [0, cnt) with the planes in the shared scratch area: one lock over all three parts
+int denoise_all_locked(DeviceCtx* ctx, int cnt, int channels, float strength, const uint8_t* src, size_t src_page_stride, size_t src_step,
+                       int width, int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, uint8_t* planes, hipStream_t s)
+{
+    int st = convert_in_locked(ctx, cnt, channels, src, src_page_stride, src_step, width, height, planes, s);
+    if (st == PRL_OK) st = nlm_locked(ctx, cnt, strength, planes, width, height, s);
+    if (st == PRL_OK) st = convert_out_locked(ctx, cnt, channels, planes, width, height, dst, dst_page_stride, dst_step, s);
+    return st;
+}
+}  // namespace prl_hip
+
 using namespace prl_hip;
 
 extern "C" {
@@ -860,62 +971,21 @@ int prl_hip_denoise_batch_device(int n_pages, int channels, float strength, cons
     int st = current_device(&dev);
     if (st != PRL_OK) return st;
     DeviceCtx* ctx = device_ctx(dev);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t cbrt_off = 2 * kLutSlot;
-    st = ensure_small(ctx, cbrt_off + 64 * 1024);
-    if (st != PRL_OK) return st;
-    if (ctx->last_use) PRL_HIP_CHECK(hipStreamWaitEvent(s, ctx->last_use, 0));
-    else PRL_HIP_CHECK(hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming));
-
-    const HostLab& hl = host_lab();
-    auto* d_cbrt = reinterpret_cast<unsigned short*>(static_cast<uint8_t*>(ctx->small) + cbrt_off);
-    PRL_HIP_CHECK(hipMemcpyAsync(d_cbrt, hl.cbrt_tab.data(), hl.cbrt_tab.size() * sizeof(unsigned short),
-                                 hipMemcpyHostToDevice, s));
-    LabTables lt{};
-    std::copy(hl.fwd, hl.fwd + 9, lt.fwd);
-    std::copy(hl.inv, hl.inv + 9, lt.inv);
-    lt.cbrt_tab = d_cbrt;
-
     // planes: L, ab, L', ab'  (1 + 2 + 1 + 2 bytes per pixel), processed in page chunks of bounded size
     const size_t px = (size_t)width * height;
     const size_t budget = (size_t)2 << 30;
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, budget / (6 * px)));
     chunk = std::min(chunk, 65535);  // grid.z of the per-page kernels
+    std::lock_guard<std::mutex> lk(ctx->mu);
     st = ensure_scratch(ctx, 6 * px * (size_t)chunk);
     if (st != PRL_OK) return st;
     auto* base = static_cast<uint8_t*>(ctx->scratch);
     for (int first = 0; first < n_pages; first += chunk) {
         const int cnt = std::min(chunk, n_pages - first);
-        uint8_t* L = base;
-        uint8_t* AB = L + px * (size_t)cnt;
-        uint8_t* L2 = AB + 2 * px * (size_t)cnt;
-        uint8_t* AB2 = L2 + px * (size_t)cnt;
-        PageSet ps{};
-        ps.base = d_src + (size_t)first * src_page_stride;
-        ps.page_stride = src_page_stride;
-        ps.step = src_step;
-        PageSetOut pd{};
-        pd.base = d_dst + (size_t)first * dst_page_stride;
-        pd.page_stride = dst_page_stride;
-        pd.step = dst_step;
-        const dim3 grid((width + 255) / 256, height, cnt);
-        hipLaunchKernelGGL(k_lbgr2lab, grid, dim3(256), 0, s, ps, channels, width, height, lt, L, AB, px);
-        PRL_HIP_CHECK(hipGetLastError());
-        PageSet sl{}, sab{};
-        sl.base = L; sl.page_stride = px; sl.step = (size_t)width;
-        sab.base = AB; sab.page_stride = 2 * px; sab.step = 2 * (size_t)width;
-        PageSetOut dl{}, dab{};
-        dl.base = L2; dl.page_stride = px; dl.step = (size_t)width;
-        dab.base = AB2; dab.page_stride = 2 * px; dab.step = 2 * (size_t)width;
-        st = nlm_planes_locked(ctx, 0, cnt, 1, strength, sl, width, height, dl, s);
+        st = denoise_all_locked(ctx, cnt, channels, strength, d_src + (size_t)first * src_page_stride, src_page_stride, src_step, width, height,
+                                d_dst + (size_t)first * dst_page_stride, dst_page_stride, dst_step, base, static_cast<hipStream_t>(stream));
         if (st != PRL_OK) return st;
-        st = nlm_planes_locked(ctx, 1, cnt, 2, 3.0f, sab, width, height, dab, s);  // hForColorComponents = 3
-        if (st != PRL_OK) return st;
-        hipLaunchKernelGGL(k_lab2lbgr, grid, dim3(256), 0, s, L2, AB2, px, channels, width, height, lt, pd);
-        PRL_HIP_CHECK(hipGetLastError());
     }
-    PRL_HIP_CHECK(hipEventRecord(ctx->last_use, s));
     return PRL_OK;
 }
 

@@ -75,7 +75,8 @@ const EnvKnobs& env_knobs()
         k.fake_devices = (int)std::max(0ll, geti("PRL_HIP_FAKE_DEVICES", 0));
         k.chain_pass = (int)std::max(0ll, geti("PRL_HIP_CHAIN_PASS", 0));
         k.chain_first_pass = (int)std::max(0ll, geti("PRL_HIP_CHAIN_FIRST_PASS", 0));
-        k.chain_overlap = (int)geti("PRL_HIP_CHAIN_OVERLAP", 1);
+        k.chain_lag_ms = (int)std::max(0ll, geti("PRL_HIP_CHAIN_LAG_MS", 50));
+        k.chain_overlap = (int)geti("PRL_HIP_CHAIN_OVERLAP", 2);
         k.chain_work_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_WORK_MB", 49152));
         k.host_chunk_mb = (size_t)std::max(1ll, geti("PRL_HIP_HOST_CHUNK_MB", 128));
         k.host_copy_threads = (int)std::max(1ll, std::min(32ll, geti("PRL_HIP_HOST_COPY_THREADS", 8)));
@@ -971,6 +972,9 @@ int prl_hip_release_workspace(void)
         ctx->host_buf_bytes[i] = 0;
     }
     host_slots_free(ctx);
+    if (ctx->chain_planes) PRL_HIP_CHECK(hipFree(ctx->chain_planes));
+    ctx->chain_planes = nullptr;
+    ctx->chain_planes_bytes = 0;
     for (auto& kv : ctx->streams) {
         std::lock_guard<std::mutex> wl(kv.second->mu);
         ws_free(kv.second.get());

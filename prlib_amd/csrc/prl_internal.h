@@ -73,6 +73,8 @@ struct DeviceCtx {
     void* host_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // in 0 / 1, out 0 / 1
     size_t host_buf_bytes[4] = {0, 0, 0, 0};
     void* host_slots[2] = {nullptr, nullptr};   // PinSlots of host_batch.hip (replaced when they grow, never freed at exit)
+    void* chain_planes = nullptr;   // Lab planes of a whole chain pass (split mode of glue.hip; guarded by stage_mu)
+    size_t chain_planes_bytes = 0;
     hipStream_t side = nullptr;     // created on first use (non-blocking)
     hipEvent_t side_ev = nullptr;
 };
@@ -94,7 +96,9 @@ struct EnvKnobs {
     int ppht_mw = -1;                   // PRL_HIP_PPHT_MW   1 / 0: always / never three wavefronts per page (default: by batch size)
     int ppht_prio = 3;                  // PRL_HIP_PPHT_PRIO=0   k_ppht does not raise its wavefront priority
     int chain_pass = 0, chain_first_pass = 0;   // PRL_HIP_CHAIN_PASS / PRL_HIP_CHAIN_FIRST_PASS   pages per pass of the chain with deskew (0: 256 / 64)
-    int chain_overlap = 1;              // PRL_HIP_CHAIN_OVERLAP=0   angle search of the next pass not overlapped with this one
+    int chain_lag_ms = 50;              // PRL_HIP_CHAIN_LAG_MS   head start of the next pass's search over this pass's NL-means kernels
+    int chain_overlap = 2;              // PRL_HIP_CHAIN_OVERLAP   0: passes one after the other; 1: the search of the next pass beside all stages
+                                        //                         of this one; 2: beside its NL-means kernels only (head / body / tail, glue.hip)
     size_t chain_work_mb = 49152;       // PRL_HIP_CHAIN_WORK_MB
     size_t host_chunk_mb = 128;         // PRL_HIP_HOST_CHUNK_MB   pages staged per buffer of prl_hip_binarize_batch_host
     int chain_host_pages = 0;           // PRL_HIP_CHAIN_HOST_PAGES   pages per device chunk of prl_hip_chain_batch_host (0: from the budget)
@@ -202,6 +206,14 @@ int fused_max_pages(const ThrParams& tp);  // pages one fused_run call can take 
 // ---- thinning (thin.hip): the C entry plus the option to thin cv::bitwise_not of the source (chain glue) ------
 int thin_batch_device(int method, int n_pages, const uint8_t* d_src, size_t src_page_stride, size_t src_step, int width,
                       int height, uint8_t* d_dst, size_t dst_page_stride, size_t dst_step, void* stream, bool invert_input);
+
+// ---- prl::denoise in three parts (nlm.hip; the chain separates its streaming parts from its compute part) ----------------
+size_t denoise_plane_bytes(int width, int height);   // per page: L, ab, L', ab'
+int denoise_convert_in(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
+                       int height, uint8_t* planes, hipStream_t s);
+int denoise_nlm(DeviceCtx* ctx, int cnt, float strength, uint8_t* planes, int width, int height, hipStream_t s);
+int denoise_convert_out(DeviceCtx* ctx, int cnt, int channels, const uint8_t* planes, int width, int height, uint8_t* dst,
+                        size_t dst_page_stride, size_t dst_step, hipStream_t s);
 
 // ---- deskew (deskew.hip): one pass over `cnt` pages, as its two halves (the chain overlaps them) or in one go ------
 int deskew_pages_per_pass(int n_pages, int width, int height);

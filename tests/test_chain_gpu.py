@@ -185,7 +185,8 @@ def test_config5_chain_matches_the_composed_oracle(prl, oracle, cuda_device, cha
     assert len(sizes) >= 2 and angles[-1] == 0.0
 
 
-def test_config5_chain_in_several_passes(prl, oracle, cuda_device, tmp_path):
+@pytest.mark.parametrize("overlap", ["2", "1", "0"])
+def test_config5_chain_in_several_passes(prl, oracle, cuda_device, tmp_path, overlap):
     """With more pages than one pass of the angle search takes, the chain searches the angles of pass k+1 on a side stream
     (helper thread) while pass k is rotated, denoised and binarized.  PRL_HIP_DESKEW_WORK_MB (read once per process) is
     shrunk in a child process so that 5 small pages need 5 passes; the result must equal the one-pass result, which the
@@ -217,7 +218,8 @@ outs, angles = prlib_amd.process_pages(torch.from_numpy(batch).cuda(), 3, prlib_
 np.savez(%r, angles=np.asarray(angles), **{"p%%d" %% i: o.cpu().numpy() for i, o in enumerate(outs)})
 print("DONE")
 ''' % (ROOT, str(tmp_path / "in.npy"), str(tmp_path / "out.npz"))
-    env = dict(os.environ, PRL_HIP_DESKEW_WORK_MB="1")
+    # PRL_HIP_CHAIN_OVERLAP: 2 = head / body / tail around the next pass's search (default), 1 = search beside all stages, 0 = serial
+    env = dict(os.environ, PRL_HIP_DESKEW_WORK_MB="1", PRL_HIP_CHAIN_OVERLAP=overlap)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
     z = np.load(tmp_path / "out.npz")
