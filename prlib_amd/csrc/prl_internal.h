@@ -95,7 +95,7 @@ struct EnvKnobs {
     size_t deskew_work_mb = 24576;      // PRL_HIP_DESKEW_WORK_MB
     int ppht_mw = -1;                   // PRL_HIP_PPHT_MW   1 / 0: always / never three wavefronts per page (default: by batch size)
     int ppht_prio = 3;                  // PRL_HIP_PPHT_PRIO=0   k_ppht does not raise its wavefront priority
-    int chain_pass = 0, chain_first_pass = 0;   // PRL_HIP_CHAIN_PASS / PRL_HIP_CHAIN_FIRST_PASS   pages per pass of the chain with deskew (0: 256 / 64)
+    int chain_pass = 0, chain_first_pass = 0;   // PRL_HIP_CHAIN_PASS / PRL_HIP_CHAIN_FIRST_PASS   pages per pass of the chain with deskew (0: 192 with denoise, else 256 / the same)
     int chain_lag_ms = 50;              // PRL_HIP_CHAIN_LAG_MS   head start of the next pass's search over this pass's NL-means kernels
     int chain_overlap = 2;              // PRL_HIP_CHAIN_OVERLAP   0: passes one after the other; 1: the search of the next pass beside all stages
                                         //                         of this one; 2: beside its NL-means kernels only (head / body / tail, glue.hip)
