@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) k_bg_maps(BgGeom g, int och, uint8_t* __r
     const int c = blockIdx.x, page = blockIdx.y, t = threadIdx.x;
     const int w = g.mw, h = g.mh, nx = g.nx, ny = g.ny;
     // the map itself is tiny (248 x 234 bytes for A4): work on an LDS copy when it fits (the column fills are chains of
-    // dependent accesses: 0.61 -> see DESIGN 4.9 ms for 64 maps from memory), on the global one otherwise
+    // dependent accesses: 0.61 ms for 64 gray pages' maps from memory, 0.27 ms from LDS), on the global one otherwise
     constexpr int LDS_MAP = 60000;  // an A4 map is 248 x 234 = 58 032 bytes
     __shared__ uint8_t lmap[LDS_MAP];
     uint8_t* gm = maps + (size_t)page * g.map_page + (size_t)c * w * h;
