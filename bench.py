@@ -212,6 +212,7 @@ def main():
     checked = []
     cpu = None
     vs_opencv = None
+    vs_opencv_why = None
     if rank == 0:
         from oracle import capi as oc
 
@@ -232,8 +233,13 @@ def main():
 
                 rep = opencv_check.report(timeout=300)
                 vs_opencv = None if (rep is None or rep.get("opencv") is None) else rep
-            except Exception:
+                if vs_opencv is None:   # say WHY the pin did not run: headers_absent / build_failed / make_failed / run_failed
+                    vs_opencv_why = (rep or {}).get("why", "no report")
+                    if (rep or {}).get("stderr"):
+                        vs_opencv_why += ": " + rep["stderr"][-300:]
+            except Exception as e:
                 vs_opencv = None
+                vs_opencv_why = "exception: " + repr(e)
         if args.cpu_seconds > 0 and world == 1:   # the CPU baseline leg runs at N=1 only
             n_host = min(n_mine, 64)
             cpu = cpu_baseline(pages[:n_host].cpu().numpy().copy(), po, args.cpu_seconds)
@@ -284,7 +290,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": {"checked_pages": checked, "mismatching_pixels": mismatches,
                        "refined_pixels": int(stats.refined_pixels), "exact_pixels": int(stats.exact_pixels),
-                       "literal_pages": int(stats.literal_pages), "vs_opencv": vs_opencv},
+                       "literal_pages": int(stats.literal_pages), "vs_opencv": vs_opencv, "vs_opencv_why": vs_opencv_why},
         }
         print(json.dumps(line), flush=True)
     pdist.finish()

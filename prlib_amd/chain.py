@@ -92,13 +92,18 @@ def process_pages(pages, channels: int, method: int = 0, windowSize: int = 101, 
 
     pages: uint8 CUDA tensor [N,] H x W (channels = 1) or [N,] H x W x channels (BGR / BGRA).
     Returns [N,] out_h x out_w: the mask, or with `thin` the skeleton of the dark strokes.  With `deskew` every page has
-    its own result size: returns (list of per-page tensors, angles in degrees)."""
+    its own result size: returns (list of per-page tensors, angles in degrees) - (tensor, angle) for a single un-batched
+    page - and `out` is not accepted."""
     import numpy as np
     import torch
 
     if deskew:
+        if out is not None:
+            raise ValueError("`out` cannot be given with deskew: every page's result has its own size")
         t, squeeze = _pages(pages, channels != 1)
         n, h, w = t.shape[0], t.shape[1], t.shape[2]
+        if channels != 1 and t.shape[3] != channels:
+            raise ValueError("last dimension does not match `channels`")
         L = _capi.lib()
         cp = _capi.ChainParams()
         L.prl_hip_default_chain_params(C.byref(cp))
@@ -118,7 +123,8 @@ def process_pages(pages, channels: int, method: int = 0, windowSize: int = 101, 
         ang = np.zeros(n, dtype=np.float64)
         _capi.check(L.prl_hip_chain_pages_device(C.byref(cp), n, channels, t.data_ptr(), t.stride(0), t.stride(1), w, h,
                                                 o.data_ptr(), o.stride(0), o.stride(1), wh.ctypes.data, ang.ctypes.data, _stream(t)))
-        return [o[i, : wh[i, 1], : wh[i, 0]] for i in range(n)], ang
+        res = [o[i, : wh[i, 1], : wh[i, 0]] for i in range(n)]
+        return (res[0], ang[0]) if squeeze else (res, ang)
 
     t, squeeze = _pages(pages, channels != 1)
     n, h, w = t.shape[0], t.shape[1], t.shape[2]

@@ -37,7 +37,9 @@
 // left is measurable: 1 = no decision (loads, slide, prefix, exchange, trivial store), 2 = no sums (compared-pixel load,
 // decision on the warm-up sums, store), 3 = loads and store only, 4 = all arithmetic but only the entering-row stream
 // (the leaving row and the compared pixels are faked from registers: what an on-chip row ring could reach at this occupancy),
-// 5 = as 4 but the compared-pixel stream is kept (leaving row faked only).
+// 5 = as 4 but the compared-pixel stream is kept (leaving row faked only), 6 = as 4 without the entering-row stream either
+// (no loads in the row loop: the arithmetic and the mask store alone; PRL_PROBE_LDS=<bytes> of dynamic LDS per wavefront
+// lowers the occupancy to what an on-chip row ring would leave).
 #ifndef PRL_PROBE
 #define PRL_PROBE 0
 #endif
@@ -82,9 +84,16 @@ struct PageK {  // per-page constants of the float32 test
 struct FusedParams {
     ThrParams tp;
     int uo;            // useful output columns per strip (multiple of 8)
-    int n_strips, n_segs, rows_per_seg;
+    int n_strips;
+    // Row segments in TIERS: the first tier has the longest segments (few (w-1)-row warm-ups), the last the shortest
+    // (a short tail when the chip drains); workgroups are dispatched in index order, so tier 0's wavefronts start first.
+    // Tier k: `segs` segments of `rows` rows per page and strip, starting at output row `row0`; `waves` = pages * strips *
+    // segs of them, numbered from `first` (the canonical wavefront id; Wolf-Jolion's per-wavefront maxima are indexed by it).
+    struct Tier { int rows, segs, row0; unsigned waves, first; } tier[8];
+    int n_tiers;
     int lane_off;      // (w-1) / 8
     unsigned total_waves;
+    unsigned xcd_waves;  // wavefront slots per XCD share of the grid (sum over tiers of ceil(waves / 8))
     float w2f;         // (float)(w*w), exact
     float c0, c1;      // method constants in float32, pre-multiplied by f and Z (see eval32)
     float eps1;        // Z * float32 decision margin (covers float32 evaluation + literal rounding noise)
@@ -652,7 +661,9 @@ __device__ __forceinline__ float bpermf(int addr, float v)
     return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
 }
 
-template <int METHOD, int SH>
+// LO: fp.lane_off as a compile-time constant; FAST: byte mask through non-temporal stores and no p == 0 fix-up (the usual
+// call) - both only remove wave-uniform branches from the row loop (~8 taken branches per row otherwise).
+template <int METHOD, int SH, int LO, bool FAST>
 __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, size_t ostep, const FusedParams& fp,
                                              int page, int xs, int ys, int ye, int lane, const PageK& pk, unsigned wid,
                                              PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
@@ -670,7 +681,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     const int x0 = xs + CPL * lane;            // first output column of this lane
     const bool lane_has_out = CPL * lane < fp.uo;  // interior strips: every output column exists
 #endif
-    const int far_addr0 = (lane + fp.lane_off) * 4, far_addr1 = far_addr0 + 4;
+    const int far_addr0 = (lane + LO) * 4, far_addr1 = far_addr0 + 4;
     const i32x4 rsrc = page_rsrc(img);
     const int step = (int)istep;
 
@@ -748,12 +759,9 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         w1s = tot_s + lane_up1f(w1s);     \
         w1q = tot_q + lane_up1f(w1q);     \
     } while (0)
-        switch (fp.lane_off) {  // w - 1 <= 30: at most 3 steps
-        case 0: break;
-        case 1: PRL_W_STEP(); break;
-        case 2: PRL_W_STEP(); PRL_W_STEP(); break;
-        default: PRL_W_STEP(); PRL_W_STEP(); PRL_W_STEP(); break;
-        }
+        if (LO >= 1) PRL_W_STEP();  // w - 1 <= 30: at most 3 steps
+        if (LO >= 2) PRL_W_STEP();
+        if (LO >= 3) PRL_W_STEP();
 #undef PRL_W_STEP
 #pragma unroll
         for (int c = 0; c < CPL; ++c) Ssum[c] = bpermf((c + SH) >= 8 ? far_addr1 : far_addr0, ES[(c + SH) & 7]);
@@ -801,7 +809,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         unsigned lo = pack_signs(tn[0], tn[1], tn[2], tn[3]), hi = pack_signs(tn[4], tn[5], tn[6], tn[7]);
 #endif
 
-        if (fp.need_p0) {
+        if (!FAST && fp.need_p0) {
             // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative); on the packed bytes
             const unsigned nzl = (((pvb.x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | pvb.x) & 0x80808080u;
             const unsigned nzh = (((pvb.y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | pvb.y) & 0x80808080u;
@@ -838,10 +846,10 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         }
 
         if (lane_has_out) {
-            if (fp.bit_out) {
+            if (!FAST && fp.bit_out) {
                 const unsigned b = (((lo & 0x01010101u) * 0x01020408u) >> 24) | ((((hi & 0x01010101u) * 0x01020408u) >> 20) & 0xf0u);
                 out[(size_t)y * ostep + (x0 >> 3)] = (uint8_t)b;
-            } else if (fp.nt_store) {
+            } else if (FAST || fp.nt_store) {
                 typedef unsigned u2v __attribute__((ext_vector_type(2)));
                 u2v o = {lo, hi};
                 __builtin_nontemporal_store(o, reinterpret_cast<u2v*>((uint8_t*)(out + (size_t)y * ostep + x0)));
@@ -852,7 +860,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         }
 
         pv_ptr += istep;  // row y + 1 <= H - 1 exists for every output row
-#if PRL_PROBE == 4
+#if PRL_PROBE == 4 || PRL_PROBE == 6
         pvb = make_uint2(__float_as_uint(vold.v[0]) >> 12, __float_as_uint(vold.v[5]) >> 11);  // no compared-pixel fetch
 #else
         pvb = gload8(pv_ptr);
@@ -884,7 +892,12 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
 #if PRL_PROBE >= 4
         {
             const F8 prev = vnew;
+#if PRL_PROBE == 6
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) vnew.v[c] = vold.v[(c + 3) & 7];  // no fetch at all: pure arithmetic + the mask store
+#else
             vnew = tload8(rsrc, col0, off_new);
+#endif
             vold = prev;  // no leaving-row fetch
         }
 #else
@@ -916,25 +929,41 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned wpb = blockDim.x >> 6;  // wavefronts per block
     // XCD-aware block order: hardware deals blocks round-robin over the 8 XCDs, so blocks b and b+8
-    // share an L2.  Give each XCD a contiguous range of logical blocks (= neighbouring strips and
+    // share an L2.  Give each XCD a contiguous range of logical wavefronts (= neighbouring strips and
     // segments of the same pages) so halo re-reads hit that XCD's L2.  Speed only, never correctness.
-    const unsigned nb = gridDim.x;
-    const unsigned lb = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+    // XCD x = blockIdx & 7 takes the x-th eighth of every tier, tier 0 first (its time index is blockIdx >> 3).
+    const unsigned xcd = blockIdx.x & 7u;
     const unsigned wv = threadIdx.x >> 6;
-    const unsigned wid = __builtin_amdgcn_readfirstlane(lb * wpb + wv);
-    if (wid >= fp.total_waves) return;
-    const int per_page = fp.n_strips * fp.n_segs;
+    unsigned u = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * wpb + wv);  // this wavefront's slot in its XCD's share
+    unsigned wid = 0;
+    int trows = 0, tsegs = 1, trow0 = 0;
+    bool found = false;
+    for (int k = 0; k < fp.n_tiers; ++k) {
+        const unsigned n = fp.tier[k].waves;
+        const unsigned lo = (unsigned)(((unsigned long long)n * xcd) >> 3), hi = (unsigned)(((unsigned long long)n * (xcd + 1u)) >> 3);
+        if (u < hi - lo) {
+            wid = lo + u;
+            trows = fp.tier[k].rows; tsegs = fp.tier[k].segs; trow0 = fp.tier[k].row0;
+            found = true;
+            u = fp.tier[k].first;  // (reused below: the canonical id offset)
+            break;
+        }
+        u -= hi - lo;
+    }
+    if (!found) return;
+    const int per_page = fp.n_strips * tsegs;
     const int page = (int)(wid / (unsigned)per_page);
     const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
     const int seg = rem / fp.n_strips;
     const int strip = rem - seg * fp.n_strips;
+    wid += u;  // canonical wavefront id over all tiers
 
     gcptr img = (gcptr)src.page(page);
     gptr out = (gptr)dst.page(page);
 
     const int xs = strip * fp.uo;          // first output column of the strip
-    const int ys = seg * fp.rows_per_seg;  // first output row of the segment
-    const int ye = min(ys + fp.rows_per_seg, tp.oh);
+    const int ys = trow0 + seg * trows;    // first output row of the segment
+    const int ye = min(ys + trows, tp.oh);
 
     PageK pk;
     pk.c1 = fp.c1;
@@ -964,9 +993,22 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     const int first_col = xs + 1 - tp.half;
     const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
     constexpr bool kFloatOk = METHOD != kWolfCollect;  // (sweep B revisits few segments and queues exact candidates: integer)
-    if ((interior || PRL_PROBE) && kFloatOk && !WIDE && fp.flt)
-        strip_loop_f<METHOD, SH>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
-    else if (interior)
+    if ((interior || PRL_PROBE) && kFloatOk && !WIDE && fp.flt) {
+        // (wave-uniform dispatch, once per wavefront: the row loop itself is branch-free in the usual configuration)
+        const bool fast = !fp.bit_out && fp.nt_store && !fp.need_p0;
+#define PRL_FLT_LOOP(LOV)                                                                                                          \
+    do {                                                                                                                           \
+        if (fast) strip_loop_f<METHOD, SH, LOV, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);  \
+        else strip_loop_f<METHOD, SH, LOV, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);      \
+    } while (0)
+        switch (fp.lane_off) {
+        case 0: PRL_FLT_LOOP(0); break;
+        case 1: PRL_FLT_LOOP(1); break;
+        case 2: PRL_FLT_LOOP(2); break;
+        default: PRL_FLT_LOOP(3); break;
+        }
+#undef PRL_FLT_LOOP
+    } else if (interior)
         strip_loop<METHOD, SH, false, WIDE>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
     else
         strip_loop<METHOD, SH, true, WIDE>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
@@ -1273,16 +1315,19 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     unsigned wpb = 1u;
     wpb = (unsigned)env_knobs().fused_wpb;
     if (fp.total_waves > 0x7fffff00u) wpb = std::max(wpb, 4u);  // grid.x is limited to 2^31 - 1 workgroups
-    unsigned blocks = (fp.total_waves + wpb - 1) / wpb;
-    blocks = (blocks + 7) / 8 * 8;
+    const unsigned blocks = 8u * ((fp.xcd_waves + wpb - 1) / wpb);   // each XCD: its share of every tier
     const dim3 grid(blocks), block(64 * wpb);
     const bool wide = fp.tp.w - 1 > 181;  // S no longer fits the mantissa of 2^23 (eval32)
+    size_t dyn_lds = 0;
+#if PRL_PROBE
+    if (const char* e = std::getenv("PRL_PROBE_LDS")) dyn_lds = (size_t)std::atoll(e);
+#endif
 #define PRL_LAUNCH_FUSED(SHV)                                                                                    \
     do {                                                                                                         \
         if (wide)                                                                                                \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, true>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);    \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, true>), grid, block, dyn_lds, stream, src, dst, fp, g, rl, cand, cnt);    \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, false>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);   \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, false>), grid, block, dyn_lds, stream, src, dst, fp, g, rl, cand, cnt);   \
     } while (0)
     switch (sh) {
     case 0: PRL_LAUNCH_FUSED(0); break;
@@ -1473,7 +1518,8 @@ size_t fused_small_bytes(int)
 }
 
 // Pages one fused_run call may take.  Wolf-Jolion keeps one float per wavefront of the call (sweep A -> sweep B), kSegmaxCap
-// of them: a call's wavefronts = pages x strips x segments, with at most 128 rows per segment.
+// of them: a call's wavefronts = pages x strips x segments; fused_run lengthens its segments until they fit, this only keeps
+// the segments of a chunk from becoming much longer than 128 rows.
 int fused_max_pages(const ThrParams& tp)
 {
     if (tp.method != PRL_WOLFJOLION) return 0x7fffffff;
@@ -1498,28 +1544,77 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.nt_store = env_knobs().nt_store ? 1 : 0;
     fp.uo = ((SW - (tp.w - 1)) / 8) * 8;
     fp.n_strips = (tp.ow + fp.uo - 1) / fp.uo;
-    // rows per segment: long segments amortise the (w-1)-row warm-up, short ones fill the chip
-    // measured on MI355X, 4K pages, w=31: 256 pages - 64..192 rows per segment within 1 %, 256: +1 %, 512: +14 %;
-    // 32 pages - 128: 0.54 ms, 64: 0.48, 32: 0.49, 16: 0.55; 8 pages - 0.168 / 0.125 / 0.127 / 0.131; one page -
-    // 0.120 / 0.066 / 0.044 / 0.031 (a single page has 9 x 32 wavefronts at 128 rows for 5120 wavefront slots)
-    auto waves_at = [&](int r) { return (long long)n_pages * fp.n_strips * ((tp.oh + r - 1) / r); };
-    int rps = 128;
-    if (waves_at(128) < 40000 && tp.w - 1 <= 64) rps = 64;   // (64 A4 pages, w=101: 128 rows 0.78 ms, 64 rows 0.80)
-    {   // small batches: halve while the chip is far from full, but keep the (w-1)-row warm-up (a warm-up row costs
-        // about a quarter of a full one) below ~the segment's own work
-        int min_rps = 16;
-        while (min_rps < (tp.w - 1) / 4) min_rps *= 2;
-        while (rps > min_rps && waves_at(rps) < 4096) rps /= 2;
+    // Row segments.  Long segments amortise the (w-1)-row warm-up, short ones fill the chip and keep the tail short when it
+    // drains; workgroups start in index order, so the segments come in TIERS of decreasing length (guided scheduling): each tier
+    // takes about half of the rows that are left, in segments sized for ~two rounds of the chip's wavefront slots, down to a
+    // floor that keeps a segment's warm-up (a warm-up row costs 0.1-0.25 of a full one) a fraction of its own work.
+    // Measured on MI355X (profiles/r03/tiers.txt); before (one size for all, 128 rows): 4K pages, w=31, 256 pages - 64..192 rows
+    // within 1 %, 512: +14 % (tail); A4, w=101: 128..512 rows within 3 % (what the longer segments save in warm-up rows the
+    // tail gives back, profiles/r03/rps_w101.txt).  Small batches (the chip is never full): one size, halved while far from full:
+    // 32 pages - 128: 0.54 ms, 64: 0.48, 32: 0.49, 16: 0.55; 8 pages - 0.168 / 0.125 / 0.127 / 0.131; one page - 0.120 / 0.066 /
+    // 0.044 / 0.031 (a single page has 9 x 32 wavefronts at 128 rows for 5120 wavefront slots)
+    const long long PS = (long long)n_pages * fp.n_strips;   // page-strips
+    const long long slots = 5120;                             // 256 CUs x 20 wavefronts
+    auto waves_at = [&](int r) { return PS * ((tp.oh + r - 1) / r); };
+    int min_rps = 16;
+    while (min_rps < (tp.w - 1) / 4) min_rps *= 2;
+    int floor_rps = 32;                                       // tiers: shortest segment = pow2ceil(w - 1) in [32, 128]
+    while (floor_rps < tp.w - 1 && floor_rps < 128) floor_rps *= 2;
+    floor_rps = std::max(floor_rps, min_rps);
+    const unsigned long long wave_cap = tp.method == PRL_WOLFJOLION ? env_knobs().segmax_cap : 0xfffffff0ull;
+    auto single_tier = [&](int rps) {
+        fp.n_tiers = 1;
+        fp.tier[0].rows = rps; fp.tier[0].segs = (tp.oh + rps - 1) / rps; fp.tier[0].row0 = 0;
+    };
+    // (tiers pay from ~600 rows of work per wavefront slot on: 256 x 4K pages -2 %, 256 A4 pages w=21 -3.5 %, 1024 A4 pages -4 %;
+    // 64 x 4K pages -2 %, 32 x 4K pages +3 % - there the single size below, tuned for small batches, stays)
+    const bool tiers_on = env_knobs().tiers && !env_knobs().rows_per_seg && PS * tp.oh >= 600 * slots;
+    if (!tiers_on) {
+        int rps = 128;
+        if (waves_at(128) < 40000 && tp.w - 1 <= 64) rps = 64;   // (64 A4 pages, w=101: 128 rows 0.78 ms, 64 rows 0.80)
+        while (rps > min_rps && waves_at(rps) < 4096) rps /= 2;  // small batches: halve while the chip is far from full
+        if (env_knobs().rows_per_seg) rps = env_knobs().rows_per_seg;  // tuning knob
+        while ((unsigned long long)waves_at(rps) > wave_cap && rps < tp.oh) rps *= 2;  // (Wolf: one sweep-A maximum per wavefront)
+        single_tier(rps);
+    } else {
+        for (int fl = floor_rps;; fl *= 2) {
+            int n = 0, rows_left = tp.oh, row0 = 0, prev = 512;
+            constexpr int kMaxTiers = (int)(sizeof(fp.tier) / sizeof(fp.tier[0]));
+            while (rows_left > 0) {
+                const double want = (double)PS * rows_left / (2.0 * (double)slots);
+                int R = fl;
+                while (R * 2 <= want && R * 2 <= prev) R *= 2;
+                R = std::min(R, std::max(prev, fl));
+                int segs;
+                if (R <= fl || n == kMaxTiers - 1 || rows_left <= R) segs = (rows_left + R - 1) / R;   // last tier: all that is left
+                else segs = std::max(1, rows_left / R / 2);
+                if (n > 0 && fp.tier[n - 1].rows == R) fp.tier[n - 1].segs += segs;   // same length as the tier before: one tier
+                else { fp.tier[n].rows = R; fp.tier[n].segs = segs; fp.tier[n].row0 = row0; ++n; }
+                row0 += segs * R;
+                rows_left -= segs * R;
+                prev = R;
+            }
+            fp.n_tiers = n;
+            unsigned long long tw = 0;
+            for (int k = 0; k < n; ++k) tw += (unsigned long long)PS * fp.tier[k].segs;
+            if (tw <= wave_cap || fl >= tp.oh) break;
+        }
     }
-    if (env_knobs().rows_per_seg) rps = env_knobs().rows_per_seg;  // tuning knob
-    if (tp.method == PRL_WOLFJOLION)  // one sweep-A maximum per wavefront is kept: never more wavefronts than slots
-        while ((unsigned long long)waves_at(rps) > env_knobs().segmax_cap && rps < tp.oh) rps *= 2;
-    fp.rows_per_seg = rps;
-    fp.n_segs = (tp.oh + rps - 1) / rps;
+    {
+        unsigned long long tw = 0, xw = 0;
+        for (int k = 0; k < fp.n_tiers; ++k) {
+            const unsigned long long nw = (unsigned long long)PS * fp.tier[k].segs;
+            if (nw > 0xfffffff0ull) return PRL_ERR_BAD_ARG;
+            fp.tier[k].waves = (unsigned)nw;
+            fp.tier[k].first = (unsigned)tw;
+            tw += nw;
+            xw += (nw + 7) / 8;
+        }
+        if (tw > 0xfffffff0ull || xw > 0x0ffffff0ull) return PRL_ERR_BAD_ARG;
+        fp.total_waves = (unsigned)tw;
+        fp.xcd_waves = (unsigned)xw;
+    }
     fp.lane_off = (tp.w - 1) / 8;
-    const unsigned long long tw = (unsigned long long)n_pages * fp.n_strips * fp.n_segs;
-    if (tw > 0xfffffff0ull) return PRL_ERR_BAD_ARG;
-    fp.total_waves = (unsigned)tw;
     double cq = 1.0;
     fp.flt = flt_usable(tp, src.step, &cq) ? 1 : 0;
     const FusedBounds b = fused_bounds(tp, fp.flt ? cq : 1.0);  // margins of the threshold sweep

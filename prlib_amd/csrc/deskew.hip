@@ -1088,6 +1088,7 @@ int host_roundtrip(int channels, const uint8_t* src, size_t src_step, int width,
     uint8_t *d_in = nullptr, *d_out = nullptr;
     // own buffers: the stage itself uses the shared staging area for its gray pages
     PRL_HIP_CHECK(hipMalloc(&d_in, in_bytes + 2 * out_bytes));
+    struct Free { uint8_t* p; ~Free() { (void)hipFree(p); } } free_d_in{d_in};  // every exit, the error returns of PRL_HIP_CHECK included
     d_out = d_in + in_bytes;
     uint8_t* d_packed = d_out + out_bytes;  // the result with rows packed to its own width
     hipStream_t stream = nullptr;
@@ -1106,7 +1107,6 @@ int host_roundtrip(int channels, const uint8_t* src, size_t src_step, int width,
         PRL_HIP_CHECK(hipMemcpy2DAsync(d_packed, out_row, d_out, out_row_max, out_row, (size_t)*out_h, hipMemcpyDeviceToDevice, stream));
         st = stage_download(ctx, 0, d_packed, out_row, *out_h, dst, dst_step, stream);
     }
-    (void)hipFree(d_in);
     return st;
 }
 }  // namespace
@@ -1189,6 +1189,7 @@ int prl_hip_houghp_device(const uint8_t* d_image, size_t step, int width, int he
     if (st != PRL_OK) return st;
     st = stage_acquire(ctx, hs);
     if (st != PRL_OK) return st;
+    StageRelease release{ctx, hs};
     st = prl_hip_invert_batch_device(1, d_image, 0, step, width, height, static_cast<uint8_t*>(ctx->stage), bytes, (size_t)width, stream);
     if (st != PRL_OK) return st;
     PageSet g{};

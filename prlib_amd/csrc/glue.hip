@@ -317,11 +317,17 @@ int chain_uniform_b(const prl_chain_params* cp, int cnt, int channels, const Run
         cur = w; cur_ps = l.gray; cur_step = (size_t)width;
         w += l.gray * (size_t)cnt;
     }
-    if (cp->thin == PRL_CHAIN_NO_THINNING)
-        return prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, out, dst_ps, dst_step, stream);
+    // The binarizer's source is this chain's own scratch, which the next pass / the next call overwrites: its flag check (and
+    // the literal redo of an overflow-flagged page) must happen HERE, whatever prl_hip_set_deferred_completion says - a
+    // pending call resolved later would redo the page from overwritten pixels.
+    if (cp->thin == PRL_CHAIN_NO_THINNING) {
+        st = prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, out, dst_ps, dst_step, stream);
+        if (st != PRL_OK) return st;
+        return prl_hip_finish(stream);
+    }
     st = prl_hip_binarize_batch_device(&cp->binarize, cnt, cur, cur_ps, cur_step, width, height, w, l.mask, (size_t)g.out_w, stream);
     if (st != PRL_OK) return st;
-    st = prl_hip_finish(stream);  // (deferred-completion mode: the mask is final before it is thinned)
+    st = prl_hip_finish(stream);  // (the mask is final before it is thinned)
     if (st != PRL_OK) return st;
     // cv::bitwise_not between the two stages happens inside the thinning's bit packing (no pass of its own)
     return prl_hip::thin_batch_device(cp->thin, cnt, w, l.mask, (size_t)g.out_w, g.out_w, g.out_h, out, dst_ps, dst_step, stream, true);
@@ -341,6 +347,9 @@ int chain_check(const prl_chain_params* cp, int n_pages, int channels, const uin
     if (cp->denoise && channels == 1) return PRL_ERR_BAD_CHANNELS;  // fastNlMeansDenoisingColored asserts 8UC3 / 8UC4
     if (cp->thin != PRL_CHAIN_NO_THINNING && cp->thin != PRL_THIN_ZHANGSUEN && cp->thin != PRL_THIN_GUOHALL) return PRL_ERR_BAD_ARG;
     if (n_pages < 0 || !d_src || !d_dst || src_step < (size_t)width * channels) return PRL_ERR_BAD_ARG;
+    // the angle search walks (x << 16) fixed-point coordinates, packs points as x | y << 16 and the warp's coordinates
+    // saturate to short: the same limit prl_hip_deskew_batch_device / rotate / houghp enforce
+    if (cp->deskew && std::max(width, height) > 32767) return PRL_ERR_BAD_ARG;
     return PRL_OK;
 }
 
@@ -427,10 +436,7 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
     hipStream_t hs = static_cast<hipStream_t>(stream);
     st = stage_acquire(ctx, hs);  // another stream's chain / host call may still read the area
     if (st != PRL_OK) return st;
-    struct Release {   // records the area's new last use on every exit, error exits included
-        DeviceCtx* c; hipStream_t s;
-        ~Release() { (void)stage_release(c, s); }
-    } release{ctx, hs};
+    StageRelease release{ctx, hs};
 
     // The angle search of deskew (HoughLinesP: one wavefront per page waiting on scattered atomics, seconds per pass) runs
     // for pass k+1 on the side stream, from a helper thread, while the rotation and the other stages of pass k (NL-means:

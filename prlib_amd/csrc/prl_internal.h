@@ -85,6 +85,7 @@ struct EnvKnobs {
     bool flt = true;              // PRL_HIP_FLT=0        forces the integer sum pipeline everywhere
     bool nt_store = true;         // PRL_HIP_NT=0         plain instead of non-temporal mask stores
     int rows_per_seg = 0;         // PRL_HIP_ROWS_PER_SEG (0 = chosen from the batch size)
+    bool tiers = true;            // PRL_HIP_TIERS=0      one segment length for the whole call (A/B of the tiered schedule)
     bool debug = false;           // PRL_HIP_DEBUG
     bool byte_mask = false;       // PRL_HIP_BYTE_MASK    byte instead of bit-plane hand-off to the morphology pass
     int morph_rps = 0, morph_wpb = 1;   // PRL_MORPH_RPS, PRL_MORPH_WPB
@@ -131,6 +132,10 @@ int ensure_stage(DeviceCtx* ctx, size_t bytes);  // caller holds stage_mu
 // (stage_acquire) before the first write and records its own work at the end (stage_release).  Caller holds stage_mu.
 int stage_acquire(DeviceCtx* ctx, hipStream_t stream);
 int stage_release(DeviceCtx* ctx, hipStream_t stream);
+struct StageRelease {   // records the area's new last use on every exit of the scope, error exits included
+    DeviceCtx* c; hipStream_t s;
+    ~StageRelease() { (void)stage_release(c, s); }
+};
 // Host image <-> device staging through the cached pinned bounce buffer (caller holds stage_mu).  hipMemcpy2D from
 // pageable memory runs at ~1 GB/s on this stack; row memcpy into pinned memory + one DMA is an order faster.
 // `pin_off`: byte offset inside the bounce buffer (so an upload and a download can share it).

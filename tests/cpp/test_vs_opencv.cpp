@@ -32,7 +32,13 @@
 #ifndef PRL_WITH_OPENCV
 int main()
 {
-    std::printf("{\"opencv\": null, \"leptonica\": null, \"note\": \"OpenCV headers not found: oracle parity stays unpinned\"}\n");
+#ifdef PRL_OPENCV_BUILD_FAILED
+    std::printf("{\"opencv\": null, \"leptonica\": null, \"why\": \"build_failed\", \"note\": \"OpenCV was found but this program did not "
+                "compile or link against it (tests/cpp/test_vs_opencv.build_error): oracle parity stays unpinned\"}\n");
+#else
+    std::printf("{\"opencv\": null, \"leptonica\": null, \"why\": \"headers_absent\", \"note\": \"OpenCV headers not found: oracle parity "
+                "stays unpinned\"}\n");
+#endif
     return 0;
 }
 #else

@@ -362,3 +362,31 @@ def test_chain_stage_subsets(prl, oracle, cuda_device):
     o = torch.empty((2, 130, 170), dtype=torch.uint8, device=cuda_device)
     assert _capi.lib().prl_hip_chain_batch_device(C.byref(cp), 2, 1, t.data_ptr(), t.stride(0), t.stride(1), 170, 130,
                                                   o.data_ptr(), o.stride(0), o.stride(1), None) == _capi.PRL_ERR_BAD_ARG
+
+
+def test_chain_without_thinning_in_deferred_mode_redoes_overflow_pages(prl, oracle, cuda_device):
+    """with prl_hip_set_deferred_completion(1) the chain's binarize stage reads library-owned scratch, so its
+    flags must be resolved inside the chain.  Page 0 (flat, threshold exactly on the decision boundary) overflows the fix-up
+    list and is redone literally; the second call would overwrite the scratch a late redo would read."""
+    import torch
+    from test_binarize_gpu import _flat_boundary_k, _pages
+
+    w, c = 15, 200
+    k = _flat_boundary_k(c, w, c)
+    gray = [np.full((640, 700), c, np.uint8), _pages((640, 700), ["doc"], seed=29)[0]]
+    other = _pages((640, 700), ["doc", "doc"], seed=31)
+    bgr = lambda g: np.repeat(np.stack(g)[..., None], 3, axis=-1)   # BGR2GRAY of a gray-replicated page is the page
+    t1, t2 = torch.from_numpy(bgr(gray)).to(cuda_device), torch.from_numpy(bgr(other)).to(cuda_device)
+    prl.set_deferred_completion(True)
+    try:
+        got1 = prl.process_pages(t1, 3, prl.SAUVOLA, w, k, 0)
+        got2 = prl.process_pages(t2, 3, prl.SAUVOLA, w, k, 0)      # reuses (overwrites) the staging area of the first call
+        prl.finish(cuda_device)
+        g1, g2 = got1.cpu().numpy(), got2.cpu().numpy()
+    finally:
+        prl.set_deferred_completion(False)
+    po = oracle.make_params(oracle.SAUVOLA, w, k, 0)
+    for got, pages in ((g1, gray), (g2, other)):
+        for i in range(2):
+            want = oracle.binarize(oracle.bgr2gray(bgr([pages[i]])[0]), po)
+            assert np.array_equal(got[i], want), int((got[i] != want).sum())

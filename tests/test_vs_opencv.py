@@ -7,6 +7,9 @@ import pytest
 def _check(rep):
     if rep is None:
         pytest.fail("tests/cpp/test_vs_opencv could not be built or run")
+    if rep.get("opencv") is None and rep.get("why") != "headers_absent":
+        # OpenCV is on the machine (or make / the program itself broke): the pin must not silently look like "no OpenCV"
+        pytest.fail(f"the OpenCV pin did not run: {rep.get('why')}: {rep.get('stderr', '')}")
     if rep.get("opencv") is None:
         pytest.skip("no OpenCV on this machine: the oracle stays parity-unpinned (" + rep.get("note", "") + ")")
     print("oracle vs OpenCV", rep["opencv"], rep)
