@@ -48,8 +48,15 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--check-pages", type=int, default=8,
                     help="pages verified against the oracle after timing (spread over the batch: first, last, evenly between)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: --pages per GPU; strong: --pages in total, split over the ranks by dist.page_range")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "both"],
+                    help="weak: --pages per GPU; strong: --pages in total, split over the ranks by dist.page_range; both (only "
+                         "with --gpus > 1): the weak line is THE line, the strong-scaling measurement rides in it as `strong`")
+    ap.add_argument("--traffic", type=int, default=1,
+                    help="1: measure roofline.traffic in this run - two child passes of this benchmark under rocprofv3 --pmc "
+                         "(FETCH_SIZE, WRITE_SIZE), started before this process touches the GPU (N=1 only); 0: traffic = null")
+    ap.add_argument("--ceilings", type=int, default=1, help="1: time the hand-written read / write / copy kernels on this batch")
+    ap.add_argument("--lib", default=None, help="A/B tooling: load this build of libprlib_hip.so instead of the in-tree one")
+    ap.add_argument("--hooks", type=int, default=0, help="A/B tooling: 1 = load libprlib_hip_testhooks.so (reads the PRL_HIP_* tuning knobs)")
     return ap.parse_args()
 
 
@@ -69,6 +76,47 @@ def spawn_ranks(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
+
+
+def measure_traffic(args):
+    """HBM-side bytes of one k_fused launch, measured NOW on this box (MI355X_MICROARCH.md, HBM / rocprofv3 section): two child
+    runs of this same benchmark under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (the TCC slots do not hold both),
+    counters only, the program itself after `--`.  gfx950: FETCH_SIZE tallies 128-B requests as 64 B (x2), WRITE_SIZE is
+    exact; both are in KiB.  Called before this process has imported torch or touched the GPU.  -> (bytes or None, note)"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="prl_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
+               "--gpus", "1", "--steps", "3", "--warmup", "1", "--pages", str(args.pages), "--size", str(args.size),
+               "--height", str(args.height), "--method", args.method, "--window", str(args.window), "--k", str(args.k),
+               "--morph", str(args.morph), "--mode", args.mode, "--cpu-seconds", "0", "--check-pages", "0", "--traffic", "0",
+               "--ceilings", "0"] + (["--lib", args.lib] if args.lib else []) + (["--hooks", "1"] if args.hooks else [])
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            per = []
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == counter and "k_fused" in row.get("Kernel_Name", ""):
+                            per.append(float(row["Counter_Value"]))
+            if not per:
+                return None, f"{counter}: no k_fused rows (rc {r.returncode}): {(r.stderr or '')[-200:]}"
+            vals[counter] = sum(per) / len(per)
+        except Exception as e:  # (timeout, profiler refused)
+            return None, f"{counter}: {e!r}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0), "2 x FETCH_SIZE + WRITE_SIZE (KiB), rocprofv3 --pmc, separate passes, this run"
 
 
 def cpu_baseline(pages_host, params_oracle, budget_s):
@@ -107,7 +155,19 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
+    if args.scaling == "both" and args.gpus == 1:
+        args.scaling = "weak"
+    elif args.scaling == "weak" and args.gpus > 1:
+        args.scaling = "both"   # N > 1: the weak-scaling line carries the strong-scaling measurement as well (`strong`)
+    traffic, traffic_note = None, "not measured (--traffic 0 or N > 1)"
+    if args.traffic and args.gpus == 1 and args.mode == "auto" and os.environ.get("PRL_BENCH_DRYRUN") != "1":
+        traffic, traffic_note = measure_traffic(args)   # child processes, before anything here touches the GPU
     import torch
+
+    if args.lib or args.hooks:
+        from prlib_amd import _capi as _capi0
+
+        _capi0.use_library(args.lib or _capi0.HOOKS_LIB_PATH)
 
     from prlib_amd import dist as pdist
 
@@ -123,7 +183,9 @@ def main():
         total = pdist.sum_over_ranks(float(len(mine)))
         if rank == 0:
             print(json.dumps({"dryrun": True, "n_gpus": world, "pages_total": int(total), "max_rank_plus_1": slowest,
-                              "first_block": [mine.start, mine.stop], "scaling": args.scaling}), flush=True)
+                              "first_block": [mine.start, mine.stop],
+                              "scaling": "weak" if args.scaling == "both" else args.scaling,
+                              "strong_ride_along": args.scaling == "both"}), flush=True)
         pdist.finish()
         return
     if not torch.cuda.is_available():
@@ -186,21 +248,27 @@ def main():
     kernel_ms = sum(kms) / len(kms)
     stats = prlib_amd.last_stats()
 
-    # measured device-copy ceiling of this box (SURVEY.md §8d asks for it beside the 8 TB/s spec peak): a plain
-    # device-to-device copy of the page batch, bytes read + bytes written over the average of 5 copies
-    copy_gbs = None
-    if rank == 0:
-        flat = torch.empty(min(n_mine * H * W, 1 << 32), dtype=torch.uint8, device=dev)  # (pages may be a pitched view)
-        scratch = torch.empty_like(flat)
-        scratch.copy_(flat)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            scratch.copy_(flat)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        copy_gbs = 2 * flat.numel() * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del scratch, flat
+    # measured ceilings of this box beside the 8 TB/s spec peak: hand-written dwordx4 kernels (16 B per lane,
+    # non-temporal, grid-stride) on THIS batch - read-only (the page batch), write-only (the mask batch), copy (pages -> a scratch
+    # batch) - tools/ubench/stream_probe.hip, not part of the product library
+    ceil = {"measured_read_gbs": None, "measured_write_gbs": None, "measured_copy_gbs": None}
+    if rank == 0 and args.ceilings:
+        so = os.path.join(ROOT, "tools", "ubench", "libstream_probe.so")
+        try:
+            P = C.CDLL(so)
+            P.prl_probe_stream.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+            nbytes = min(pages.numel(), out.numel()) // 16 * 16     # (pitched batches: the whole allocations are streamed)
+            src_t = pages if pages.is_contiguous() else pages.contiguous()
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize(dev)
+            for mode, key, moved in ((0, "measured_read_gbs", nbytes), (1, "measured_write_gbs", nbytes), (2, "measured_copy_gbs", 2 * nbytes)):
+                ms = C.c_float(0)
+                dst_ptr = scratch.data_ptr()
+                if P.prl_probe_stream(mode, src_t.data_ptr(), dst_ptr, nbytes, 5, C.byref(ms)) == 0 and ms.value > 0:
+                    ceil[key] = round(moved / (ms.value * 1e-3) / 1e9, 1)
+            del scratch
+        except OSError:
+            pass
 
     px_per_step_total = total_pages * g.out_w * g.out_h
     bytes_per_px = 3 if method == prlib_amd.WOLFJOLION else 2
@@ -244,16 +312,26 @@ def main():
             n_host = min(n_mine, 64)
             cpu = cpu_baseline(pages[:n_host].cpu().numpy().copy(), po, args.cpu_seconds)
 
+    # --scaling both (N > 1): the same job size as one GPU's weak-scaling share, now split over the ranks (strong scaling);
+    # every rank re-uses the first pages of its batch, the timing protocol is the one above
+    strong = None
+    if args.scaling == "both" and world > 1:
+        s_mine = pdist.page_range(args.pages, world, rank)
+        sp, so_ = pages[: len(s_mine)], out[: len(s_mine)]
+        for _ in range(args.warmup):
+            prlib_amd.binarize(sp, params, out=so_)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            prlib_amd.binarize(sp, params, out=so_)
+        barrier()
+        s_elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+        strong = {"pages_total": args.pages, "pages_per_gpu": len(s_mine), "ms_per_step": round(s_elapsed / args.steps * 1e3, 4),
+                  "value": round(args.pages * g.out_w * g.out_h * args.steps / s_elapsed / 1e6, 1), "unit": "Mpixels/s",
+                  "note": "strong scaling: the job of ONE GPU's weak-scaling share split over all ranks"}
+
     if rank == 0:
         value = px_per_step_total * args.steps / elapsed / 1e6
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        key = f"{args.method}_w{args.window}_{n_mine}x{W}x{H}_{args.mode}"
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(key)
-            except Exception:
-                traffic = None
         line = {
             "metric": "Mpixels/s Sauvola w=31 on batched 4K pages" if (args.method == "sauvola" and args.window == 31)
             else f"Mpixels/s {args.method} w={args.window}",
@@ -264,12 +342,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": "weak" if args.scaling == "both" else args.scaling,
             "vs_baseline": None,
             "dtype": "u8 in/out; exact integer window sums (u32, f32 below 2^24 in interior strips); f32 decision with f64/literal refinement",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.pages} x {W}x{H} u8 pages {'per GPU' if args.scaling == 'weak' else 'in total'}, "
+                "workload": f"{args.pages} x {W}x{H} u8 pages {'in total' if args.scaling == 'strong' else 'per GPU'}, "
                             f"{args.method} k={args.k} w={args.window} morph={args.morph}, mode={args.mode}",
                 "pages_per_gpu": n_mine,
                 "pages_total": total_pages,
@@ -282,16 +360,22 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_note": traffic_note,
                 "kernel": "k_fused" if args.mode == "auto" else "literal chain",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "measured_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
+                "measured_read_gbs": ceil["measured_read_gbs"],
+                "measured_write_gbs": ceil["measured_write_gbs"],
+                "measured_copy_gbs": ceil["measured_copy_gbs"],
+                "frac_of_measured_copy": round(achieved_gbs / ceil["measured_copy_gbs"], 4) if ceil["measured_copy_gbs"] else None,
             },
             "cpu_baseline": cpu,
             "parity": {"checked_pages": checked, "mismatching_pixels": mismatches,
                        "refined_pixels": int(stats.refined_pixels), "exact_pixels": int(stats.exact_pixels),
                        "literal_pages": int(stats.literal_pages), "vs_opencv": vs_opencv, "vs_opencv_why": vs_opencv_why},
         }
+        if strong is not None:
+            line["strong"] = strong
         print(json.dumps(line), flush=True)
     pdist.finish()
 

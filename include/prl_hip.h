@@ -177,11 +177,25 @@ int prl_hip_binarize_host(const prl_binarize_params* p,
 /*
  * A list of n_pages equal-size 1-channel pages in HOST memory (what a caller holding n cv::Mat has,
  * samples/binarizations/binarizeSauvola_sample.cpp:48-53), sharded over the devices of the node: contiguous blocks
- * (prl_hip_page_range), one worker thread + two streams + pinned double buffers per device, results in the caller's
- * buffers in the caller's order.  n_devices: 0 = every visible device.  No collective; returns when all pages are done.
+ * (prl_hip_page_range); per device a three-stage pipeline (upload / kernels / download of neighbouring chunks of pages on
+ * three streams, chunk slots kept between calls), results in the caller's buffers in the caller's order.
+ * n_devices: 0 = every visible device.  No collective; returns when all pages are done.
  */
 int prl_hip_binarize_batch_host(const prl_binarize_params* p, int n_pages, const uint8_t* const* src, size_t src_step,
                                 int width, int height, uint8_t* const* dst, size_t dst_step, int n_devices);
+
+/*
+ * Pinned host memory for a caller's pages.  The reference's callers hold pages as cv::Mat (pageable memory,
+ * samples/binarizations/binarizeSauvola_sample.cpp:48); a Mat header over memory from prl_hip_alloc_host -
+ * cv::Mat(rows, cols, CV_8UC1, ptr, step) - or over memory pinned in place with prl_hip_host_register is moved by the
+ * DMA engines directly: prl_hip_binarize_batch_host detects such pages (hipPointerGetAttributes) and skips its bounce
+ * buffers and the two CPU copies per page.  Pageable pages keep working (bounce path).
+ * prl_hip_host_register page-locks `bytes` at `p` (costs about one copy of them; pays from the second call on).
+ */
+int prl_hip_alloc_host(size_t bytes, void** out);
+int prl_hip_free_host(void* p);
+int prl_hip_host_register(void* p, size_t bytes);
+int prl_hip_host_unregister(void* p);
 
 /* The block of a list of n_items that part `part` of `n_parts` owns (sizes differ by at most one): the split used by
  * prl_hip_binarize_batch_host over devices and by one-process-per-GPU launchers over ranks. */

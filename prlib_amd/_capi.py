@@ -10,8 +10,18 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PRLIB_HIP_SO: load another build of the library (kernel experiments: A/B on one box)
-LIB_PATH = os.environ.get("PRLIB_HIP_SO") or os.path.join(_HERE, "libprlib_hip.so")
+LIB_PATH = os.path.join(_HERE, "libprlib_hip.so")
+# the same library built with -DPRL_TEST_HOOKS (`make -C prlib_amd/csrc hooks`): reads the PRL_HIP_* tuning knobs; loaded only
+# by tests / tools that call use_library(HOOKS_LIB_PATH) before their first call
+HOOKS_LIB_PATH = os.path.join(_HERE, "libprlib_hip_testhooks.so")
+
+
+def use_library(path: str) -> None:
+    """Load another build of the library (tests: the hooks build; tools: A/B of kernel experiments).  Before the first call."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("the library is already loaded")
+    LIB_PATH = os.path.abspath(path)
 
 PRL_OK = 0
 PRL_ERR_EMPTY = 1
@@ -40,7 +50,7 @@ EXPORTED_SYMBOLS = [
     "prl_hip_rotate_out_size", "prl_hip_rotate_batch_device", "prl_hip_houghp_device", "prl_hip_deskew_batch_device",
     "prl_hip_rotate_host", "prl_hip_deskew_host", "prl_hip_chain_max_out_size", "prl_hip_chain_pages_device",
     "prl_hip_binarize_batch_host", "prl_hip_page_range", "prl_hip_binarize_lv_batch_device", "prl_hip_binarize_lv_host",
-    "prl_hip_chain_batch_host",
+    "prl_hip_chain_batch_host", "prl_hip_alloc_host", "prl_hip_free_host", "prl_hip_host_register", "prl_hip_host_unregister",
 ]
 
 
@@ -117,6 +127,10 @@ def lib() -> C.CDLL:
         L.prl_hip_set_profiling.argtypes = [i]
         L.prl_hip_last_kernel_ms.argtypes = [P(C.c_float)]
         L.prl_hip_set_deferred_completion.argtypes = [i]
+        L.prl_hip_alloc_host.argtypes = [sz, P(vp)]
+        L.prl_hip_free_host.argtypes = [vp]
+        L.prl_hip_host_register.argtypes = [vp, sz]
+        L.prl_hip_host_unregister.argtypes = [vp]
         L.prl_hip_finish.argtypes = [vp]
         L.prl_hip_default_params.argtypes = [i, P(BinarizeParams)]
         L.prl_hip_binarize_geometry.argtypes = [P(BinarizeParams), i, i, P(BinarizeGeometry)]

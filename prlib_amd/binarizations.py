@@ -71,16 +71,43 @@ def last_stats() -> BinarizeStats:
     return s
 
 
-def binarize_pages_host(pages, params: BinarizeParams, n_devices: int = 0):
+class PinnedPages:
+    """N x H x W uint8 pages in pinned host memory (prl_hip_alloc_host): `array` is a numpy view; the memory is freed by
+    close() / the context manager.  Pages in such memory are moved by DMA directly (no bounce copies)."""
+
+    def __init__(self, n: int, h: int, w: int):
+        self._ptr = C.c_void_p()
+        _capi.check(_capi.lib().prl_hip_alloc_host(max(1, n * h * w), C.byref(self._ptr)))
+        buf = (C.c_uint8 * (n * h * w)).from_address(self._ptr.value)
+        self.array = np.frombuffer(buf, dtype=np.uint8).reshape(n, h, w)
+
+    def close(self):
+        if self._ptr is not None and self._ptr.value:
+            self.array = None
+            _capi.check(_capi.lib().prl_hip_free_host(self._ptr))
+            self._ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def binarize_pages_host(pages, params: BinarizeParams, n_devices: int = 0, out=None):
     """prl_hip_binarize_batch_host: a list (or N x H x W array) of equal-size uint8 host pages, sharded over the node's
-    GPUs by the library (worker thread + two streams per device).  Returns an N x out_h x out_w array."""
+    GPUs by the library (upload / kernels / download pipelined per device).  Returns an N x out_h x out_w array (`out`, if
+    given - e.g. a PinnedPages array, which the DMA engines then write directly)."""
     pages = [np.ascontiguousarray(p) if p.strides[1] != 1 else p for p in pages]
     n = len(pages)
     h, w = pages[0].shape
     if any(p.shape != (h, w) or p.dtype != np.uint8 for p in pages):
         raise TypeError("expected equal-size uint8 pages")
     g = geometry(params, w, h)
-    out = np.empty((n, g.out_h, g.out_w), dtype=np.uint8)
+    if out is None:
+        out = np.empty((n, g.out_h, g.out_w), dtype=np.uint8)
+    elif out.shape != (n, g.out_h, g.out_w) or out.dtype != np.uint8 or out.strides[2] != 1:
+        raise ValueError("output array has the wrong shape")
     if any(p.strides[0] != pages[0].strides[0] for p in pages):
         pages = [np.ascontiguousarray(p) for p in pages]
     src = (C.c_void_p * n)(*[p.ctypes.data for p in pages])

@@ -869,7 +869,7 @@ size_t r256(size_t v) { return (v + 255) / 256 * 256; }
 // per page in `lines_out` (host).  Synchronises the stream.  The caller holds ctx->ppht_mu (the workspace is ctx->ppht_buf).
 static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int width, int height, int threshold, int line_length,
                       int line_gap, bool otsu, int fixed_thr, std::vector<std::vector<int>>* lines_out, std::vector<int>* thr_out,
-                      hipStream_t stream)
+                      hipStream_t stream, SearchStart* start = nullptr)
 {
     const int numrho = (int)std::lrint((double)(float)((width + height) * 2 + 1));
     const size_t mask_page = r256((size_t)width * height);
@@ -958,8 +958,10 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     a.prio = env_knobs().ppht_prio;
     // three wavefronts per page (shorter critical path per page; equal to one per page once the memory system is the limit)
     const int mw_env = env_knobs().ppht_mw;
+    if (start && start->ev) PRL_HIP_CHECK(hipEventRecord(start->ev, stream));   // the streaming prelude ends here
     if (mw_env == 1 || (mw_env < 0 && n_pages <= kPphtMwMaxPages)) hipLaunchKernelGGL(k_ppht_mw, dim3((unsigned)n_pages), dim3(64 * kMwWaves), 0, stream, a);
     else hipLaunchKernelGGL(k_ppht, dim3((unsigned)n_pages), dim3(64), 0, stream, a);
+    if (start) start->launched();
 
     PRL_HIP_CHECK(hipGetLastError());
     std::vector<unsigned> h_nl((size_t)n_pages);
@@ -995,7 +997,7 @@ int deskew_pages_per_pass(int n_pages, int width, int height)
 
 // First half of prl::deskew on `cnt` pages (cnt <= deskew_pages_per_pass): gray -> Otsu -> HoughLinesP -> angle vote.
 int deskew_find(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
-                int height, DeskewPlan* plan, hipStream_t hs)
+                int height, DeskewPlan* plan, hipStream_t hs, SearchStart* start)
 {
     const size_t gray_page = r256((size_t)width * height);
     std::lock_guard<std::mutex> lk(ctx->ppht_mu);
@@ -1015,7 +1017,7 @@ int deskew_find(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_
     std::vector<std::vector<int>> lines;
     // cv::threshold(..., THRESH_BINARY | THRESH_OTSU) (:224) + findAngle's bitwise_not (:146): points = (p <= otsu)
     st = ppht_pages(ctx, cnt, g, width, height, 100, (int)std::lrint((double)(width / 8.f)), (int)std::lrint(20.0), true, 0, &lines,
-                    nullptr, hs);
+                    nullptr, hs, start);
     if (st != PRL_OK) return st;
     plan->warp.resize(sizeof(WarpPage) * (size_t)cnt);
     plan->wh.resize(2 * (size_t)cnt);

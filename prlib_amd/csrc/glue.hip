@@ -408,27 +408,27 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
     if (st != PRL_OK) return st;
     // Pass schedule (with deskew).  Passes must be large enough for the angle search to run near its full rate (>= ~128 pages) and,
     // when NL-means runs beside the next pass's search, small enough for it to finish inside that search: the search's time per
-    // page grows as passes shrink (it is latency-bound per page), NL-means' does not.  Measured on A4 colour scans: 192 pages per
-    // pass hide NL-means completely (search 1.45 s, pass 1.52 s), 256 leave it 0.3 s past every search, 128 waste search rate;
-    // the remainder goes last (a short tail).  Without the denoise stage there is nothing to balance: 256.
-    std::vector<int> pass_first, pass_cnt;
-    {
-        int first_sz = chunk, main_sz = chunk;
-        if (cp->deskew && env_knobs().chain_overlap) {
-            const int want_main = env_knobs().chain_pass > 0 ? env_knobs().chain_pass : (cp->denoise ? 192 : 256);
-            main_sz = std::min(chunk, want_main);
-            const int want_first = env_knobs().chain_first_pass > 0 ? env_knobs().chain_first_pass : main_sz;
-            first_sz = n_pages >= 3 * want_first ? std::min(main_sz, want_first) : main_sz;
-        }
-        for (int first = 0; first < n_pages;) {
-            int cnt = std::min(first == 0 ? first_sz : main_sz, n_pages - first);
-            if (n_pages - first - cnt > 0 && n_pages - first - cnt < main_sz / 8 && n_pages - first <= chunk) cnt = n_pages - first;  // no tiny last pass
-            pass_first.push_back(first);
-            pass_cnt.push_back(cnt);
-            first += cnt;
-        }
+    // page grows as passes shrink (it is latency-bound per page), NL-means' does not.  The sizes below are STARTING values (A4
+    // colour scans with ~9 % ink: 192 pages per pass hide NL-means completely, 256 leave it 0.3 s past every search); with the
+    // head / body / tail split every pass measures how long its NL-means kernels ran past the search beside them and the
+    // following searches are sized from that (shrink in proportion; creep up while there is slack), so other page sizes and ink
+    // densities find their own balance.  PRL_HIP_CHAIN_PASS fixes the size (no adaptation).  Without denoise: 256, fixed.
+    int first_sz = chunk, main_sz = chunk;
+    bool adaptive = false;
+    if (cp->deskew && env_knobs().chain_overlap) {
+        const int want_main = env_knobs().chain_pass > 0 ? env_knobs().chain_pass : (cp->denoise ? 192 : 256);
+        main_sz = std::min(chunk, want_main);
+        const int want_first = env_knobs().chain_first_pass > 0 ? env_knobs().chain_first_pass : main_sz;
+        first_sz = n_pages >= 3 * want_first ? std::min(main_sz, want_first) : main_sz;
+        adaptive = cp->denoise && env_knobs().chain_overlap == 2 && env_knobs().chain_pass == 0;
     }
-    const int max_cnt = *std::max_element(pass_cnt.begin(), pass_cnt.end());
+    // the largest pass the workspace is sized for (an adaptive schedule may grow by a third)
+    const int max_cnt = std::max(1, std::min({chunk, n_pages, adaptive ? std::max(main_sz, first_sz) * 4 / 3 : std::max(main_sz, first_sz)}));
+    auto next_count = [&](int first) {
+        int cnt = std::min({first == 0 ? first_sz : main_sz, n_pages - first, max_cnt});
+        if (n_pages - first - cnt > 0 && n_pages - first - cnt < main_sz / 8 && n_pages - first <= max_cnt) cnt = n_pages - first;  // no tiny last pass
+        return cnt;
+    };
     if (per_page) {
         st = ensure_stage(ctx, per_page * (size_t)max_cnt);
         if (st != PRL_OK) return st;
@@ -446,19 +446,21 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
         int st = PRL_OK;
         std::string detail;
         DeskewPlan plan;
+        SearchStart start;     // lets this thread's caller wait for the Hough kernel of the search to be under way
+        double seconds = 0.0;  // how long the search took
         void join() { if (th.joinable()) th.join(); }
-        ~Finder() { join(); }
+        ~Finder() { join(); if (start.ev) (void)hipEventDestroy(start.ev); }
     } finder;
-    auto cnt_at = [&](int first) { return pass_cnt[(size_t)(std::lower_bound(pass_first.begin(), pass_first.end(), first) - pass_first.begin())]; };
-    auto start_find = [&](int first) {
-        const int cnt = cnt_at(first);
+    auto start_find = [&](int first, int cnt) {
         finder.st = PRL_OK;
+        finder.start.reset();
         finder.th = std::thread([&, first, cnt] {
+            struct Done { Finder* f; std::chrono::steady_clock::time_point t; ~Done() { f->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); f->start.finish(); } } done{&finder, std::chrono::steady_clock::now()};
             if (hipSetDevice(dev) != hipSuccess) { finder.st = PRL_ERR_NO_DEVICE; return; }
             const auto t0 = std::chrono::steady_clock::now();
             struct Log { decltype(t0) t; int first; ~Log() { if (env_knobs().debug) std::fprintf(stderr, "[prl chain %.3f] angle search of pages %d..: %.3f s\n", std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(), first, std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count()); } } log{t0, first};
             finder.st = deskew_find(ctx, cnt, channels, d_src + (size_t)first * src_page_stride, src_page_stride, src_step, width,
-                                    height, &finder.plan, ctx->side);
+                                    height, &finder.plan, ctx->side, &finder.start);
             if (finder.st != PRL_OK) finder.detail = prl_hip_last_error_detail();
         });
     };
@@ -469,12 +471,28 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
         }
         PRL_HIP_CHECK(hipEventRecord(ctx->side_ev, hs));  // the source pages may come from earlier work on the caller's stream
         PRL_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->side_ev, 0));
-        start_find(0);
+        PRL_HIP_CHECK(hipEventCreateWithFlags(&finder.start.ev, hipEventDisableTiming));
+    }
+    // Beside a search only runs what is enqueued through this: the caller's stream waits (on the device) for the streaming prelude
+    // of the search to be through, the host for its Hough kernel to be submitted - a search that starts next to other kernels is
+    // slowed for good, one whose wavefronts are resident first runs at its own speed.  No wall-clock guesses.
+    auto behind_search_start = [&]() -> int {
+        if (finder.start.wait()) PRL_HIP_CHECK(hipStreamWaitEvent(hs, finder.start.ev, 0));
+        return PRL_OK;
+    };
+    struct EventOwner { hipEvent_t e = nullptr; ~EventOwner() { if (e) (void)hipEventDestroy(e); } } body_done;
+    if (cp->deskew && cp->denoise && env_knobs().chain_overlap == 2) {
+        // the Lab planes of the largest pass, up front: growing the buffer later synchronises the device under a running search
+        st = ensure_buffer(&ctx->chain_planes, &ctx->chain_planes_bytes, denoise_plane_bytes(len, len) * (size_t)max_cnt);
+        if (st != PRL_OK) return st;
     }
     std::vector<int32_t> wh((size_t)max_cnt * 2);
     DeskewPlan plan;
-    for (size_t pi = 0; pi < pass_first.size(); ++pi) {
-        const int first = pass_first[pi], cnt = pass_cnt[pi];
+    int first = 0, cnt = next_count(0);
+    if (cp->deskew) start_find(0, cnt);
+    for (; first < n_pages;) {
+        const int nfirst = first + cnt;
+        int ncnt = 0;   // size of the next pass: fixed when its search starts
         uint8_t* ws = static_cast<uint8_t*>(ctx->stage);
         const uint8_t* cur = d_src + (size_t)first * src_page_stride;
         size_t cur_ps = src_page_stride, cur_step = src_step;
@@ -492,11 +510,11 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
             finder.plan = DeskewPlan();
             const bool overlap = env_knobs().chain_overlap != 0;
             const bool later = env_knobs().chain_overlap == 2 && cp->denoise;   // split mode starts it after the streaming head of the pass
-            if (overlap && !later && first + cnt < n_pages) {
-                start_find(first + cnt);
-                // the first part of a search (every point still votes) saturates the memory system and everything beside it
-                // crawls; this pass's own work fits into the rest of the search, so it can start a little later
-                if (env_knobs().chain_lag_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(env_knobs().chain_lag_ms));
+            if (overlap && !later && nfirst < n_pages) {
+                ncnt = next_count(nfirst);
+                start_find(nfirst, ncnt);
+                st = behind_search_start();   // this pass's own work starts once the search is under way
+                if (st != PRL_OK) return st;
             }
             uint8_t* desk = ws;
             ws = desk + desk_page * (size_t)cnt;
@@ -557,21 +575,39 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
                 st = denoise_convert_in(ctx, run.r1 - run.r0, channels, cur + (size_t)run.r0 * cur_ps, cur_ps, cur_step, run.pw, run.ph, run.planes, hs);
                 if (st != PRL_OK) return st;
             }
-            if (first + cnt < n_pages) {
+            const bool beside = nfirst < n_pages;
+            if (beside) {
                 PRL_HIP_CHECK(hipStreamSynchronize(hs));   // the head is through before the next search takes the memory system
-                start_find(first + cnt);
-                if (env_knobs().chain_lag_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(env_knobs().chain_lag_ms));
+                ncnt = next_count(nfirst);
+                start_find(nfirst, ncnt);
+                st = behind_search_start();
+                if (st != PRL_OK) return st;
             }
             for (Run& run : runs) {   // BODY
                 st = denoise_nlm(ctx, run.r1 - run.r0, cp->denoise_strength, run.planes, run.pw, run.ph, hs);
                 if (st != PRL_OK) return st;
             }
+            if (beside) {
+                if (!body_done.e) PRL_HIP_CHECK(hipEventCreateWithFlags(&body_done.e, hipEventDisableTiming));
+                PRL_HIP_CHECK(hipEventRecord(body_done.e, hs));
+            }
             finder.join();
-            if (env_knobs().debug) {
+            if (beside) {
+                // how the body compared with the search beside it sizes the searches that are still to start
+                const bool early = hipEventQuery(body_done.e) == hipSuccess;
                 const auto tj = std::chrono::steady_clock::now();
-                (void)hipStreamSynchronize(hs);
-                std::fprintf(stderr, "[prl chain] pass at page %d: NL-means ran %.3f s past the search\n", first,
-                             std::chrono::duration<double>(std::chrono::steady_clock::now() - tj).count());
+                if (!early) PRL_HIP_CHECK(hipEventSynchronize(body_done.e));   // (the tail is enqueued behind the body anyway)
+                const double past = early ? 0.0 : std::chrono::duration<double>(std::chrono::steady_clock::now() - tj).count();
+                if (adaptive && finder.seconds > 0.0 && ncnt >= main_sz) {   // (a short last search says nothing about the balance)
+                    const int before = main_sz;
+                    if (past > 0.03 * finder.seconds) main_sz = (int)(main_sz * finder.seconds / (finder.seconds + past)) / 16 * 16;
+                    else if (early) main_sz += 16;
+                    main_sz = std::max(std::min(64, max_cnt), std::min(main_sz, max_cnt));
+                    if (env_knobs().debug && main_sz != before)
+                        std::fprintf(stderr, "[prl chain] pass size %d -> %d (search %.3f s, NL-means %.3f s past it)\n", before, main_sz, finder.seconds, past);
+                }
+                if (env_knobs().debug)
+                    std::fprintf(stderr, "[prl chain] pass at page %d: NL-means ran %.3f s past the search\n", first, past);
             }
             for (Run& run : runs) {   // TAIL
                 prl_binarize_geometry g;
@@ -588,9 +624,10 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
                 if (st != PRL_OK) return st;
             }
         }
-        if (cp->deskew && !env_knobs().chain_overlap && first + cnt < n_pages) {
+        if (cp->deskew && !env_knobs().chain_overlap && nfirst < n_pages) {
             PRL_HIP_CHECK(hipStreamSynchronize(hs));
-            start_find(first + cnt);
+            ncnt = next_count(nfirst);
+            start_find(nfirst, ncnt);
             finder.join();
         }
         if (env_knobs().debug) {
@@ -598,6 +635,8 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
             std::fprintf(stderr, "[prl chain %.3f] pass at page %d (%d pages) done after %.3f s\n", std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(), first, cnt,
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pass).count());
         }
+        first = nfirst;
+        cnt = ncnt > 0 ? ncnt : (first < n_pages ? next_count(first) : 0);
     }
     return PRL_OK;
 }

@@ -3,19 +3,19 @@
 // A PRLib user holds pages as cv::Mat in host memory and calls prl::binarizeSauvola once per page
 // (samples/binarizations/binarizeSauvola_sample.cpp:48-53).  Pages are independent (src/binarizations/binarizeSauvola.cpp:32-134
 // touches only its two Mats), so a list of n pages splits into contiguous blocks, one per device (prl_hip_page_range: the
-// same split prlib_amd/dist.py uses for one-process-per-GPU runs), and inside a device into chunks that alternate between
-// TWO streams with their own pinned and device buffers:
-//
-//     worker thread of device d:   stage chunk k (host memcpy into pinned, `host_copy_threads` threads)
-//                                  stream k%2:  H2D  ->  binarize (enqueue only)                       [GPU works on k]
-//                                  chunk k-1:   prl_hip_finish -> D2H -> copy out to the caller's pages [host works on k-1]
-//
-// so the host copies of one chunk overlap the DMA and the kernels of the other.  No collective, no peer traffic: each
-// device only ever sees its own block.  Results land in the caller's buffers in the caller's order.
-// End to end this path is bound by host memory copies and PCIe, not by the kernels.
+// same split prlib_amd/dist.py uses for one-process-per-GPU runs), and inside a device into chunks that run through a
+// three-stage pipeline (device_worker): upload of chunk k+1, kernels of chunk k, download of chunk k-1, on three streams
+// with four chunk slots that the library keeps between calls.  Pageable pages go through pinned bounce slots (copied by a
+// persistent pool of host threads); pages in pinned memory (prl_hip_alloc_host / prl_hip_host_register, or any
+// hipHostMalloc'ed buffer a cv::Mat header points into) are read and written by the DMA engines directly.
+// No collective, no peer traffic: each device only ever sees its own block.  Results land in the caller's buffers in the
+// caller's order.  End to end this path is bound by PCIe (and, for pageable pages, host memory copies), not by the kernels.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -23,44 +23,222 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "prl_internal.h"
 
 namespace prl_hip {
 namespace {
 
-void copy_pages(int n, size_t row_bytes, int rows, const uint8_t* const* src, size_t src_step, uint8_t* dst_packed, bool to_packed,
-                uint8_t* const* dst_pages, size_t dst_step, int threads)
-{
-    // pages [0, n) between the caller's strided pages and a packed pinned buffer, rows split over `threads`
-    const size_t page_bytes = row_bytes * (size_t)rows;
-    const long long total_rows = (long long)n * rows;
-    auto work = [&](long long r0, long long r1) {
-        for (long long r = r0; r < r1; ++r) {
-            const int pg = (int)(r / rows), y = (int)(r % rows);
-            uint8_t* packed = dst_packed + (size_t)pg * page_bytes + (size_t)y * row_bytes;
-            if (to_packed) std::memcpy(packed, src[pg] + (size_t)y * src_step, row_bytes);
-            else std::memcpy(dst_pages[pg] + (size_t)y * dst_step, packed, row_bytes);
+// ---- a persistent pool of copy threads --------------------------------------------------------------------------------
+// parallel_for(n, f) runs f(0) .. f(n-1) on the pool's threads and the caller; several callers may be inside at once (the
+// upload and the download side of a worker, the workers of several devices): every call waits for its own batch only.
+// Created on first use, sized by PRL_HIP_HOST_COPY_THREADS (default: half of the cores, at most 32), never destroyed (no
+// joins during process teardown); after a fork() the child runs everything on the calling thread.
+class WorkPool {
+public:
+    static WorkPool& get()
+    {
+        static WorkPool* pool = new WorkPool();
+        return *pool;
+    }
+    template <typename F>
+    void parallel_for(int n, F&& f)
+    {
+        if (n <= 0) return;
+        if (n == 1 || workers_.empty() || getpid() != owner_pid_) {
+            for (int i = 0; i < n; ++i) f(i);
+            return;
         }
-    };
-    const int t = (int)std::max<long long>(1, std::min<long long>(threads, total_rows / 256));
-    if (t == 1) { work(0, total_rows); return; }
-    std::vector<std::thread> pool;
-    const long long per = (total_rows + t - 1) / t;
-    for (int i = 1; i < t; ++i) pool.emplace_back(work, std::min(total_rows, i * per), std::min(total_rows, (i + 1) * per));
-    work(0, std::min(total_rows, per));
-    for (auto& th : pool) th.join();
-}
+        Batch b;
+        b.fn = [&](int i) { f(i); };
+        b.n = n;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            batches_.push_back(&b);
+        }
+        cv_.notify_all();
+        work_on(&b);   // the caller helps with its own batch
+        std::unique_lock<std::mutex> lk(mu_);
+        b.done_cv.wait(lk, [&] { return b.finished == b.n; });
+    }
+    int threads() const { return (int)workers_.size() + 1; }
 
-struct Buf {
-    hipStream_t stream = nullptr;
-    uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr;
-    hipEvent_t done = nullptr;
-    int first = 0, count = 0;  // chunk in flight
+private:
+    struct Batch {
+        std::function<void(int)> fn;
+        int n = 0, next = 0, finished = 0;   // guarded by the pool's mutex
+        std::condition_variable done_cv;
+    };
+    void work_on(Batch* only)
+    {
+        for (;;) {
+            Batch* b = nullptr;
+            int i = -1;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                if (only) {
+                    if (only->next < only->n) { b = only; i = b->next++; }
+                    else return;
+                } else {
+                    cv_.wait(lk, [&] {
+                        while (!batches_.empty() && batches_.front()->next >= batches_.front()->n) batches_.pop_front();
+                        return !batches_.empty();
+                    });
+                    b = batches_.front();
+                    i = b->next++;
+                }
+            }
+            b->fn(i);
+            bool last;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                last = ++b->finished == b->n;
+                if (last) b->done_cv.notify_all();   // (under the lock: the batch lives on its caller's stack)
+            }
+        }
+    }
+    WorkPool()
+    {
+        owner_pid_ = getpid();
+        const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
+        int n = env_knobs().host_copy_threads > 0 ? env_knobs().host_copy_threads : (int)std::min(32u, std::max(2u, hc / 2));
+        n = std::max(1, std::min(n, (int)hc));
+        for (int i = 0; i + 1 < n; ++i) workers_.emplace_back([this] { work_on(nullptr); });
+        for (auto& t : workers_) t.detach();
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Batch*> batches_;
+    std::vector<std::thread> workers_;
+    pid_t owner_pid_ = 0;
 };
 
+// pages [0, n) between the caller's strided pages and a packed buffer, in tasks of about a megabyte
+void copy_pages(int n, size_t row_bytes, int rows, const uint8_t* const* src, size_t src_step, uint8_t* dst_packed, bool to_packed,
+                uint8_t* const* dst_pages, size_t dst_step, int /*threads*/)
+{
+    const size_t page_bytes = row_bytes * (size_t)rows;
+    const int rows_per_task = (int)std::max<size_t>(1, ((size_t)1 << 20) / std::max<size_t>(1, row_bytes));
+    const int tasks_per_page = (rows + rows_per_task - 1) / rows_per_task;
+    WorkPool::get().parallel_for(n * tasks_per_page, [&](int t) {
+        const int pg = t / tasks_per_page, y0 = (t % tasks_per_page) * rows_per_task, y1 = std::min(rows, y0 + rows_per_task);
+        uint8_t* packed = dst_packed + (size_t)pg * page_bytes;
+        if (to_packed) {
+            if (src_step == row_bytes) std::memcpy(packed + (size_t)y0 * row_bytes, src[pg] + (size_t)y0 * row_bytes, row_bytes * (size_t)(y1 - y0));
+            else for (int y = y0; y < y1; ++y) std::memcpy(packed + (size_t)y * row_bytes, src[pg] + (size_t)y * src_step, row_bytes);
+        } else {
+            if (dst_step == row_bytes) std::memcpy(dst_pages[pg] + (size_t)y0 * row_bytes, packed + (size_t)y0 * row_bytes, row_bytes * (size_t)(y1 - y0));
+            else for (int y = y0; y < y1; ++y) std::memcpy(dst_pages[pg] + (size_t)y * dst_step, packed + (size_t)y * row_bytes, row_bytes);
+        }
+    });
+}
+
+// Is every page of the list in pinned (hipHostMalloc / hipHostRegister) memory?  Then the DMA engines read and write the
+// caller's pages directly and no byte is copied by the CPU.
+bool pages_pinned(int n, const uint8_t* const* pages, size_t last_byte)
+{
+    for (int i = 0; i < n; ++i) {
+        for (const uint8_t* p : {pages[i], pages[i] + last_byte}) {
+            hipPointerAttribute_t at{};
+            if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+                (void)hipGetLastError();   // (an ordinary malloc'ed pointer is an "invalid value" to the runtime)
+                return false;
+            }
+            if (at.type != hipMemoryTypeHost) return false;
+        }
+    }
+    return true;
+}
+
+// ---- prl_hip_binarize_batch_host: per-device resources, kept between calls (DeviceCtx::host_bin, guarded by host_mu) -------
+// Three streams (upload, kernels, download) and kSlots chunk slots, each with its device pages and - for callers whose pages are
+// pageable memory - pinned bounce buffers.  Allocating these per call cost more than the transfers (and left the
+// per-stream workspaces of two short-lived streams behind on every call).
+struct HostBin {
+    static constexpr int kSlots = 4;
+    hipStream_t up = nullptr, run = nullptr, down = nullptr;
+    struct Slot {
+        uint8_t *pin_in = nullptr, *pin_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+        hipEvent_t ev_up = nullptr, ev_down = nullptr;
+    } slot[kSlots];
+    size_t pin_in_bytes = 0, pin_out_bytes = 0, d_in_bytes = 0, d_out_bytes = 0;   // per slot
+
+    int ensure(size_t d_in_need, size_t d_out_need, size_t pin_in_need, size_t pin_out_need)
+    {
+        if (!up) {
+            PRL_HIP_CHECK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+            PRL_HIP_CHECK(hipStreamCreateWithFlags(&run, hipStreamNonBlocking));
+            PRL_HIP_CHECK(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+            for (auto& s : slot) {
+                PRL_HIP_CHECK(hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+                PRL_HIP_CHECK(hipEventCreateWithFlags(&s.ev_down, hipEventDisableTiming));
+            }
+        }
+        auto grow_dev = [&](uint8_t* Slot::*member, size_t* have, size_t need) -> int {
+            if (*have >= need) return PRL_OK;
+            PRL_HIP_CHECK(hipDeviceSynchronize());
+            for (auto& s : slot) {
+                if (s.*member) PRL_HIP_CHECK(hipFree(s.*member));
+                s.*member = nullptr;
+            }
+            *have = 0;
+            for (auto& s : slot) {
+                hipError_t e = hipMalloc(reinterpret_cast<void**>(&(s.*member)), need);
+                if (e != hipSuccess) { set_error_detail(std::string("host batch: hipMalloc: ") + hipGetErrorString(e)); return e == hipErrorOutOfMemory ? PRL_ERR_NOMEM : PRL_ERR_HIP; }
+            }
+            *have = need;
+            return PRL_OK;
+        };
+        auto grow_pin = [&](uint8_t* Slot::*member, size_t* have, size_t need) -> int {
+            if (*have >= need) return PRL_OK;
+            PRL_HIP_CHECK(hipDeviceSynchronize());
+            for (auto& s : slot) {
+                if (s.*member) PRL_HIP_CHECK(hipHostFree(s.*member));
+                s.*member = nullptr;
+            }
+            *have = 0;
+            for (auto& s : slot) {
+                hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&(s.*member)), need, hipHostMallocDefault);
+                if (e != hipSuccess) { set_error_detail(std::string("host batch: hipHostMalloc: ") + hipGetErrorString(e)); return e == hipErrorOutOfMemory ? PRL_ERR_NOMEM : PRL_ERR_HIP; }
+            }
+            *have = need;
+            return PRL_OK;
+        };
+        int st;
+        if ((st = grow_dev(&Slot::d_in, &d_in_bytes, d_in_need)) != PRL_OK) return st;
+        if ((st = grow_dev(&Slot::d_out, &d_out_bytes, d_out_need)) != PRL_OK) return st;
+        if ((st = grow_pin(&Slot::pin_in, &pin_in_bytes, pin_in_need)) != PRL_OK) return st;
+        if ((st = grow_pin(&Slot::pin_out, &pin_out_bytes, pin_out_need)) != PRL_OK) return st;
+        return PRL_OK;
+    }
+    ~HostBin()
+    {
+        for (hipStream_t s : {up, run, down})
+            if (s) (void)hipStreamSynchronize(s);
+        // the binarizer's per-stream workspace of `run` goes with the stream (prl_hip_release_workspace's job otherwise)
+        for (auto& s : slot) {
+            if (s.pin_in) (void)hipHostFree(s.pin_in);
+            if (s.pin_out) (void)hipHostFree(s.pin_out);
+            if (s.d_in) (void)hipFree(s.d_in);
+            if (s.d_out) (void)hipFree(s.d_out);
+            if (s.ev_up) (void)hipEventDestroy(s.ev_up);
+            if (s.ev_down) (void)hipEventDestroy(s.ev_down);
+        }
+        for (hipStream_t s : {up, run, down})
+            if (s) (void)hipStreamDestroy(s);
+    }
+};
+
+// One device's block of the page list, as a three-stage pipeline over chunks of pages:
+//     uploader thread   chunk k+1:  [pageable: caller pages -> pinned slot (pool threads)]  H2D on `up`
+//     this thread       chunk k  :  binarize on `run` (enqueue), prl_hip_finish (flags, literal redo of an overflowing page)
+//     downloader thread chunk k-1:  D2H on `down`  [pageable: pinned slot -> caller pages (pool threads)]
+// so both DMA directions and both host copies are busy at once.  Pinned caller pages are read and written by the DMA engines
+// directly (no bounce buffers, no CPU copies).
 int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geometry& g, int first, int count,
                   const uint8_t* const* src, size_t src_step, int width, int height, uint8_t* const* dst, size_t dst_step,
-                  int copy_threads)
+                  int /*copy_threads*/)
 {
     if (count == 0) return PRL_OK;
     int st = prl_hip_set_device(dev);
@@ -70,75 +248,114 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
     const size_t in_page = (size_t)width * height, out_page = (size_t)g.out_w * g.out_h;
     const size_t in_pitch_page = (in_page + 255) / 256 * 256, out_pitch_page = (out_page + 255) / 256 * 256;
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, (knobs.host_chunk_mb << 20) / (in_pitch_page + out_pitch_page)));
-    Buf b[2];
-    auto cleanup = [&]() {
-        for (auto& x : b) {
-            if (x.stream) (void)hipStreamSynchronize(x.stream);
-            if (x.pin_in) (void)hipHostFree(x.pin_in);
-            if (x.pin_out) (void)hipHostFree(x.pin_out);
-            if (x.d_in) (void)hipFree(x.d_in);
-            if (x.d_out) (void)hipFree(x.d_out);
-            if (x.done) (void)hipEventDestroy(x.done);
-            if (x.stream) (void)hipStreamDestroy(x.stream);
+    const int n_chunks = (count + chunk - 1) / chunk;
+    const bool pinned_in = pages_pinned(count, src + first, (size_t)(height - 1) * src_step + (size_t)width - 1);
+    const bool pinned_out = pages_pinned(count, dst + first, (size_t)(g.out_h - 1) * dst_step + (size_t)g.out_w - 1);
+
+    DeviceCtx* ctx = device_ctx(dev);
+    std::lock_guard<std::mutex> host_lk(ctx->host_mu);   // one host-list call at a time per device
+    if (!ctx->host_bin) ctx->host_bin = new HostBin();
+    HostBin& hb = *static_cast<HostBin*>(ctx->host_bin);
+    st = hb.ensure(in_pitch_page * (size_t)chunk, out_pitch_page * (size_t)chunk, pinned_in ? 0 : in_page * (size_t)chunk,
+                   pinned_out ? 0 : out_page * (size_t)chunk);
+    if (st != PRL_OK) return st;
+
+    struct Pipe {
+        std::mutex mu;
+        std::condition_variable cv;
+        int uploaded = 0, ran = 0, freed = 0;   // chunks that have passed each stage
+        int err = PRL_OK;
+        std::string detail;
+        void fail(int code, const std::string& d) { { std::lock_guard<std::mutex> lk(mu); if (err == PRL_OK) { err = code; detail = d; } } cv.notify_all(); }
+    } pipe;
+    auto chunk_first = [&](int k) { return first + k * chunk; };
+    auto chunk_count = [&](int k) { return std::min(chunk, count - k * chunk); };
+
+    std::thread uploader([&] {
+        if (hipSetDevice(dev) != hipSuccess) { pipe.fail(PRL_ERR_NO_DEVICE, "uploader: hipSetDevice"); return; }
+        for (int k = 0; k < n_chunks; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(pipe.mu);
+                pipe.cv.wait(lk, [&] { return pipe.err != PRL_OK || k - pipe.freed < HostBin::kSlots; });
+                if (pipe.err != PRL_OK) return;
+            }
+            HostBin::Slot& s = hb.slot[k % HostBin::kSlots];
+            const int f = chunk_first(k), cnt = chunk_count(k);
+            hipError_t e = hipSuccess;
+            if (pinned_in) {
+                for (int i = 0; i < cnt && e == hipSuccess; ++i)
+                    e = hipMemcpy2DAsync(s.d_in + (size_t)i * in_pitch_page, (size_t)width, src[f + i], src_step, (size_t)width, (size_t)height,
+                                         hipMemcpyHostToDevice, hb.up);
+            } else {
+                copy_pages(cnt, (size_t)width, height, src + f, src_step, s.pin_in, true, nullptr, 0, 0);
+                e = hipMemcpy2DAsync(s.d_in, in_pitch_page, s.pin_in, in_page, in_page, (size_t)cnt, hipMemcpyHostToDevice, hb.up);
+            }
+            if (e == hipSuccess) e = hipEventRecord(s.ev_up, hb.up);
+            if (e != hipSuccess) { pipe.fail(PRL_ERR_HIP, std::string("host batch upload: ") + hipGetErrorString(e)); return; }
+            { std::lock_guard<std::mutex> lk(pipe.mu); pipe.uploaded = k + 1; }
+            pipe.cv.notify_all();
         }
-    };
-    auto fail = [&](int code) { cleanup(); return code; };
-#define HB_CHECK(expr)                                                                   \
-    do {                                                                                 \
-        hipError_t e_ = (expr);                                                          \
-        if (e_ != hipSuccess) {                                                          \
-            set_error_detail(std::string(#expr) + ": " + hipGetErrorString(e_));         \
-            return fail(e_ == hipErrorOutOfMemory ? PRL_ERR_NOMEM : PRL_ERR_HIP);       \
-        }                                                                                \
-    } while (0)
-    const int n_buf = count > chunk ? 2 : 1;
-    for (int i = 0; i < n_buf; ++i) {
-        HB_CHECK(hipStreamCreateWithFlags(&b[i].stream, hipStreamNonBlocking));
-        HB_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b[i].pin_in), in_page * (size_t)chunk, hipHostMallocDefault));
-        HB_CHECK(hipHostMalloc(reinterpret_cast<void**>(&b[i].pin_out), out_page * (size_t)chunk, hipHostMallocDefault));
-        HB_CHECK(hipMalloc(reinterpret_cast<void**>(&b[i].d_in), in_pitch_page * (size_t)chunk));
-        HB_CHECK(hipMalloc(reinterpret_cast<void**>(&b[i].d_out), out_pitch_page * (size_t)chunk));
-        HB_CHECK(hipEventCreateWithFlags(&b[i].done, hipEventDisableTiming));
-    }
-    DeferredScope deferred;  // binarize only enqueues; this worker finishes each chunk itself
-    // second half of a chunk's life: flags / literal redo, download, copy out
-    auto drain = [&](Buf& x) -> int {
-        if (x.count == 0) return PRL_OK;
-        int s2 = prl_hip_finish(x.stream);
-        if (s2 != PRL_OK) return s2;
-        if (hipMemcpy2DAsync(x.pin_out, out_page, x.d_out, out_pitch_page, out_page, (size_t)x.count, hipMemcpyDeviceToHost, x.stream) != hipSuccess ||
-            hipStreamSynchronize(x.stream) != hipSuccess) {
-            set_error_detail("host batch: download failed");
-            return PRL_ERR_HIP;
+    });
+    std::thread downloader([&] {
+        if (hipSetDevice(dev) != hipSuccess) { pipe.fail(PRL_ERR_NO_DEVICE, "downloader: hipSetDevice"); return; }
+        auto finalize = [&](int k) -> bool {   // chunk k's D2H has been enqueued: wait for it, hand the pages over, free the slot
+            HostBin::Slot& s = hb.slot[k % HostBin::kSlots];
+            if (hipEventSynchronize(s.ev_down) != hipSuccess) { pipe.fail(PRL_ERR_HIP, "host batch: download failed"); return false; }
+            if (!pinned_out) copy_pages(chunk_count(k), (size_t)g.out_w, g.out_h, nullptr, 0, s.pin_out, false, dst + chunk_first(k), dst_step, 0);
+            { std::lock_guard<std::mutex> lk(pipe.mu); pipe.freed = k + 1; }
+            pipe.cv.notify_all();
+            return true;
+        };
+        for (int k = 0; k < n_chunks; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(pipe.mu);
+                pipe.cv.wait(lk, [&] { return pipe.err != PRL_OK || pipe.ran > k; });
+                if (pipe.err != PRL_OK) return;
+            }
+            HostBin::Slot& s = hb.slot[k % HostBin::kSlots];
+            const int f = chunk_first(k), cnt = chunk_count(k);
+            hipError_t e = hipSuccess;
+            if (pinned_out) {
+                for (int i = 0; i < cnt && e == hipSuccess; ++i)
+                    e = hipMemcpy2DAsync(dst[f + i], dst_step, s.d_out + (size_t)i * out_pitch_page, (size_t)g.out_w, (size_t)g.out_w,
+                                         (size_t)g.out_h, hipMemcpyDeviceToHost, hb.down);
+            } else {
+                e = hipMemcpy2DAsync(s.pin_out, out_page, s.d_out, out_pitch_page, out_page, (size_t)cnt, hipMemcpyDeviceToHost, hb.down);
+            }
+            if (e == hipSuccess) e = hipEventRecord(s.ev_down, hb.down);
+            if (e != hipSuccess) { pipe.fail(PRL_ERR_HIP, std::string("host batch download: ") + hipGetErrorString(e)); return; }
+            if (k > 0 && !finalize(k - 1)) return;   // the copy-out of chunk k-1 runs beside the DMA of chunk k
         }
-        copy_pages(x.count, (size_t)g.out_w, g.out_h, nullptr, 0, x.pin_out, false, dst + x.first, dst_step, copy_threads);
-        x.count = 0;
-        return PRL_OK;
-    };
-    int k = 0;
-    for (int off = 0; off < count; off += chunk, ++k) {
-        Buf& x = b[k % n_buf];
-        st = drain(x);  // the chunk that used this buffer two steps ago
-        if (st != PRL_OK) return fail(st);
-        const int cnt = std::min(chunk, count - off);
-        x.first = first + off;
-        x.count = cnt;
-        copy_pages(cnt, (size_t)width, height, src + x.first, src_step, x.pin_in, true, nullptr, 0, copy_threads);
-        HB_CHECK(hipMemcpy2DAsync(x.d_in, in_pitch_page, x.pin_in, in_page, in_page, (size_t)cnt, hipMemcpyHostToDevice, x.stream));
-        st = prl_hip_binarize_batch_device(p, cnt, x.d_in, in_pitch_page, (size_t)width, width, height, x.d_out, out_pitch_page,
-                                           (size_t)g.out_w, x.stream);
-        if (st != PRL_OK) return fail(st);
-        if (n_buf == 2) {  // while the GPU works on this chunk, finish the other one
-            st = drain(b[(k + 1) % 2]);
-            if (st != PRL_OK) return fail(st);
+        (void)finalize(n_chunks - 1);
+    });
+
+    {
+        DeferredScope deferred;  // binarize only enqueues; prl_hip_finish below closes every chunk
+        for (int k = 0; k < n_chunks; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(pipe.mu);
+                pipe.cv.wait(lk, [&] { return pipe.err != PRL_OK || pipe.uploaded > k; });
+                if (pipe.err != PRL_OK) break;
+            }
+            HostBin::Slot& s = hb.slot[k % HostBin::kSlots];
+            int s2 = hipStreamWaitEvent(hb.run, s.ev_up, 0) == hipSuccess ? PRL_OK : PRL_ERR_HIP;
+            if (s2 == PRL_OK)
+                s2 = prl_hip_binarize_batch_device(p, chunk_count(k), s.d_in, in_pitch_page, (size_t)width, width, height, s.d_out, out_pitch_page,
+                                                   (size_t)g.out_w, hb.run);
+            if (s2 == PRL_OK) s2 = prl_hip_finish(hb.run);   // the chunk's masks are final (and the stream idle) when this returns
+            if (s2 != PRL_OK) { pipe.fail(s2, prl_hip_last_error_detail()); break; }
+            { std::lock_guard<std::mutex> lk(pipe.mu); pipe.ran = k + 1; }
+            pipe.cv.notify_all();
         }
     }
-    for (int i = 0; i < n_buf; ++i) {
-        st = drain(b[i]);
-        if (st != PRL_OK) return fail(st);
+    uploader.join();
+    downloader.join();
+    for (hipStream_t q : {hb.up, hb.run, hb.down}) (void)hipStreamSynchronize(q);   // nothing of this call stays in flight
+    if (pipe.err != PRL_OK) {
+        (void)prl_hip_finish(hb.run);   // drop what the failed call left pending on the kept stream
+        set_error_detail(pipe.detail);
+        return pipe.err;
     }
-#undef HB_CHECK
-    cleanup();
     return PRL_OK;
 }
 
@@ -347,6 +564,8 @@ void host_slots_free(DeviceCtx* ctx)
         delete static_cast<PinSlots*>(ctx->host_slots[i]);
         ctx->host_slots[i] = nullptr;
     }
+    delete static_cast<HostBin*>(ctx->host_bin);
+    ctx->host_bin = nullptr;
 }
 }  // namespace prl_hip
 
@@ -383,11 +602,11 @@ int prl_hip_binarize_batch_host(const prl_binarize_params* p, int n_pages, const
         return PRL_ERR_NO_DEVICE;
     }
     const int real = visible;
+#ifdef PRL_TEST_HOOKS
     visible = std::max(visible, env_knobs().fake_devices);   // tests on a one-GPU box: several workers, all on the real device(s)
+#endif
     const int devs = std::min(n_pages, n_devices == 0 ? visible : std::min(n_devices, visible));
-    // host threads copying pages in / out of pinned memory, per device worker: the knob, bounded by the cores there are
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int copy_threads = std::max(1, std::min(env_knobs().host_copy_threads, hw ? (int)(hw / (unsigned)devs) : 1));
+    const int copy_threads = 0;   // (page copies run on the process-wide WorkPool, shared by the device workers)
     std::vector<int> status((size_t)devs, PRL_OK);
     std::vector<std::string> detail((size_t)devs);
     std::vector<std::thread> workers;
@@ -405,6 +624,48 @@ int prl_hip_binarize_batch_host(const prl_binarize_params* p, int n_pages, const
             set_error_detail("device " + std::to_string(d) + ": " + detail[(size_t)d]);
             return status[(size_t)d];
         }
+    return PRL_OK;
+}
+
+/* Pinned host memory for a caller's pages (a cv::Mat header over it: cv::Mat(rows, cols, CV_8UC1, ptr, step)): the host-list
+ * entries then move such pages by DMA straight from / to the caller's memory. */
+int prl_hip_alloc_host(size_t bytes, void** out)
+{
+    if (!out || bytes == 0) return PRL_ERR_BAD_ARG;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error_detail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? PRL_ERR_NOMEM : PRL_ERR_HIP;
+    }
+    return PRL_OK;
+}
+
+int prl_hip_free_host(void* p)
+{
+    if (!p) return PRL_OK;
+    PRL_HIP_CHECK(hipHostFree(p));
+    return PRL_OK;
+}
+
+/* Pin / unpin memory the caller already owns (page-locks it: costs about as much as copying it once, pays from the second
+ * call on the same buffers on). */
+int prl_hip_host_register(void* p, size_t bytes)
+{
+    if (!p || bytes == 0) return PRL_ERR_BAD_ARG;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    PRL_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return PRL_OK;
+}
+
+int prl_hip_host_unregister(void* p)
+{
+    if (!p) return PRL_ERR_BAD_ARG;
+    PRL_HIP_CHECK(hipHostUnregister(p));
     return PRL_OK;
 }
 
@@ -436,10 +697,11 @@ int prl_hip_chain_batch_host(const prl_chain_params* cp, int n_pages, int channe
         return PRL_ERR_NO_DEVICE;
     }
     const int real = visible;
+#ifdef PRL_TEST_HOOKS
     visible = std::max(visible, env_knobs().fake_devices);
+#endif
     const int devs = std::min(n_pages, n_devices == 0 ? visible : std::min(n_devices, visible));
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int copy_threads = std::max(1, std::min(env_knobs().host_copy_threads, hw ? (int)(hw / (unsigned)devs) : 1));
+    const int copy_threads = 0;   // (page copies run on the process-wide WorkPool, shared by the device workers)
     std::vector<int> status((size_t)devs, PRL_OK);
     std::vector<std::string> detail((size_t)devs);
     std::vector<std::thread> workers;

@@ -50,6 +50,18 @@ const EnvKnobs& env_knobs()
     static const EnvKnobs knobs = [] {
         EnvKnobs k;
         auto geti = [](const char* name, long long dflt) { const char* e = std::getenv(name); return e ? std::atoll(e) : dflt; };
+        // what a user sets: diagnostics, the execution mode, memory budgets, host copy threads
+        k.debug = std::getenv("PRL_HIP_DEBUG") != nullptr;
+        const char* m = std::getenv("PRL_HIP_MODE");
+        k.literal_mode = (m && std::strcmp(m, "literal") == 0) ? 1 : 0;
+        k.literal_scratch_mb = (size_t)std::max(64ll, geti("PRL_HIP_LITERAL_SCRATCH_MB", 8192));
+        k.deskew_work_mb = (size_t)std::max(1ll, geti("PRL_HIP_DESKEW_WORK_MB", 24576));
+        k.chain_work_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_WORK_MB", 49152));
+        k.chain_host_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_HOST_MB", 65536));
+        k.host_chunk_mb = (size_t)std::max(1ll, geti("PRL_HIP_HOST_CHUNK_MB", 128));
+        k.host_copy_threads = (int)std::max(0ll, std::min(64ll, geti("PRL_HIP_HOST_COPY_THREADS", 0)));
+#ifdef PRL_TEST_HOOKS
+        // kernel-selection / schedule knobs of the experiments and tests: only libprlib_hip_testhooks.so (make hooks) reads them
         auto is0 = [](const char* name) { const char* e = std::getenv(name); return e && e[0] == '0'; };
         k.fused_wpb = (int)std::max(1ll, std::min(4ll, geti("PRL_HIP_WPB", 1)));
         k.flt = !is0("PRL_HIP_FLT");
@@ -57,7 +69,6 @@ const EnvKnobs& env_knobs()
         k.rows_per_seg = (int)geti("PRL_HIP_ROWS_PER_SEG", 0);
         if (k.rows_per_seg) k.rows_per_seg = std::max(16, k.rows_per_seg);
         k.tiers = !is0("PRL_HIP_TIERS");
-        k.debug = std::getenv("PRL_HIP_DEBUG") != nullptr;
         k.byte_mask = std::getenv("PRL_HIP_BYTE_MASK") != nullptr;
         k.morph_rps = (int)geti("PRL_MORPH_RPS", 0);
         if (k.morph_rps) k.morph_rps = std::max(8, k.morph_rps);
@@ -67,23 +78,15 @@ const EnvKnobs& env_knobs()
         k.thin_wpb = (int)std::max(1ll, std::min(4ll, geti("PRL_THIN_WPB", 4)));
         k.nlm_xl = (int)geti("PRL_NLM_XL", 3);
         k.nlm_glut = (int)geti("PRL_NLM_GLUT", 0);
-        k.literal_scratch_mb = (size_t)std::max(64ll, geti("PRL_HIP_LITERAL_SCRATCH_MB", 8192));
-        k.deskew_work_mb = (size_t)std::max(1ll, geti("PRL_HIP_DESKEW_WORK_MB", 24576));
         k.ppht_mw = (int)geti("PRL_HIP_PPHT_MW", -1);
         k.ppht_prio = (int)geti("PRL_HIP_PPHT_PRIO", 3);
         k.chain_host_pages = (int)std::max(0ll, geti("PRL_HIP_CHAIN_HOST_PAGES", 0));
-        k.chain_host_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_HOST_MB", 65536));
         k.fake_devices = (int)std::max(0ll, geti("PRL_HIP_FAKE_DEVICES", 0));
         k.chain_pass = (int)std::max(0ll, geti("PRL_HIP_CHAIN_PASS", 0));
         k.chain_first_pass = (int)std::max(0ll, geti("PRL_HIP_CHAIN_FIRST_PASS", 0));
-        k.chain_lag_ms = (int)std::max(0ll, geti("PRL_HIP_CHAIN_LAG_MS", 50));
         k.chain_overlap = (int)geti("PRL_HIP_CHAIN_OVERLAP", 2);
-        k.chain_work_mb = (size_t)std::max(16ll, geti("PRL_HIP_CHAIN_WORK_MB", 49152));
-        k.host_chunk_mb = (size_t)std::max(1ll, geti("PRL_HIP_HOST_CHUNK_MB", 128));
-        k.host_copy_threads = (int)std::max(1ll, std::min(32ll, geti("PRL_HIP_HOST_COPY_THREADS", 8)));
         k.segmax_cap = (unsigned)std::max(64ll, std::min(1ll << 20, geti("PRL_HIP_SEGMAX_CAP", 1 << 20)));
-        const char* m = std::getenv("PRL_HIP_MODE");
-        k.literal_mode = (m && std::strcmp(m, "literal") == 0) ? 1 : 0;
+#endif
         return k;
     }();
     return knobs;

@@ -8,6 +8,7 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <vector>
 #include <string>
@@ -73,13 +74,17 @@ struct DeviceCtx {
     void* host_buf[4] = {nullptr, nullptr, nullptr, nullptr};  // in 0 / 1, out 0 / 1
     size_t host_buf_bytes[4] = {0, 0, 0, 0};
     void* host_slots[2] = {nullptr, nullptr};   // PinSlots of host_batch.hip (replaced when they grow, never freed at exit)
+    void* host_bin = nullptr;                   // HostBin of host_batch.hip: streams and chunk slots of prl_hip_binarize_batch_host (same lock)
     void* chain_planes = nullptr;   // Lab planes of a whole chain pass (split mode of glue.hip; guarded by stage_mu)
     size_t chain_planes_bytes = 0;
     hipStream_t side = nullptr;     // created on first use (non-blocking)
     hipEvent_t side_ev = nullptr;
 };
 
-// Tuning / debugging knobs of the PRL_* environment variables, read ONCE (first use) instead of on every call.
+// Knobs of the PRL_* environment variables, read ONCE (first use) instead of on every call.  The product library reads the
+// user-facing ones (PRL_HIP_DEBUG, PRL_HIP_MODE, the memory budgets *_MB, the copy-thread counts); the kernel-selection and
+// schedule knobs below keep their defaults unless the library is built with -DPRL_TEST_HOOKS (libprlib_hip_testhooks.so,
+// `make hooks`: what tests/ and tools/ load for A/B runs and for forcing rarely taken paths).
 struct EnvKnobs {
     int fused_wpb = 1;            // PRL_HIP_WPB          wavefronts per workgroup of k_fused (1..4)
     bool flt = true;              // PRL_HIP_FLT=0        forces the integer sum pipeline everywhere
@@ -96,8 +101,7 @@ struct EnvKnobs {
     size_t deskew_work_mb = 24576;      // PRL_HIP_DESKEW_WORK_MB
     int ppht_mw = -1;                   // PRL_HIP_PPHT_MW   1 / 0: always / never three wavefronts per page (default: by batch size)
     int ppht_prio = 3;                  // PRL_HIP_PPHT_PRIO=0   k_ppht does not raise its wavefront priority
-    int chain_pass = 0, chain_first_pass = 0;   // PRL_HIP_CHAIN_PASS / PRL_HIP_CHAIN_FIRST_PASS   pages per pass of the chain with deskew (0: 192 with denoise, else 256 / the same)
-    int chain_lag_ms = 50;              // PRL_HIP_CHAIN_LAG_MS   head start of the next pass's search over this pass's NL-means kernels
+    int chain_pass = 0, chain_first_pass = 0;   // PRL_HIP_CHAIN_PASS / PRL_HIP_CHAIN_FIRST_PASS   pages per pass of the chain with deskew (0: start at 192 with denoise, then follow the measured search / NL-means times; else 256)
     int chain_overlap = 2;              // PRL_HIP_CHAIN_OVERLAP   0: passes one after the other; 1: the search of the next pass beside all stages
                                         //                         of this one; 2: beside its NL-means kernels only (head / body / tail, glue.hip)
     size_t chain_work_mb = 49152;       // PRL_HIP_CHAIN_WORK_MB
@@ -105,7 +109,7 @@ struct EnvKnobs {
     int chain_host_pages = 0;           // PRL_HIP_CHAIN_HOST_PAGES   pages per device chunk of prl_hip_chain_batch_host (0: from the budget)
     size_t chain_host_mb = 65536;       // PRL_HIP_CHAIN_HOST_MB      device memory for the page buffers of prl_hip_chain_batch_host
     int fake_devices = 0;               // PRL_HIP_FAKE_DEVICES   (tests) logical devices of the *_batch_host entries, mapped onto the real ones
-    int host_copy_threads = 8;          // PRL_HIP_HOST_COPY_THREADS  host threads per device copying pages in / out of pinned memory (bounded by cores / devices)
+    int host_copy_threads = 0;          // PRL_HIP_HOST_COPY_THREADS  threads of the pool that copies pageable pages in / out of pinned memory (0: half of the cores, at most 32)
     unsigned segmax_cap = 1u << 20;     // PRL_HIP_SEGMAX_CAP   wavefronts per Wolf-Jolion call (tests shrink it)
     int literal_mode = 0;         // PRL_HIP_MODE=literal
 };
@@ -229,8 +233,22 @@ struct DeskewPlan {                   // what the angle search of a pass hands t
     int max_ow = 0, max_oh = 0;
 };
 // gray -> Otsu -> HoughLinesP -> vote on `hs` (synchronises it); own workspace, takes ctx->ppht_mu only
+// Lets a caller order its own work behind the START of the search's long kernel (the Hough transform): deskew_find records
+// `ev` on the search's stream right before it launches that kernel - the event completes when the streaming prelude (gray, Otsu,
+// point lists) is through - and then calls launched().  wait() returns true once that has happened, false when the search
+// ended without getting there (finish() is called by whoever ran deskew_find).
+struct SearchStart {
+    hipEvent_t ev = nullptr;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool recorded = false, done = false;
+    void reset() { std::lock_guard<std::mutex> lk(mu); recorded = done = false; }
+    void launched() { { std::lock_guard<std::mutex> lk(mu); recorded = true; } cv.notify_all(); }
+    void finish() { { std::lock_guard<std::mutex> lk(mu); done = true; } cv.notify_all(); }
+    bool wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return recorded || done; }); return recorded; }
+};
 int deskew_find(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
-                int height, DeskewPlan* plan, hipStream_t hs);
+                int height, DeskewPlan* plan, hipStream_t hs, SearchStart* start = nullptr);
 // prl::rotate of every page by its angle (copy where none was found); takes ctx->mu
 int deskew_apply(DeviceCtx* ctx, const DeskewPlan& plan, int cnt, int channels, const uint8_t* src, size_t src_page_stride,
                  size_t src_step, int width, int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, hipStream_t hs);

@@ -431,6 +431,7 @@ def test_wolfjolion_batches_larger_than_the_per_call_wavefront_budget(cuda_devic
 import numpy as np, torch, sys
 sys.path.insert(0, %r)
 import prlib_amd
+prlib_amd._capi.use_library(prlib_amd._capi.HOOKS_LIB_PATH)   # the build that reads the PRL_HIP_* tuning knobs
 from oracle import capi as oc
 from prlib_amd import synth
 pages = np.stack([synth.page_numpy(200, 1300, index=i) for i in range(12)])
@@ -509,3 +510,41 @@ def test_host_batch_entry_shards_and_double_buffers(prl, oracle, cuda_device):
         assert np.array_equal(got2[i], oracle.binarize(np.ascontiguousarray(pages[i]), oracle.make_params(NICK, 21, -0.1, 0)))
     with pytest.raises(ValueError):
         prl.binarize_pages_host(pages[:2], prl.make_params(SAUVOLA, 30, 0.34, 0))
+
+
+def test_host_batch_entry_pinned_pages_and_repeated_calls(prl, oracle, cuda_device):
+    """Pages in pinned memory (prl_hip_alloc_host) are moved by DMA directly, no bounce copies: same masks as the pageable
+    path and as the oracle; mixed (pinned in / pageable out and the reverse) too.  Repeated calls re-use the per-device
+    streams and chunk slots (each call used to leave two streams' workspaces behind): device memory settles."""
+    import torch
+    from prlib_amd import synth
+
+    n, h, w = 24, 1024, 1536
+    base = [synth.page_numpy(h, w, index=i) for i in range(4)]
+    p = prl.make_params(SAUVOLA, 31, 0.34, 0)
+    po = oracle.make_params(SAUVOLA, 31, 0.34, 0)
+    with prl.PinnedPages(n, h, w) as pin_in, prl.PinnedPages(n, h - 1, w - 1) as pin_out:
+        for i in range(n):
+            pin_in.array[i] = np.roll(base[i % 4], 61 * i, axis=1)
+        pageable = [pin_in.array[i].copy() for i in range(n)]
+        ref = prl.binarize_pages_host(pageable, p, n_devices=1)                     # bounce path
+        got = prl.binarize_pages_host(list(pin_in.array), p, n_devices=1, out=pin_out.array)   # zero-copy both ways
+        assert got is pin_out.array and np.array_equal(got, ref)
+        got2 = prl.binarize_pages_host(list(pin_in.array), p, n_devices=1)          # pinned in, pageable out
+        got3 = prl.binarize_pages_host(pageable, p, n_devices=1, out=pin_out.array)  # pageable in, pinned out
+        assert np.array_equal(got2, ref) and np.array_equal(got3, ref)
+        for i in (0, 7, n - 1):
+            assert np.array_equal(ref[i], oracle.binarize(pageable[i], po))
+        # strided pinned pages (a cv::Mat ROI inside a pinned buffer)
+        with prl.PinnedPages(4, h, w + 128) as wide:
+            views = []
+            for i in range(4):
+                wide.array[i, :, 64:64 + w] = pageable[i]
+                views.append(wide.array[i, :, 64:64 + w])
+            assert np.array_equal(prl.binarize_pages_host(views, p, n_devices=1), ref[:4])
+        free = []
+        for it in range(12):
+            prl.binarize_pages_host(pageable[: 8 + (it % 3) * 8], prl.make_params(SAUVOLA, 31, 0.34, 2 * (it % 2)), n_devices=1)
+            torch.cuda.synchronize(cuda_device)
+            free.append(torch.cuda.mem_get_info(cuda_device)[0] >> 20)
+        assert max(free[4:]) - min(free[4:]) < 64, free

@@ -212,6 +212,7 @@ def test_config5_chain_in_several_passes(prl, oracle, cuda_device, tmp_path, ove
 import numpy as np, torch, sys
 sys.path.insert(0, %r)
 import prlib_amd
+prlib_amd._capi.use_library(prlib_amd._capi.HOOKS_LIB_PATH)   # the build that reads the PRL_HIP_* tuning knobs
 batch = np.load(%r)
 outs, angles = prlib_amd.process_pages(torch.from_numpy(batch).cuda(), 3, prlib_amd.SAUVOLA, 31, 0.34, 0,
                                        denoise_strength=10.0, thin=0, deskew=True, background_normalization=True)
@@ -262,6 +263,7 @@ def test_chain_on_host_pages(prl, oracle, cuda_device):
 import numpy as np, sys
 sys.path.insert(0, %r)
 import prlib_amd
+prlib_amd._capi.use_library(prlib_amd._capi.HOOKS_LIB_PATH)   # the build that reads the PRL_HIP_* tuning knobs
 batch = np.load(%r)
 outs, angles = prlib_amd.process_pages_host(list(batch), prlib_amd.SAUVOLA, 31, 0.34, 0, denoise_strength=10.0, thin=0, deskew=True,
                                             background_normalization=True, n_devices=1)
@@ -301,6 +303,7 @@ def test_host_entries_with_several_device_workers(prl, cuda_device, tmp_path):
 import numpy as np, sys
 sys.path.insert(0, %r)
 import prlib_amd
+prlib_amd._capi.use_library(prlib_amd._capi.HOOKS_LIB_PATH)   # the build that reads the PRL_HIP_* tuning knobs
 gray, col = np.load(%r), np.load(%r)
 b = prlib_amd.binarize_pages_host(list(gray), prlib_amd.make_params(prlib_amd.NICK, 31, -0.1, 1))
 c, a = prlib_amd.process_pages_host(list(col), prlib_amd.SAUVOLA, 31, 0.34, 0, denoise_strength=10.0, thin=0, deskew=True,

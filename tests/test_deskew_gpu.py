@@ -89,6 +89,7 @@ def test_single_wavefront_kernel_gives_the_same_segments():
 import numpy as np, torch, sys
 sys.path.insert(0, %r)
 import prlib_amd
+prlib_amd._capi.use_library(prlib_amd._capi.HOOKS_LIB_PATH)   # the build that reads the PRL_HIP_* tuning knobs
 from prlib_amd import synth
 from oracle import capi as oc
 bad = 0

@@ -115,7 +115,7 @@ def test_bench_launcher_path_two_ranks_dryrun():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d == {"dryrun": True, "n_gpus": 2, "pages_total": 10, "max_rank_plus_1": 2.0, "first_block": [0, 5],
-                 "scaling": "weak"}
+                 "scaling": "weak", "strong_ride_along": True}   # N > 1: the weak line also carries the strong-scaling measurement
 
 
 def _run_bench(argv, extra_env=None):
@@ -140,7 +140,7 @@ def test_bench_gpus_flag_spawns_its_own_ranks():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d == {"dryrun": True, "n_gpus": 2, "pages_total": 7, "max_rank_plus_1": 2.0, "first_block": [0, 4],
-                 "scaling": "strong"}
+                 "scaling": "strong", "strong_ride_along": False}
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():

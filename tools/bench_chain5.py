@@ -44,6 +44,8 @@ ap.add_argument("--stage-pages", type=int, default=64)
 ap.add_argument("--repeat", type=int, default=1, help="run the one-call chain this many times (the first call allocates the workspaces)")
 ap.add_argument("--host", type=int, default=0, help="also time prl_hip_chain_batch_host on the same pages in host memory (end to end)")
 ap.add_argument("--check-pages", type=int, default=0, help="pages compared with the composed CPU oracle (slow: NL-means on the host)")
+ap.add_argument("--cpu-pages", type=int, default=-1, help="pages of the CPU baseline leg: the composed oracle chain on that many of the same pages, "
+                "run side by side on all host cores (-1: one page per 32 cores, at least 2; 0: skip)")
 a = ap.parse_args()
 world, rank, local_rank = pdist.init()
 if world != a.gpus:
@@ -128,6 +130,31 @@ if a.host and world == 1:
     same = bool(np.array_equal(h_ang, angles)) and all(np.array_equal(h_out[i], outs[i].cpu().numpy()) for i in range(0, a.pages, max(1, a.pages // 8)))
     res["host_pages_end_to_end"] = {"s": round(t_host, 3), "pages_per_s": round(a.pages / t_host, 2),
                                     "input_Mpx_s": round(px_in / t_host / 1e6, 1), "equals_device_entry": same}
+if a.cpu_pages != 0 and world == 1:
+    # CPU baseline beside the number: the oracle's stages composed on the host, several pages side by side so
+    # that every core is busy (the Hough transform and the thinning are single-threaded per page, NL-means takes the threads
+    # it is given); pages per second over the wall time of the sample
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import capi as oc
+    cores = os.cpu_count() or 1
+    n_cpu = a.cpu_pages if a.cpu_pages > 0 else max(2, cores // 32)
+    n_cpu = min(n_cpu, a.pages)
+    per = max(1, cores // n_cpu)
+    sample = [np.ascontiguousarray(pages[i].cpu().numpy()) for i in np.linspace(0, a.pages - 1, n_cpu).round().astype(int)]
+    def one(pg):
+        cur, info = oc.deskew(pg)
+        cur = oc.denoise(np.ascontiguousarray(cur), a.strength, threads=per)
+        cur = oc.bgnorm(np.ascontiguousarray(cur))
+        cur = oc.bgr2gray(np.ascontiguousarray(cur)) if cur.ndim == 3 else cur
+        mask = oc.binarize(np.ascontiguousarray(cur), oc.make_params(oc.SAUVOLA, a.window, 0.34, 0))
+        return oc.thin(255 - mask, 0).shape
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(n_cpu) as ex:
+        list(ex.map(one, sample))
+    tc = time.perf_counter() - t0
+    res["cpu_baseline"] = {"value": round(n_cpu / tc, 3), "unit": "pages/s", "cores": cores, "kind": "port",
+                           "sample": f"{n_cpu} of the benchmark's pages through the composed oracle chain, side by side, {per} OpenMP threads each for NL-means, {tc:.1f} s"}
+    res["speedup_vs_cpu_baseline"] = round(res["pages_per_s"] / max(res["cpu_baseline"]["value"], 1e-9), 1)
 if a.check_pages:
     from oracle import capi as oc
     bad = 0

@@ -12,6 +12,7 @@ ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--strength", type=float, default=10.0)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--check", type=int, default=0)
+ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (oracle NL-means on crops of the same scans, all host cores; 0 = skip)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 gray = synth.pages_torch(a.pages, a.size, a.size, dev)
@@ -46,6 +47,22 @@ res["alu_roofline"] = {"bound": "lds", "valu_wave_instr_per_px": round(VALU_WAVE
                        "lds_active_cycles_per_px": round(LDS_ACTIVE_CYCLES_PER_PX, 1),
                        "lds_frac": round(LDS_ACTIVE_CYCLES_PER_PX * px / dt / (256 * 2.4e9), 3),   # of 256 CUs x 2.4 GHz
                        "source": "profiles/r02/pmc_nlm.txt"}
+if a.cpu_seconds > 0:
+    # CPU baseline beside the number: the oracle's prl::denoise (oracle/prl_oracle_nlm.c, OpenMP over rows) on crops
+    # of the same scans with every host core, for about --cpu-seconds; extrapolation: NL-means costs the same per pixel everywhere
+    from oracle import capi as oc
+    cores = os.cpu_count() or 1
+    side = 1024
+    crop = img[0, :side, :side].cpu().numpy().copy()
+    t0 = time.perf_counter(); oc.denoise(crop, a.strength, threads=cores); t1 = time.perf_counter() - t0
+    reps, tn = 1, t1
+    while tn < a.cpu_seconds and reps < 64:
+        crop = img[reps % a.pages, :side, :side].cpu().numpy().copy()
+        t0 = time.perf_counter(); oc.denoise(crop, a.strength, threads=cores); tn += time.perf_counter() - t0
+        reps += 1
+    res["cpu_baseline"] = {"value": round(reps * side * side / tn / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+                           "sample": f"{reps} crops of {side}x{side}x3 of the benchmark's scans, oracle/prl_oracle_nlm.c with {cores} OpenMP threads, {tn:.1f} s"}
+    res["speedup_vs_cpu_baseline"] = round(res["Mpixels/s"] / max(res["cpu_baseline"]["value"], 1e-9), 1)
 if a.check:
     from oracle import capi as oc
     sub = img[0, :256, :256].cpu().numpy().copy()

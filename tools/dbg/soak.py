@@ -16,6 +16,7 @@ for it in range(15):
         host = [p for p in pages[:16].cpu().numpy()]
         prlib_amd.process_pages_host(host, prlib_amd.SAUVOLA, 31, 0.34, 0, denoise_strength=10.0, thin=0, deskew=True, background_normalization=True, n_devices=1)
     g = prlib_amd.cvtColorBGR2GRAY(pages)
+    prlib_amd.binarize_pages_host([q for q in g[: 8 + 8 * (it % 3)].cpu().numpy()], prlib_amd.make_params(prlib_amd.SAUVOLA, 31, 0.34, 2 * (it % 2)), n_devices=1)
     prlib_amd.binarize(g, prlib_amd.make_params(prlib_amd.WOLFJOLION, 31, 0.3, 2))
     prlib_amd.binarizeByLocalVariances(pages[:8])
     del pages, outs, g

@@ -7,7 +7,7 @@ out=gpurun_out/probe_fused.jsonl
 for tag in ${PROBE_TAGS:-shipped probe1 probe2 probe3 probe4 probe5 shipped_again}; do
   so=prlib_amd/libprlib_hip.so
   case $tag in probe*) so=tools/probe_build/libprlib_$tag.so;; esac
-  line=$(PRLIB_HIP_SO=$PWD/$so python bench.py --steps 10 --warmup 3 --cpu-seconds 0 --check-pages 0 2>/dev/null | tail -1)
+  line=$(python3 bench.py --lib $PWD/$so --traffic 0 --ceilings 0 --steps 10 --warmup 3 --cpu-seconds 0 --check-pages 0 2>/dev/null | tail -1)
   echo "{\"build\": \"$tag\", \"line\": $line}" >> $out
 done
 python - <<'PY'

@@ -4,7 +4,7 @@ cd "$(dirname "$0")/../.."
 ARGS=$1; shift
 for round in 1 2; do
   for so in "$@"; do
-    line=$(PRLIB_HIP_SO=$PWD/$so python3 bench.py $ARGS --cpu-seconds 0 --check-pages 2 2>/dev/null | tail -1)
+    line=$(python3 bench.py $ARGS --lib $PWD/$so --traffic 0 --ceilings 0 --cpu-seconds 0 --check-pages 2 2>/dev/null | tail -1)
     echo "$line" | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$so', 'ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms'], 'frac', d['roofline']['frac'], 'mismatch', d['parity']['mismatching_pixels'])"
   done
