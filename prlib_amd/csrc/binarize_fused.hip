@@ -32,18 +32,6 @@
 #include "prl_device_math.h"
 #include "prl_internal.h"
 
-// PRL_PROBE (experiment builds only, never the shipped library; DESIGN.md 4.1 "speed-of-light probes"): every strip runs the
-// float32 loop with clamped columns and parts of the loop are cut out, so the result is wrong but the time of what is
-// left is measurable: 1 = no decision (loads, slide, prefix, exchange, trivial store), 2 = no sums (compared-pixel load,
-// decision on the warm-up sums, store), 3 = loads and store only, 4 = all arithmetic but only the entering-row stream
-// (the leaving row and the compared pixels are faked from registers: what an on-chip row ring could reach at this occupancy),
-// 5 = as 4 but the compared-pixel stream is kept (leaving row faked only), 6 = as 4 without the entering-row stream either
-// (no loads in the row loop: the arithmetic and the mask store alone; PRL_PROBE_LDS=<bytes> of dynamic LDS per wavefront
-// lowers the occupancy to what an on-chip row ring would leave).
-#ifndef PRL_PROBE
-#define PRL_PROBE 0
-#endif
-
 namespace prl_hip {
 
 namespace {
@@ -672,15 +660,9 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     constexpr bool SWEEP_A = METHOD == kWolfMax;  // Wolf-Jolion's variance-maximum sweep: sums and K~ only, no decision
     const ThrParams& tp = fp.tp;
     const int H = tp.height, h = tp.half, w = tp.w;
-#if PRL_PROBE
-    const int col0 = clampi(xs + 1 - h + CPL * lane, 0, tp.width - 8);
-    const int x0 = xs + CPL * lane;
-    const bool lane_has_out = CPL * lane < fp.uo && x0 + CPL <= tp.ow;
-#else
     const int col0 = xs + 1 - h + CPL * lane;  // image column of this lane's sub-column 0 (interior: no clamp)
     const int x0 = xs + CPL * lane;            // first output column of this lane
     const bool lane_has_out = CPL * lane < fp.uo;  // interior strips: every output column exists
-#endif
     const int far_addr0 = (lane + LO) * 4, far_addr1 = far_addr0 + 4;
     const i32x4 rsrc = page_rsrc(img);
     const int step = (int)istep;
@@ -695,13 +677,6 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         if (!SWEEP_A) return;
         pmin = fminf(fminf(pmin, fminf(v.v[0], v.v[1])), fminf(fminf(v.v[2], v.v[3]), fminf(fminf(v.v[4], v.v[5]), fminf(v.v[6], v.v[7]))));
     };
-#if PRL_PROBE == 2
-    {   // no warm-up either: plausible constant sums (kept out of the compiler's sight by the lane id)
-        const F8 v = load_win(ys + 1);
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) { VS[c] = 190000.0f + v.v[c]; VQ[c] = 4.1e7f + 3.0f * v.v[c]; }
-    }
-#else
 #pragma unroll 2
     for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
         const F8 v = load_win(pr);
@@ -712,7 +687,6 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             VQ[c] = fmaf(v.v[c], v.v[c], VQ[c]);
         }
     }
-#endif
 
     // Loads are issued where their destination registers have just died, one iteration ahead of their use: the
     // compared pixels of the next row right after this row's decision, the next entering and leaving rows right
@@ -733,10 +707,6 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     for (int y = ys; y < ye; ++y) {
         track_min(vnew);
         float Ssum[CPL], Qsum[CPL];
-#if PRL_PROBE >= 2
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) { Ssum[c] = VS[c]; Qsum[c] = VQ[c]; }
-#else
         float ES[CPL], EQ[CPL], tot_s, tot_q;
         {
             float accs = VS[0], accq = VQ[0];  // (not 0 + VS[0]: the compiler keeps a float add of +0)
@@ -771,7 +741,6 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         for (int c = 0; c < CPL; ++c) Ssum[c] = (Ssum[c] - ES[c]) + ((c + SH) >= 8 ? w1s : w0s);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) Qsum[c] = (Qsum[c] - EQ[c]) + ((c + SH) >= 8 ? w1q : w0q);
-#endif  // PRL_PROBE >= 2
 
         if constexpr (SWEEP_A) {
 #pragma unroll
@@ -788,16 +757,6 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         for (int c = 0; c < CPL; ++c) pv.v[c] = (float)byte_of(pvb, c);
         float tn[CPL];
         float tmin = 3.0e38f, vmin = 3.0e38f;
-#if PRL_PROBE == 1 || PRL_PROBE == 3
-        // no decision: fold the 16 sums and the compared pixels into the two mask words with 2-cycle integer ops
-        unsigned lo = pvb.x, hi = pvb.y;
-#pragma unroll
-        for (int c = 0; c < CPL; c += 2) {
-            lo ^= __float_as_uint(Ssum[c]) ^ __float_as_uint(Qsum[c]);
-            hi ^= __float_as_uint(Ssum[c + 1]) ^ __float_as_uint(Qsum[c + 1]);
-        }
-        tmin = 3.0e38f; vmin = 3.0e38f; tn[0] = 0.0f;
-#else
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const float P2 = fmaf(pv.v[c], kZ, pk.p0);
@@ -807,7 +766,6 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             vmin = fminf(vmin, v32);
         }
         unsigned lo = pack_signs(tn[0], tn[1], tn[2], tn[3]), hi = pack_signs(tn[4], tn[5], tn[6], tn[7]);
-#endif
 
         if (!FAST && fp.need_p0) {
             // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative); on the packed bytes
@@ -860,51 +818,21 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         }
 
         pv_ptr += istep;  // row y + 1 <= H - 1 exists for every output row
-#if PRL_PROBE == 4 || PRL_PROBE == 6
-        pvb = make_uint2(__float_as_uint(vold.v[0]) >> 12, __float_as_uint(vold.v[5]) >> 11);  // no compared-pixel fetch
-#else
         pvb = gload8(pv_ptr);
-#endif
         }  // !SWEEP_A
 
         // slide the window one row down: new^2 - old^2 = (new - old)(new + old), one exact fma
-#if PRL_PROBE == 2
-        // no sums: the window rows are not even fetched
-#elif PRL_PROBE == 3
-        // loads only: the fetched rows are made live with one 2-cycle op per value (VS / VQ feed the store)
-#pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            VS[c] = __uint_as_float(__float_as_uint(VS[c]) ^ __float_as_uint(vnew.v[c]));
-            VQ[c] = __uint_as_float(__float_as_uint(VQ[c]) ^ __float_as_uint(vold.v[c]));
-        }
-#else
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const float d = vnew.v[c] - vold.v[c], sm = vnew.v[c] + vold.v[c];
             VS[c] += d;
             VQ[c] = fmaf(d, sm, VQ[c]);
         }
-#endif
-#if PRL_PROBE != 2
         off_new = min(off_new + step, off_last);
         off_old_raw += step;
         off_old = max(off_old_raw, 0);
-#if PRL_PROBE >= 4
-        {
-            const F8 prev = vnew;
-#if PRL_PROBE == 6
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) vnew.v[c] = vold.v[(c + 3) & 7];  // no fetch at all: pure arithmetic + the mask store
-#else
-            vnew = tload8(rsrc, col0, off_new);
-#endif
-            vold = prev;  // no leaving-row fetch
-        }
-#else
         vnew = tload8(rsrc, col0, off_new);
         vold = tload8(rsrc, col0, off_old);  // (a non-temporal hint on this last use of the row measured 2 % slower)
-#endif
-#endif
     }
     if (SWEEP_A) {
 #pragma unroll
@@ -993,7 +921,7 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     const int first_col = xs + 1 - tp.half;
     const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
     constexpr bool kFloatOk = METHOD != kWolfCollect;  // (sweep B revisits few segments and queues exact candidates: integer)
-    if ((interior || PRL_PROBE) && kFloatOk && !WIDE && fp.flt) {
+    if (interior && kFloatOk && !WIDE && fp.flt) {
         // (wave-uniform dispatch, once per wavefront: the row loop itself is branch-free in the usual configuration)
         const bool fast = !fp.bit_out && fp.nt_store && !fp.need_p0;
 #define PRL_FLT_LOOP(LOV)                                                                                                          \
@@ -1318,16 +1246,12 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     const unsigned blocks = 8u * ((fp.xcd_waves + wpb - 1) / wpb);   // each XCD: its share of every tier
     const dim3 grid(blocks), block(64 * wpb);
     const bool wide = fp.tp.w - 1 > 181;  // S no longer fits the mantissa of 2^23 (eval32)
-    size_t dyn_lds = 0;
-#if PRL_PROBE
-    if (const char* e = std::getenv("PRL_PROBE_LDS")) dyn_lds = (size_t)std::atoll(e);
-#endif
 #define PRL_LAUNCH_FUSED(SHV)                                                                                    \
     do {                                                                                                         \
         if (wide)                                                                                                \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, true>), grid, block, dyn_lds, stream, src, dst, fp, g, rl, cand, cnt);    \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, true>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);    \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, false>), grid, block, dyn_lds, stream, src, dst, fp, g, rl, cand, cnt);   \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, false>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);   \
     } while (0)
     switch (sh) {
     case 0: PRL_LAUNCH_FUSED(0); break;
@@ -1573,6 +1497,12 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         int rps = 128;
         if (waves_at(128) < 40000 && tp.w - 1 <= 64) rps = 64;   // (64 A4 pages, w=101: 128 rows 0.78 ms, 64 rows 0.80)
         while (rps > min_rps && waves_at(rps) < 4096) rps /= 2;  // small batches: halve while the chip is far from full
+        // a few rounds of the chip's wavefront slots: make it a WHOLE number of rounds (32 x 4K pages: 64 rows = 3.6 rounds, the
+        // last one 60 % full, 0.462 ms; 58 rows = 71 segments per strip = 3.99 rounds: profiles/r03/strong_proxy.txt)
+        if (waves_at(rps) > slots && waves_at(rps) < 12 * slots) {
+            const long long rounds = (waves_at(rps) + slots / 2) / slots, segs = rounds * slots / PS;
+            if (segs >= 1) rps = std::max(min_rps, (int)((tp.oh + segs - 1) / segs));
+        }
         if (env_knobs().rows_per_seg) rps = env_knobs().rows_per_seg;  // tuning knob
         while ((unsigned long long)waves_at(rps) > wave_cap && rps < tp.oh) rps *= 2;  // (Wolf: one sweep-A maximum per wavefront)
         single_tier(rps);

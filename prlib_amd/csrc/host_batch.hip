@@ -260,6 +260,11 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
                    pinned_out ? 0 : out_page * (size_t)chunk);
     if (st != PRL_OK) return st;
 
+    struct Clock {   // PRL_HIP_DEBUG: where each of the three threads spends the call
+        double wait = 0, copy = 0, dma = 0, run = 0;
+        static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    } clk_up, clk_run, clk_down;
+    const bool dbg = knobs.debug;
     struct Pipe {
         std::mutex mu;
         std::condition_variable cv;
@@ -274,22 +279,29 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
     std::thread uploader([&] {
         if (hipSetDevice(dev) != hipSuccess) { pipe.fail(PRL_ERR_NO_DEVICE, "uploader: hipSetDevice"); return; }
         for (int k = 0; k < n_chunks; ++k) {
+            double t0 = dbg ? Clock::now() : 0;
             {
                 std::unique_lock<std::mutex> lk(pipe.mu);
                 pipe.cv.wait(lk, [&] { return pipe.err != PRL_OK || k - pipe.freed < HostBin::kSlots; });
                 if (pipe.err != PRL_OK) return;
             }
+            if (dbg) { const double t1 = Clock::now(); clk_up.wait += t1 - t0; t0 = t1; }
             HostBin::Slot& s = hb.slot[k % HostBin::kSlots];
             const int f = chunk_first(k), cnt = chunk_count(k);
             hipError_t e = hipSuccess;
             if (pinned_in) {
-                for (int i = 0; i < cnt && e == hipSuccess; ++i)
-                    e = hipMemcpy2DAsync(s.d_in + (size_t)i * in_pitch_page, (size_t)width, src[f + i], src_step, (size_t)width, (size_t)height,
-                                         hipMemcpyHostToDevice, hb.up);
+                for (int i = 0; i < cnt && e == hipSuccess; ++i) {
+                    // (a page with dense rows is ONE transfer: the 2-D form moved a 4096-row page in 37 ms, row by row)
+                    if (src_step == (size_t)width) e = hipMemcpyAsync(s.d_in + (size_t)i * in_pitch_page, src[f + i], in_page, hipMemcpyHostToDevice, hb.up);
+                    else e = hipMemcpy2DAsync(s.d_in + (size_t)i * in_pitch_page, (size_t)width, src[f + i], src_step, (size_t)width, (size_t)height,
+                                              hipMemcpyHostToDevice, hb.up);
+                }
             } else {
                 copy_pages(cnt, (size_t)width, height, src + f, src_step, s.pin_in, true, nullptr, 0, 0);
+                if (dbg) { const double t1 = Clock::now(); clk_up.copy += t1 - t0; t0 = t1; }
                 e = hipMemcpy2DAsync(s.d_in, in_pitch_page, s.pin_in, in_page, in_page, (size_t)cnt, hipMemcpyHostToDevice, hb.up);
             }
+            if (dbg) { const double t1 = Clock::now(); clk_up.dma += t1 - t0; t0 = t1; }
             if (e == hipSuccess) e = hipEventRecord(s.ev_up, hb.up);
             if (e != hipSuccess) { pipe.fail(PRL_ERR_HIP, std::string("host batch upload: ") + hipGetErrorString(e)); return; }
             { std::lock_guard<std::mutex> lk(pipe.mu); pipe.uploaded = k + 1; }
@@ -300,25 +312,32 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
         if (hipSetDevice(dev) != hipSuccess) { pipe.fail(PRL_ERR_NO_DEVICE, "downloader: hipSetDevice"); return; }
         auto finalize = [&](int k) -> bool {   // chunk k's D2H has been enqueued: wait for it, hand the pages over, free the slot
             HostBin::Slot& s = hb.slot[k % HostBin::kSlots];
+            double t0 = dbg ? Clock::now() : 0;
             if (hipEventSynchronize(s.ev_down) != hipSuccess) { pipe.fail(PRL_ERR_HIP, "host batch: download failed"); return false; }
+            if (dbg) { const double t1 = Clock::now(); clk_down.dma += t1 - t0; t0 = t1; }
             if (!pinned_out) copy_pages(chunk_count(k), (size_t)g.out_w, g.out_h, nullptr, 0, s.pin_out, false, dst + chunk_first(k), dst_step, 0);
+            if (dbg) clk_down.copy += Clock::now() - t0;
             { std::lock_guard<std::mutex> lk(pipe.mu); pipe.freed = k + 1; }
             pipe.cv.notify_all();
             return true;
         };
         for (int k = 0; k < n_chunks; ++k) {
+            const double tw = dbg ? Clock::now() : 0;
             {
                 std::unique_lock<std::mutex> lk(pipe.mu);
                 pipe.cv.wait(lk, [&] { return pipe.err != PRL_OK || pipe.ran > k; });
                 if (pipe.err != PRL_OK) return;
             }
+            if (dbg) clk_down.wait += Clock::now() - tw;
             HostBin::Slot& s = hb.slot[k % HostBin::kSlots];
             const int f = chunk_first(k), cnt = chunk_count(k);
             hipError_t e = hipSuccess;
             if (pinned_out) {
-                for (int i = 0; i < cnt && e == hipSuccess; ++i)
-                    e = hipMemcpy2DAsync(dst[f + i], dst_step, s.d_out + (size_t)i * out_pitch_page, (size_t)g.out_w, (size_t)g.out_w,
-                                         (size_t)g.out_h, hipMemcpyDeviceToHost, hb.down);
+                for (int i = 0; i < cnt && e == hipSuccess; ++i) {
+                    if (dst_step == (size_t)g.out_w) e = hipMemcpyAsync(dst[f + i], s.d_out + (size_t)i * out_pitch_page, out_page, hipMemcpyDeviceToHost, hb.down);
+                    else e = hipMemcpy2DAsync(dst[f + i], dst_step, s.d_out + (size_t)i * out_pitch_page, (size_t)g.out_w, (size_t)g.out_w,
+                                              (size_t)g.out_h, hipMemcpyDeviceToHost, hb.down);
+                }
             } else {
                 e = hipMemcpy2DAsync(s.pin_out, out_page, s.d_out, out_pitch_page, out_page, (size_t)cnt, hipMemcpyDeviceToHost, hb.down);
             }
@@ -332,11 +351,13 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
     {
         DeferredScope deferred;  // binarize only enqueues; prl_hip_finish below closes every chunk
         for (int k = 0; k < n_chunks; ++k) {
+            double t0 = dbg ? Clock::now() : 0;
             {
                 std::unique_lock<std::mutex> lk(pipe.mu);
                 pipe.cv.wait(lk, [&] { return pipe.err != PRL_OK || pipe.uploaded > k; });
                 if (pipe.err != PRL_OK) break;
             }
+            if (dbg) { const double t1 = Clock::now(); clk_run.wait += t1 - t0; t0 = t1; }
             HostBin::Slot& s = hb.slot[k % HostBin::kSlots];
             int s2 = hipStreamWaitEvent(hb.run, s.ev_up, 0) == hipSuccess ? PRL_OK : PRL_ERR_HIP;
             if (s2 == PRL_OK)
@@ -344,12 +365,18 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
                                                    (size_t)g.out_w, hb.run);
             if (s2 == PRL_OK) s2 = prl_hip_finish(hb.run);   // the chunk's masks are final (and the stream idle) when this returns
             if (s2 != PRL_OK) { pipe.fail(s2, prl_hip_last_error_detail()); break; }
+            if (dbg) clk_run.run += Clock::now() - t0;
             { std::lock_guard<std::mutex> lk(pipe.mu); pipe.ran = k + 1; }
             pipe.cv.notify_all();
         }
     }
     uploader.join();
     downloader.join();
+    if (dbg)
+        std::fprintf(stderr, "[prl host batch] device %d, %d pages in %d chunks (%s in, %s out), %d copy threads: upload thread waited %.3f s for a slot, "
+                     "copied %.3f, enqueued %.3f; kernel thread waited %.3f for uploads, ran %.3f; download thread waited %.3f for kernels, "
+                     "%.3f for the DMA, copied %.3f\n", dev, count, n_chunks, pinned_in ? "pinned" : "pageable", pinned_out ? "pinned" : "pageable",
+                     WorkPool::get().threads(), clk_up.wait, clk_up.copy, clk_up.dma, clk_run.wait, clk_run.run, clk_down.wait, clk_down.dma, clk_down.copy);
     for (hipStream_t q : {hb.up, hb.run, hb.down}) (void)hipStreamSynchronize(q);   // nothing of this call stays in flight
     if (pipe.err != PRL_OK) {
         (void)prl_hip_finish(hb.run);   // drop what the failed call left pending on the kept stream

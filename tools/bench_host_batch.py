@@ -17,7 +17,8 @@ a = ap.parse_args()
 base = [synth.page_numpy(a.size, a.size, index=i) for i in range(4)]
 pages = [np.roll(base[i % 4], 131 * i, axis=1).copy() for i in range(a.pages)]
 p = prlib_amd.make_params(prlib_amd.SAUVOLA, 31, 0.34, 0)
-dst = None
+g = prlib_amd.geometry(p, a.size, a.size)
+dst = np.zeros((a.pages, g.out_h, g.out_w), np.uint8)   # the caller's mask buffers, allocated (and touched) once and re-used by every call
 if a.pinned:
     pin_in, pin_out = prlib_amd.PinnedPages(a.pages, a.size, a.size), prlib_amd.PinnedPages(a.pages, a.size - 1, a.size - 1)
     for i in range(a.pages):

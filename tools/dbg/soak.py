@@ -22,4 +22,4 @@ for it in range(15):
     del pages, outs, g
     torch.cuda.synchronize(); torch.cuda.empty_cache()
     free.append(torch.cuda.mem_get_info()[0] >> 20)
-print(json.dumps({"free_MiB_after_each_round": free, "settled": max(free[6:]) - min(free[6:]) < 64}))
+print(json.dumps({"free_MiB_after_each_round": free, "settled": max(free[-5:]) - min(free[-5:]) < 64}))
