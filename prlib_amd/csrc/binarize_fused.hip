@@ -1497,12 +1497,8 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         int rps = 128;
         if (waves_at(128) < 40000 && tp.w - 1 <= 64) rps = 64;   // (64 A4 pages, w=101: 128 rows 0.78 ms, 64 rows 0.80)
         while (rps > min_rps && waves_at(rps) < 4096) rps /= 2;  // small batches: halve while the chip is far from full
-        // a few rounds of the chip's wavefront slots: make it a WHOLE number of rounds (32 x 4K pages: 64 rows = 3.6 rounds, the
-        // last one 60 % full, 0.462 ms; 58 rows = 71 segments per strip = 3.99 rounds: profiles/r03/strong_proxy.txt)
-        if (waves_at(rps) > slots && waves_at(rps) < 12 * slots) {
-            const long long rounds = (waves_at(rps) + slots / 2) / slots, segs = rounds * slots / PS;
-            if (segs >= 1) rps = std::max(min_rps, (int)((tp.oh + segs - 1) / segs));
-        }
+        // (32 x 4K pages: 40 .. 72 rows per segment all measure 0.445-0.478 ms, whole or fractional rounds of the chip's wavefront
+        // slots alike - profiles/r03/strong_proxy.txt; a wavefront lives ~160 us of the kernel's 450: ramp-up and drain, not the tail)
         if (env_knobs().rows_per_seg) rps = env_knobs().rows_per_seg;  // tuning knob
         while ((unsigned long long)waves_at(rps) > wave_cap && rps < tp.oh) rps *= 2;  // (Wolf: one sweep-A maximum per wavefront)
         single_tier(rps);
