@@ -61,6 +61,7 @@ public:
         work_on(&b);   // the caller helps with its own batch
         std::unique_lock<std::mutex> lk(mu_);
         b.done_cv.wait(lk, [&] { return b.finished == b.n; });
+        batches_.erase(std::remove(batches_.begin(), batches_.end(), &b), batches_.end());   // (it lives on this stack frame)
     }
     int threads() const { return (int)workers_.size() + 1; }
 

@@ -5,7 +5,7 @@ for spec in "$@"; do
   so=${rest%%,*}; envs=""
   [ "$rest" != "$so" ] && envs=$(echo "${rest#*,}" | tr ',' ' ')
   for i in 1 2; do
-    env $envs ${so:+PRLIB_HIP_SO=$PWD/$so} timeout 300 python3 bench.py --steps 10 --warmup 2 --cpu-seconds 0 2>&1 | tail -1 | \
+    env $envs timeout 300 python3 bench.py ${so:+--lib $PWD/$so} --hooks $([ -z "$so" ] && echo 1 || echo 0) --traffic 0 --ceilings 0 --steps 10 --warmup 2 --cpu-seconds 0 2>&1 | tail -1 | \
       python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$label', 'step', d['ms_per_step'], 'kernel', d['roofline']['kernel_ms'], 'mism', d['parity']['mismatching_pixels'], 'refined', d['parity']['refined_pixels'])"
   done
 done

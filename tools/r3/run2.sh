@@ -4,7 +4,7 @@ cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r3
 out=gpurun_out/r3/probe6.txt; : > $out
 run() {  # tag so lds
-  line=$(PRL_PROBE_LDS=$3 PRLIB_HIP_SO=$PWD/$2 python3 bench.py --steps 10 --warmup 3 --cpu-seconds 0 --check-pages 0 2>/dev/null | tail -1)
+  line=$(PRL_PROBE_LDS=$3 python3 bench.py --lib $PWD/$2 --traffic 0 --ceilings 0 --steps 10 --warmup 3 --cpu-seconds 0 --check-pages 0 2>/dev/null | tail -1)
   echo "$line" | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$1 lds=$3', 'ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline']['kernel_ms'])" >> $out
 }
