@@ -146,18 +146,21 @@ def binarize(image, params: BinarizeParams, out=None, return_padded: bool = Fals
                                256-byte-pitched buffer), enqueued on torch's current stream.
     """
     if isinstance(image, np.ndarray):
-        return _binarize_numpy(image, params, return_padded)
+        return _binarize_numpy(image, params, return_padded, out)
     return _binarize_torch(image, params, out)
 
 
-def _binarize_numpy(img: np.ndarray, params: BinarizeParams, return_padded: bool):
+def _binarize_numpy(img: np.ndarray, params: BinarizeParams, return_padded: bool, out=None):
     if img.ndim != 2 or img.dtype != np.uint8:
         raise TypeError("expected a 2-D uint8 page (convert colour pages with cvtColor first)")
     h, w = img.shape
     g = geometry(params, w, h)
     if img.size and img.strides[1] != 1:
         img = np.ascontiguousarray(img)
-    out = np.empty((g.out_h, g.out_w), dtype=np.uint8)
+    if out is None:
+        out = np.empty((g.out_h, g.out_w), dtype=np.uint8)
+    elif out.shape != (g.out_h, g.out_w) or out.dtype != np.uint8 or out.strides[1] != 1:
+        raise ValueError("output array has the wrong shape")
     padded = np.empty((g.padded_h, g.padded_w), dtype=np.uint8) if return_padded else None
     st = _capi.lib().prl_hip_binarize_host(
         C.byref(params), img.ctypes.data, img.strides[0], w, h, out.ctypes.data, out.strides[0],

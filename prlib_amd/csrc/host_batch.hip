@@ -26,94 +26,21 @@
 #include <unistd.h>
 
 #include "prl_internal.h"
+#include "prl/work_pool.h"
 
 namespace prl_hip {
 namespace {
 
-// ---- a persistent pool of copy threads --------------------------------------------------------------------------------
-// parallel_for(n, f) runs f(0) .. f(n-1) on the pool's threads and the caller; several callers may be inside at once (the
-// upload and the download side of a worker, the workers of several devices): every call waits for its own batch only.
-// Created on first use, sized by PRL_HIP_HOST_COPY_THREADS (default: half of the cores, at most 32), never destroyed (no
-// joins during process teardown); after a fork() the child runs everything on the calling thread.
-class WorkPool {
-public:
-    static WorkPool& get()
-    {
-        static WorkPool* pool = new WorkPool();
-        return *pool;
-    }
-    template <typename F>
-    void parallel_for(int n, F&& f)
-    {
-        if (n <= 0) return;
-        if (n == 1 || workers_.empty() || getpid() != owner_pid_) {
-            for (int i = 0; i < n; ++i) f(i);
-            return;
-        }
-        Batch b;
-        b.fn = [&](int i) { f(i); };
-        b.n = n;
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            batches_.push_back(&b);
-        }
-        cv_.notify_all();
-        work_on(&b);   // the caller helps with its own batch
-        std::unique_lock<std::mutex> lk(mu_);
-        b.done_cv.wait(lk, [&] { return b.finished == b.n; });
-        batches_.erase(std::remove(batches_.begin(), batches_.end(), &b), batches_.end());   // (it lives on this stack frame)
-    }
-    int threads() const { return (int)workers_.size() + 1; }
-
-private:
-    struct Batch {
-        std::function<void(int)> fn;
-        int n = 0, next = 0, finished = 0;   // guarded by the pool's mutex
-        std::condition_variable done_cv;
-    };
-    void work_on(Batch* only)
-    {
-        for (;;) {
-            Batch* b = nullptr;
-            int i = -1;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                if (only) {
-                    if (only->next < only->n) { b = only; i = b->next++; }
-                    else return;
-                } else {
-                    cv_.wait(lk, [&] {
-                        while (!batches_.empty() && batches_.front()->next >= batches_.front()->n) batches_.pop_front();
-                        return !batches_.empty();
-                    });
-                    b = batches_.front();
-                    i = b->next++;
-                }
-            }
-            b->fn(i);
-            bool last;
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                last = ++b->finished == b->n;
-                if (last) b->done_cv.notify_all();   // (under the lock: the batch lives on its caller's stack)
-            }
-        }
-    }
-    WorkPool()
-    {
-        owner_pid_ = getpid();
+// ---- the pool of copy threads (prl/work_pool.h), created on first use: PRL_HIP_HOST_COPY_THREADS, default half of the cores, at most 32
+WorkPool& copy_pool()
+{
+    static WorkPool* pool = [] {
         const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
         int n = env_knobs().host_copy_threads > 0 ? env_knobs().host_copy_threads : (int)std::min(32u, std::max(2u, hc / 2));
-        n = std::max(1, std::min(n, (int)hc));
-        for (int i = 0; i + 1 < n; ++i) workers_.emplace_back([this] { work_on(nullptr); });
-        for (auto& t : workers_) t.detach();
-    }
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::deque<Batch*> batches_;
-    std::vector<std::thread> workers_;
-    pid_t owner_pid_ = 0;
-};
+        return new WorkPool(std::max(1, std::min(n, (int)hc)));   // never destroyed: no joins during process teardown
+    }();
+    return *pool;
+}
 
 // pages [0, n) between the caller's strided pages and a packed buffer, in tasks of about a megabyte
 void copy_pages(int n, size_t row_bytes, int rows, const uint8_t* const* src, size_t src_step, uint8_t* dst_packed, bool to_packed,
@@ -122,7 +49,7 @@ void copy_pages(int n, size_t row_bytes, int rows, const uint8_t* const* src, si
     const size_t page_bytes = row_bytes * (size_t)rows;
     const int rows_per_task = (int)std::max<size_t>(1, ((size_t)1 << 20) / std::max<size_t>(1, row_bytes));
     const int tasks_per_page = (rows + rows_per_task - 1) / rows_per_task;
-    WorkPool::get().parallel_for(n * tasks_per_page, [&](int t) {
+    copy_pool().parallel_for(n * tasks_per_page, [&](int t) {
         const int pg = t / tasks_per_page, y0 = (t % tasks_per_page) * rows_per_task, y1 = std::min(rows, y0 + rows_per_task);
         uint8_t* packed = dst_packed + (size_t)pg * page_bytes;
         if (to_packed) {
@@ -139,16 +66,8 @@ void copy_pages(int n, size_t row_bytes, int rows, const uint8_t* const* src, si
 // caller's pages directly and no byte is copied by the CPU.
 bool pages_pinned(int n, const uint8_t* const* pages, size_t last_byte)
 {
-    for (int i = 0; i < n; ++i) {
-        for (const uint8_t* p : {pages[i], pages[i] + last_byte}) {
-            hipPointerAttribute_t at{};
-            if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-                (void)hipGetLastError();   // (an ordinary malloc'ed pointer is an "invalid value" to the runtime)
-                return false;
-            }
-            if (at.type != hipMemoryTypeHost) return false;
-        }
-    }
+    for (int i = 0; i < n; ++i)
+        if (!host_range_pinned(pages[i], last_byte + 1)) return false;
     return true;
 }
 
@@ -377,7 +296,7 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
         std::fprintf(stderr, "[prl host batch] device %d, %d pages in %d chunks (%s in, %s out), %d copy threads: upload thread waited %.3f s for a slot, "
                      "copied %.3f, enqueued %.3f; kernel thread waited %.3f for uploads, ran %.3f; download thread waited %.3f for kernels, "
                      "%.3f for the DMA, copied %.3f\n", dev, count, n_chunks, pinned_in ? "pinned" : "pageable", pinned_out ? "pinned" : "pageable",
-                     WorkPool::get().threads(), clk_up.wait, clk_up.copy, clk_up.dma, clk_run.wait, clk_run.run, clk_down.wait, clk_down.dma, clk_down.copy);
+                     copy_pool().threads(), clk_up.wait, clk_up.copy, clk_up.dma, clk_run.wait, clk_run.run, clk_down.wait, clk_down.dma, clk_down.copy);
     for (hipStream_t q : {hb.up, hb.run, hb.down}) (void)hipStreamSynchronize(q);   // nothing of this call stays in flight
     if (pipe.err != PRL_OK) {
         (void)prl_hip_finish(hb.run);   // drop what the failed call left pending on the kept stream

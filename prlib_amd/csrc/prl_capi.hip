@@ -412,6 +412,22 @@ private:
 };
 }  // namespace
 
+// Is [p, p + bytes) pinned host memory (hipHostMalloc / prl_hip_alloc_host / hipHostRegister)?  Then the DMA engines can
+// read / write it directly.  An ordinary malloc'ed pointer is an "invalid value" to the runtime: not an error here.
+bool host_range_pinned(const void* p, size_t bytes)
+{
+    if (!p || bytes == 0) return false;
+    for (const uint8_t* q : {static_cast<const uint8_t*>(p), static_cast<const uint8_t*>(p) + bytes - 1}) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (at.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
 int stage_upload(DeviceCtx* ctx, size_t pin_off, const uint8_t* src, size_t src_step, size_t row_bytes, int rows,
                  uint8_t* d_dst, hipStream_t stream)
 {
@@ -420,6 +436,12 @@ int stage_upload(DeviceCtx* ctx, size_t pin_off, const uint8_t* src, size_t src_
     {   // the staging area may still be read by a chain call enqueued on another (non-blocking) stream
         const int st = stage_acquire(ctx, stream);
         if (st != PRL_OK) return st;
+    }
+    // a dense page in pinned memory (a cv::Mat over prl_hip_alloc_host memory): one DMA straight from the caller's pixels,
+    // no bounce copy.  (The *_host entries return only after their stream has drained, so the source outlives the copy.)
+    if (src_step == row_bytes && host_range_pinned(src, row_bytes * (size_t)rows)) {
+        PRL_HIP_CHECK(hipMemcpyAsync(d_dst, src, row_bytes * (size_t)rows, hipMemcpyHostToDevice, stream));
+        return PRL_OK;
     }
     for (int y0 = 0; y0 < rows; y0 += band) {
         const int n = std::min(band, rows - y0);
@@ -433,6 +455,11 @@ int stage_upload(DeviceCtx* ctx, size_t pin_off, const uint8_t* src, size_t src_
 int stage_download(DeviceCtx* ctx, size_t pin_off, const uint8_t* d_src, size_t row_bytes, int rows, uint8_t* dst,
                    size_t dst_step, hipStream_t stream)
 {
+    if (dst_step == row_bytes && host_range_pinned(dst, row_bytes * (size_t)rows)) {   // dense pinned destination: one DMA, no bounce
+        PRL_HIP_CHECK(hipMemcpyAsync(dst, d_src, row_bytes * (size_t)rows, hipMemcpyDeviceToHost, stream));
+        PRL_HIP_CHECK(hipStreamSynchronize(stream));
+        return PRL_OK;
+    }
     uint8_t* pin = static_cast<uint8_t*>(ctx->stage_pinned) + pin_off;
     const int band = rows_per_band(row_bytes, rows);
     const int n_bands = (rows + band - 1) / band;

@@ -148,6 +148,7 @@ int stage_upload(DeviceCtx* ctx, size_t pin_off, const uint8_t* src, size_t src_
 int stage_download(DeviceCtx* ctx, size_t pin_off, const uint8_t* d_src, size_t row_bytes, int rows, uint8_t* dst,
                    size_t dst_step, hipStream_t stream);                  // synchronises `stream`
 int ensure_stage_pinned(DeviceCtx* ctx, size_t bytes);
+bool host_range_pinned(const void* p, size_t bytes);   // pinned host memory: the DMA engines may use it directly
 
 // ---- page addressing: contiguous batch or table of page pointers ---------------------------------
 struct PageSet {

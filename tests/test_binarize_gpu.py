@@ -548,3 +548,26 @@ def test_host_batch_entry_pinned_pages_and_repeated_calls(prl, oracle, cuda_devi
             torch.cuda.synchronize(cuda_device)
             free.append(torch.cuda.mem_get_info(cuda_device)[0] >> 20)
         assert max(free[4:]) - min(free[4:]) < 64, free
+
+
+def test_single_page_host_entry_with_pinned_buffers(prl, oracle, cuda_device):
+    """prl_hip_binarize_host (what the cv::Mat wrapper calls): a dense page / mask in pinned memory is one DMA each, no
+    bounce copy; a strided view of pinned memory and pageable memory take the bounce path.  All equal the oracle."""
+    from prlib_amd import synth
+
+    h, w = 700, 1100
+    page = synth.page_numpy(h, w, index=3)
+    for method, win, k, morph in ((SAUVOLA, 31, 0.34, 2), (WOLFJOLION, 21, 0.3, 0)):
+        p = prl.make_params(method, win, k, morph)
+        want = oracle.binarize(page, oracle.make_params(method, win, k, morph))
+        oh, ow = want.shape
+        with prl.PinnedPages(1, h, w) as pin, prl.PinnedPages(1, oh, ow) as pout, prl.PinnedPages(1, h, w + 64) as wide:
+            pin.array[0] = page
+            got = prl.binarize(pin.array[0], p, out=pout.array[0])                      # pinned in, pinned out
+            assert np.shares_memory(got, pout.array) and np.array_equal(got, want)
+            assert np.array_equal(prl.binarize(pin.array[0], p), want)                   # pinned in, pageable out
+            assert np.array_equal(prl.binarize(page, p, out=pout.array[0]), want)        # pageable in, pinned out
+            wide.array[0, :, 32:32 + w] = page
+            assert np.array_equal(prl.binarize(wide.array[0, :, 32:32 + w], p), want)    # strided pinned view: bounce path
+            got, padded = prl.binarize(pin.array[0], p, return_padded=True)
+            assert np.array_equal(got, want) and padded.shape == (h + 2 * (min(win, h, w) // 2), w + 2 * (min(win, h, w) // 2))

@@ -35,3 +35,11 @@ def test_cpp_host_parity_on_device():
         _build()
     r = subprocess.run([BIN, "gpu"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_work_pool_many_callers():
+    """prlib_amd/csrc/prl/work_pool.h (copy threads of the host-list entries): five callers inside parallel_for at once, every
+    index run exactly once (plain C++, no device; tools/sanitize_cpu.sh runs the same program under ThreadSanitizer)."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s", "test_work_pool"], check=True)
+    r = subprocess.run([os.path.join(os.path.join(ROOT, "tests", "cpp"), "test_work_pool")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "work_pool: OK" in r.stdout, r.stdout + r.stderr

@@ -33,3 +33,7 @@ for (h, w) in [(40, 50), (97, 131), (1, 1), (33, 200)]:
 print("oracle under ASan/UBSan: ok")
 PY
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python3 /tmp/asan_oracle.py "$ROOT"
+# the copy-thread pool of the host-list entries (prlib_amd/csrc/prl/work_pool.h) under ThreadSanitizer
+g++ -O1 -g -std=c++17 -fsanitize=thread -pthread "$ROOT/tests/cpp/test_work_pool.cpp" -o /tmp/test_work_pool_tsan
+/tmp/test_work_pool_tsan 2>&1 | tee /tmp/test_work_pool_tsan.log | tail -2
+if grep -q "ThreadSanitizer" /tmp/test_work_pool_tsan.log; then echo "work_pool under TSan: FAILED"; exit 1; else echo "work_pool under TSan: ok"; fi
