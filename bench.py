@@ -318,11 +318,11 @@ def main():
     if args.scaling == "both" and world > 1:
         s_mine = pdist.page_range(args.pages, world, rank)
         sp, so_ = pages[: len(s_mine)], out[: len(s_mine)]
-        for _ in range(args.warmup):
+        for _ in range(args.warmup if len(s_mine) else 0):   # (fewer pages than ranks: this rank only joins the barriers)
             prlib_amd.binarize(sp, params, out=so_)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps if len(s_mine) else 0):
             prlib_amd.binarize(sp, params, out=so_)
         barrier()
         s_elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)

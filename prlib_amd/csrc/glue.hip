@@ -595,6 +595,7 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
             if (beside) {
                 // how the body compared with the search beside it sizes the searches that are still to start
                 const bool early = hipEventQuery(body_done.e) == hipSuccess;
+                if (!early) (void)hipGetLastError();   // ("not ready" is an answer, not an error to find later)
                 const auto tj = std::chrono::steady_clock::now();
                 if (!early) PRL_HIP_CHECK(hipEventSynchronize(body_done.e));   // (the tail is enqueued behind the body anyway)
                 const double past = early ? 0.0 : std::chrono::duration<double>(std::chrono::steady_clock::now() - tj).count();
