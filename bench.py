@@ -102,7 +102,7 @@ def measure_traffic(args):
                "--ceilings", "0"] + (["--lib", args.lib] if args.lib else []) + (["--hooks", "1"] if args.hooks else [])
         env = dict(os.environ, TMPDIR="/tmp")
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
             per = []
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
