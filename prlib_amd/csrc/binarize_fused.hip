@@ -301,6 +301,25 @@ __device__ __forceinline__ uint2 apply_edge(uint2 v, const EdgeFix& e)
     return make_uint2(__builtin_amdgcn_perm(v.y, v.x, e.selx), __builtin_amdgcn_perm(v.y, v.x, e.sely));
 }
 
+// the lane that straddles the row end: its nv = 1..7 mask bytes as dword + halfword + byte
+__device__ __forceinline__ void store_tail(gptr o, unsigned lo, unsigned hi, int nv)
+{
+    unsigned long long bytes = ((unsigned long long)hi << 32) | lo;
+    if (nv & 4) {
+        const unsigned d4 = (unsigned)bytes;
+        __builtin_memcpy((uint8_t*)o, &d4, 4);
+        o += 4;
+        bytes >>= 32;
+    }
+    if (nv & 2) {
+        const unsigned short d2 = (unsigned short)bytes;
+        __builtin_memcpy((uint8_t*)o, &d2, 2);
+        o += 2;
+        bytes >>= 16;
+    }
+    if (nv & 1) *o = (uint8_t)bytes;
+}
+
 // One wavefront: a strip of SW padded columns x a segment of output rows.
 //   EDGE  : the strip touches the left/right page border (replicate clamp, partial stores)
 //           the leaving row and the compared pixels are never re-read from memory
@@ -551,23 +570,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                     __builtin_memcpy((uint8_t*)(out + (size_t)y * ostep + x0), &o, 8);
                 }
             } else if (EDGE && lane_has_out) {
-                // the lane that straddles the row end: its 1..7 bytes as dword + halfword + byte
-                const int nv = tp.ow - x0;
-                gptr o = out + (size_t)y * ostep + x0;
-                unsigned long long bytes = ((unsigned long long)hi << 32) | lo;
-                if (nv & 4) {
-                    const unsigned d4 = (unsigned)bytes;
-                    __builtin_memcpy((uint8_t*)o, &d4, 4);
-                    o += 4;
-                    bytes >>= 32;
-                }
-                if (nv & 2) {
-                    const unsigned short d2 = (unsigned short)bytes;
-                    __builtin_memcpy((uint8_t*)o, &d2, 2);
-                    o += 2;
-                    bytes >>= 16;
-                }
-                if (nv & 1) *o = (uint8_t)bytes;
+                store_tail(out + (size_t)y * ostep + x0, lo, hi, tp.ow - x0);
             }
         }
 
@@ -651,7 +654,11 @@ __device__ __forceinline__ float bpermf(int addr, float v)
 
 // LO: fp.lane_off as a compile-time constant; FAST: byte mask through non-temporal stores and no p == 0 fix-up (the usual
 // call) - both only remove wave-uniform branches from the row loop (~8 taken branches per row otherwise).
-template <int METHOD, int SH, int LO, bool FAST>
+// EDGE: the strip touches the left / right page border.  Typed loads cannot replicate a border column, so the window rows
+// come as packed bytes from a clamped address, are put in place by strip_loop's two v_perm_b32 and converted when the
+// slide uses them (16 conversions a row more than an interior strip, still a quarter fewer vector instructions than the
+// integer loop: 2 of the 9 strips of a 4096-column page, 2 of the 6 of an A4 page); partial stores at the row end.
+template <int METHOD, int SH, int LO, bool FAST, bool EDGE>
 __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, size_t ostep, const FusedParams& fp,
                                              int page, int xs, int ys, int ye, int lane, const PageK& pk, unsigned wid,
                                              PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
@@ -662,12 +669,27 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     const int H = tp.height, h = tp.half, w = tp.w;
     const int col0 = xs + 1 - h + CPL * lane;  // image column of this lane's sub-column 0 (interior: no clamp)
     const int x0 = xs + CPL * lane;            // first output column of this lane
-    const bool lane_has_out = CPL * lane < fp.uo;  // interior strips: every output column exists
+    // interior strips: every output column exists
+    const bool lane_has_out = (CPL * lane < fp.uo) && (!EDGE || x0 < tp.ow);
+    const bool full8 = lane_has_out && (!EDGE || x0 + CPL <= tp.ow);
     const int far_addr0 = (lane + LO) * 4, far_addr1 = far_addr0 + 4;
     const i32x4 rsrc = page_rsrc(img);
     const int step = (int)istep;
+    const EdgeFix ew = EDGE ? make_edge(col0, tp.width) : EdgeFix{0, 0u, 0u};
+    const EdgeFix ep = EDGE ? make_edge(x0, tp.width) : EdgeFix{0, 0u, 0u};  // lanes without output fetch a clamped (ignored) location
+    auto to_f8 = [](uint2 b) -> F8 {
+        F8 r;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) r.v[c] = (float)byte_of(b, c);
+        return r;
+    };
+    auto edge_row = [&](int off) -> uint2 { return apply_edge(gload8(img + off + ew.colc), ew); };  // bytes in place (EDGE)
 
-    auto load_win = [&](int padded_row) -> F8 { return tload8(rsrc, col0, clampi(padded_row - h, 0, H - 1) * step); };
+    auto load_win = [&](int padded_row) -> F8 {
+        const int off = clampi(padded_row - h, 0, H - 1) * step;
+        if constexpr (EDGE) return to_f8(edge_row(off));
+        else return tload8(rsrc, col0, off);
+    };
 
     float VS[CPL], VQ[CPL];
 #pragma unroll
@@ -697,15 +719,26 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     const int off_last = (H - 1) * step;
     int off_new = min((ys + w - h) * step, off_last);   // padded row ys + w
     int off_old = max((ys + 1 - h) * step, 0);          // padded row ys + 1
-    gcptr pv_ptr = img + (size_t)ys * istep + x0;
-    F8 vnew = tload8(rsrc, col0, off_new);
-    F8 vold = tload8(rsrc, col0, off_old);
+    gcptr pv_ptr = img + (size_t)ys * istep + (EDGE ? ep.colc : x0);
+    F8 vnew, vold;           // interior: the two window rows as floats (typed loads)
+    uint2 bnew = make_uint2(0u, 0u), bold = bnew;  // EDGE: as packed bytes, converted where the slide uses them
+    if constexpr (EDGE) {
+        bnew = edge_row(off_new);
+        bold = edge_row(off_old);
+    } else {
+        vnew = tload8(rsrc, col0, off_new);
+        vold = tload8(rsrc, col0, off_old);
+    }
     int off_old_raw = (ys + 1 - h) * step;
     uint2 pvb = make_uint2(0u, 0u);
     if (!SWEEP_A) pvb = gload8(pv_ptr);
 #pragma unroll 1
     for (int y = ys; y < ye; ++y) {
-        track_min(vnew);
+        if constexpr (EDGE) {
+            if (SWEEP_A) track_min(to_f8(bnew));
+        } else {
+            track_min(vnew);
+        }
         float Ssum[CPL], Qsum[CPL];
         float ES[CPL], EQ[CPL], tot_s, tot_q;
         {
@@ -746,12 +779,13 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const float K = fmaf(fp.w2f, Qsum[c], -(Ssum[c] * Ssum[c]));
-                if (lane_has_out) vmax_lane = fmaxf(vmax_lane, K);
+                if (lane_has_out && (!EDGE || x0 + c < tp.ow)) vmax_lane = fmaxf(vmax_lane, K);
             }
         } else {
         // the compared pixels come as packed bytes (one 8-byte load, 8 v_cvt_f32_ubyte): the kernel leans on the
         // vector-memory pipe, and one load instruction less is worth more than eight conversions (3.48 -> 3.39 ms;
         // fetching the leaving or both window rows this way too: 3.80 ms)
+        if constexpr (EDGE) pvb = apply_edge(pvb, ep);
         F8 pv;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) pv.v[c] = (float)byte_of(pvb, c);
@@ -782,6 +816,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             if (unsure) {
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
+                    if (EDGE && x0 + c >= tp.ow) continue;
                     if (pv_cur.v[c] == 0.0f) continue;  // 0 > T8 is false whatever T is
                     float v32;
                     const float t = eval32f<METHOD>(fp, Ssum[c], Qsum[c], fmaf(pv_cur.v[c], kZ, pk.p0), pk, &v32);
@@ -805,8 +840,11 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
 
         if (lane_has_out) {
             if (!FAST && fp.bit_out) {
-                const unsigned b = (((lo & 0x01010101u) * 0x01020408u) >> 24) | ((((hi & 0x01010101u) * 0x01020408u) >> 20) & 0xf0u);
+                unsigned b = (((lo & 0x01010101u) * 0x01020408u) >> 24) | ((((hi & 0x01010101u) * 0x01020408u) >> 20) & 0xf0u);
+                if (EDGE && !full8) b &= (1u << (tp.ow - x0)) - 1u;  // pixels past the row end stay 0
                 out[(size_t)y * ostep + (x0 >> 3)] = (uint8_t)b;
+            } else if (EDGE && !full8) {
+                store_tail(out + (size_t)y * ostep + x0, lo, hi, tp.ow - x0);
             } else if (FAST || fp.nt_store) {
                 typedef unsigned u2v __attribute__((ext_vector_type(2)));
                 u2v o = {lo, hi};
@@ -822,6 +860,10 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         }  // !SWEEP_A
 
         // slide the window one row down: new^2 - old^2 = (new - old)(new + old), one exact fma
+        if constexpr (EDGE) {
+            vnew = to_f8(bnew);
+            vold = to_f8(bold);
+        }
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const float d = vnew.v[c] - vold.v[c], sm = vnew.v[c] + vold.v[c];
@@ -831,8 +873,13 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         off_new = min(off_new + step, off_last);
         off_old_raw += step;
         off_old = max(off_old_raw, 0);
-        vnew = tload8(rsrc, col0, off_new);
-        vold = tload8(rsrc, col0, off_old);  // (a non-temporal hint on this last use of the row measured 2 % slower)
+        if constexpr (EDGE) {
+            bnew = edge_row(off_new);
+            bold = edge_row(off_old);
+        } else {
+            vnew = tload8(rsrc, col0, off_new);
+            vold = tload8(rsrc, col0, off_old);  // (a non-temporal hint on this last use of the row measured 2 % slower)
+        }
     }
     if (SWEEP_A) {
 #pragma unroll
@@ -921,13 +968,14 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     const int first_col = xs + 1 - tp.half;
     const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
     constexpr bool kFloatOk = METHOD != kWolfCollect;  // (sweep B revisits few segments and queues exact candidates: integer)
-    if (interior && kFloatOk && !WIDE && fp.flt) {
+    if (kFloatOk && !WIDE && fp.flt) {
         // (wave-uniform dispatch, once per wavefront: the row loop itself is branch-free in the usual configuration)
         const bool fast = !fp.bit_out && fp.nt_store && !fp.need_p0;
 #define PRL_FLT_LOOP(LOV)                                                                                                          \
     do {                                                                                                                           \
-        if (fast) strip_loop_f<METHOD, SH, LOV, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);  \
-        else strip_loop_f<METHOD, SH, LOV, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);      \
+        if (!interior) strip_loop_f<METHOD, SH, LOV, false, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);  \
+        else if (fast) strip_loop_f<METHOD, SH, LOV, true, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);  \
+        else strip_loop_f<METHOD, SH, LOV, false, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);      \
     } while (0)
         switch (fp.lane_off) {
         case 0: PRL_FLT_LOOP(0); break;
