@@ -80,6 +80,7 @@ struct FusedParams {
     struct Tier { int rows, segs, row0; unsigned waves, first; } tier[8];
     int n_tiers;
     int lane_off;      // (w-1) / 8
+    int ext;           // the last strip of a row is an extended one (strip_layout)
     unsigned total_waves;
     unsigned xcd_waves;  // wavefront slots per XCD share of the grid (sum over tiers of ceil(waves / 8))
     float w2f;         // (float)(w*w), exact
@@ -328,7 +329,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                                            const FusedParams& fp, int page, int xs, int ys, int ye, int lane,
                                            const PageK& pk, unsigned wid, PageGlobals* __restrict__ g,
                                            RefItem* __restrict__ rl, WorkItem* __restrict__ cand,
-                                           unsigned* __restrict__ counters)
+                                           unsigned* __restrict__ counters, bool last_ext = false)
 {
     constexpr bool SWEEP = (METHOD == kWolfMax || METHOD == kWolfCollect);
     // WIDE: w - 1 > 181, S does not fit the mantissa trick (eval32)
@@ -336,12 +337,19 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     const int W = tp.width, H = tp.height, h = tp.half, w = tp.w;
     const int col0 = xs + 1 - h + CPL * lane;  // image column of this lane's sub-column 0
     const int x0 = xs + CPL * lane;            // first output column of this lane
-    const bool lane_has_out = (CPL * lane < fp.uo) && (x0 < tp.ow);
+    // Extended last strip (EDGE, wide windows - strip_layout()): lane 63 and every column right of it is the replicated
+    // border column, so the lanes whose far edge lies beyond the wavefront have outputs too.  Their far lane is clamped to
+    // lane 63 - any padding lane holds the same in-lane prefixes sub x V - and the totals of the lanes that do not exist,
+    // 8 V each (V = the border column's sums), are added to W: n0 / n1 missing lanes' worth for the two far positions.
+    const bool ext = EDGE && last_ext;
+    const bool lane_has_out = ((CPL * lane < fp.uo) || ext) && (x0 < tp.ow);
     const bool full8 = lane_has_out && (x0 + CPL <= tp.ow);
     const EdgeFix ew = EDGE ? make_edge(col0, W) : EdgeFix{col0, 0x03020100u, 0x07060504u};
     const EdgeFix ep = make_edge(x0, W);  // lanes without output fetch a clamped (ignored) location
-    const int far_addr0 = (lane + fp.lane_off) * 4;  // ds_bpermute byte address of the lane holding E(j0+w-1)
-    const int far_addr1 = far_addr0 + 4;
+    const int far_addr0 = min(lane + fp.lane_off, 63) * 4;  // ds_bpermute byte address of the lane holding E(j0+w-1)
+    const int far_addr1 = min(lane + fp.lane_off + 1, 63) * 4;
+    const unsigned n0 = ext ? 8u * (unsigned)max(lane + fp.lane_off - 63, 0) : 0u;
+    const unsigned n1 = ext ? 8u * (unsigned)max(lane + fp.lane_off + 1 - 63, 0) : 0u;
 
     auto load_win = [&](int padded_row) -> uint2 {
         const size_t ro = (size_t)clampi(padded_row - h, 0, H - 1) * istep;  // wave-uniform
@@ -429,6 +437,14 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             w1s = (unsigned)__builtin_amdgcn_ds_bpermute(far_addr1, (int)ps) - ps;
             w0q = (unsigned)__builtin_amdgcn_ds_bpermute(far_addr0, (int)pq) - pq;
             w1q = (unsigned)__builtin_amdgcn_ds_bpermute(far_addr1, (int)pq) - pq;
+            if (ext) {  // wave-uniform; both factors below 2^24, sums modulo 2^32 like every partial sum here
+                const unsigned vs = (unsigned)__builtin_amdgcn_readlane((int)VS[CPL - 1], 63);
+                const unsigned vq = (unsigned)__builtin_amdgcn_readlane((int)VQ[CPL - 1], 63);
+                w0s += __umul24(n0, vs);
+                w1s += __umul24(n1, vs);
+                w0q += __umul24(n0, vq);
+                w1q += __umul24(n1, vq);
+            }
         }
         }
 #undef PRL_W_STEP
@@ -987,7 +1003,8 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     } else if (interior)
         strip_loop<METHOD, SH, false, WIDE>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
     else
-        strip_loop<METHOD, SH, true, WIDE>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters);
+        strip_loop<METHOD, SH, true, WIDE>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters,
+                                           fp.ext && strip == fp.n_strips - 1);
 }
 
 // ---- second stage: float64 interval test of the queued pixels ------------------------------------------------------
@@ -1489,6 +1506,37 @@ size_t fused_small_bytes(int)
            sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(float) * kSegmaxCap + sizeof(unsigned) * (size_t)kWorkCap;
 }
 
+// Strips of a row: uo output columns each, fetched with w - 1 halo columns.  When everything from the last lane of what would
+// be the last but one strip onwards is right-hand padding (copies of the border column), that strip takes the rest of the
+// row as well: the totals of the lanes beyond the wavefront are known without fetching them (strip_loop, `ext`).  Up to
+// 512 - h - 7 outputs instead of 512 - (w - 1); an A4 row (2479 outputs) at the default w = 101 takes 6 strips instead of
+// 7, a 4096-column row 10 instead of 11.  Wide windows only (the wavefront-scan form of the horizontal sums).
+static int strip_layout(const ThrParams& tp, int uo, int* ext)
+{
+    int n = (tp.ow + uo - 1) / uo;
+    *ext = 0;
+    if (!env_knobs().ext_strip || (tp.w - 1) / 8 < 5 || n < 2) return n;
+    const int xs = (n - 2) * uo;  // first output column of the strip that would take over
+    if (xs + 1 - tp.half + 8 * 63 >= tp.width - 1 && tp.ow - xs <= SW) {
+        *ext = 1;
+        --n;
+    }
+    return n;
+}
+
+extern "C" int prl_hip_internal_strip_layout(int w, int width, int ow, int* ext)
+{
+    // test hook (not in the public header): strips per row and whether the last one is an extended one
+    ThrParams tp{};
+    tp.w = w;
+    tp.half = w / 2;
+    tp.width = width;
+    tp.ow = ow;
+    const int uo = ((SW - (w - 1)) / 8) * 8;
+    *ext = 0;
+    return uo > 0 ? strip_layout(tp, uo, ext) : 0;
+}
+
 // Pages one fused_run call may take.  Wolf-Jolion keeps one float per wavefront of the call (sweep A -> sweep B), kSegmaxCap
 // of them: a call's wavefronts = pages x strips x segments; fused_run lengthens its segments until they fit, this only keeps
 // the segments of a chunk from becoming much longer than 128 rows.
@@ -1515,7 +1563,7 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     // window rows that ARE re-read (the leaving row, the compared-pixel row): 4.31-4.47 -> 4.15 ms on 256 x 4K pages
     fp.nt_store = env_knobs().nt_store ? 1 : 0;
     fp.uo = ((SW - (tp.w - 1)) / 8) * 8;
-    fp.n_strips = (tp.ow + fp.uo - 1) / fp.uo;
+    fp.n_strips = strip_layout(tp, fp.uo, &fp.ext);
     // Row segments.  Long segments amortise the (w-1)-row warm-up, short ones fill the chip and keep the tail short when it
     // drains; workgroups start in index order, so the segments come in TIERS of decreasing length (guided scheduling): each tier
     // takes about half of the rows that are left, in segments sized for ~two rounds of the chip's wavefront slots, down to a

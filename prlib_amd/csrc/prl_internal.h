@@ -91,6 +91,7 @@ struct EnvKnobs {
     bool nt_store = true;         // PRL_HIP_NT=0         plain instead of non-temporal mask stores
     int rows_per_seg = 0;         // PRL_HIP_ROWS_PER_SEG (0 = chosen from the batch size)
     bool tiers = true;            // PRL_HIP_TIERS=0      one segment length for the whole call (A/B of the tiered schedule)
+    bool ext_strip = true;        // PRL_HIP_EXT_STRIP=0  no extended last strip (binarize_fused.hip strip_layout)
     bool debug = false;           // PRL_HIP_DEBUG
     bool byte_mask = false;       // PRL_HIP_BYTE_MASK    byte instead of bit-plane hand-off to the morphology pass
     int morph_rps = 0, morph_wpb = 1;   // PRL_MORPH_RPS, PRL_MORPH_WPB

@@ -571,3 +571,23 @@ def test_single_page_host_entry_with_pinned_buffers(prl, oracle, cuda_device):
             assert np.array_equal(prl.binarize(wide.array[0, :, 32:32 + w], p), want)    # strided pinned view: bounce path
             got, padded = prl.binarize(pin.array[0], p, return_padded=True)
             assert np.array_equal(got, want) and padded.shape == (h + 2 * (min(win, h, w) // 2), w + 2 * (min(win, h, w) // 2))
+
+
+@pytest.mark.parametrize("method,k", [(SAUVOLA, 0.2), (NIBLACK, -0.2), (NICK, -0.1), (WOLFJOLION, 0.3), (FENG, 0.0)])
+@pytest.mark.parametrize("win,widths", [
+    (41, (473, 474, 480, 486, 487, 488, 945, 958, 959)),       # uo = 472: one strip for 473..485 outputs, two up to 957
+    (101, (410, 431, 455, 456, 457, 818, 840, 864, 865, 1272)),  # uo = 408 (456: the widest page one strip takes)
+    (201, (314, 360, 405, 406, 407, 718, 719)),                  # wide windows (S beyond the mantissa trick), uo = 312
+    (257, (258, 300, 377, 378, 379, 634, 635)),                  # the widest fused window, uo = 256
+])
+def test_extended_last_strip(prl, oracle, cuda_device, method, k, win, widths):
+    """The last strip of a row takes the columns of a would-be extra strip when all of those are right-hand padding
+    (binarize_fused.hip strip_layout): every width around the switch points, against the oracle."""
+    for wd in widths:
+        if wd <= win + 1 and method in (NICK, WOLFJOLION, FENG):
+            continue  # no output columns
+        ht = win + 37
+        kinds = ["doc", "noise", "dark_corner"]
+        _check(prl, oracle, cuda_device, _pages((ht, wd), kinds, seed=wd), method, win, k, 0)
+    # the bit-plane hand-off to the morphology pass on an extended strip
+    _check(prl, oracle, cuda_device, _pages((win + 40, widths[1]), ["doc", "noise"], seed=3), method, win, k, 2)

@@ -151,3 +151,38 @@ def test_float32_pipeline_q_error_bound(prl, w):
                     assert err == 0.0, (w, trial, lane, c, exact, qmin, err)
                 worst = max(worst, err)
     assert cq >= 1.0 and worst <= delta
+
+
+def test_strip_layout(prl):
+    """Strips per row (binarize_fused.hip strip_layout): the extended last strip saves the seventh strip of an A4 row and the
+    eleventh of a 4096-column row at the default w = 101; narrow windows and rows without a small remainder are untouched;
+    the extended strip never has more than 64 lanes of outputs and its last lane is padding."""
+    from prlib_amd import _capi
+
+    L = _capi.lib()
+    L.prl_hip_internal_strip_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    ext = C.c_int(0)
+
+    def layout(w, width, ow):
+        n = L.prl_hip_internal_strip_layout(w, width, ow, C.byref(ext))
+        return n, ext.value
+
+    assert layout(101, 2480, 2479) == (6, 1)     # Sauvola / Niblack, A4 at 300 dpi
+    assert layout(101, 4096, 4095) == (10, 1)
+    assert layout(101, 2480, 2480 - 101) == (6, 0)   # Wolf-Jolion / NICK / Feng: 2379 outputs, six plain strips
+    assert layout(31, 4096, 4095) == (9, 0)      # the chain form of the horizontal sums: never
+    assert layout(31, 2480, 2479) == (6, 0)
+    assert layout(41, 486, 485) == (1, 1) and layout(41, 487, 486) == (2, 0)
+    assert layout(101, 456, 455) == (1, 1) and layout(101, 457, 456) == (2, 0)
+    for w in (41, 51, 101, 151, 201, 257):
+        uo, h = ((512 - (w - 1)) // 8) * 8, w // 2
+        for width in range(w + 2, 2200, 3):
+            ow = width - 1
+            n, e = layout(w, width, ow)
+            plain = -(-ow // uo)
+            assert n == plain - e
+            if e:
+                xs = (n - 1) * uo
+                assert ow - xs <= 512 and xs + 1 - h + 504 >= width - 1
+            else:
+                assert ow - (n - 1) * uo <= uo
