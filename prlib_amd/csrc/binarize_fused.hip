@@ -685,9 +685,11 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     const int H = tp.height, h = tp.half, w = tp.w;
     const int col0 = xs + 1 - h + CPL * lane;  // image column of this lane's sub-column 0 (interior: no clamp)
     const int x0 = xs + CPL * lane;            // first output column of this lane
-    // interior strips: every output column exists
-    const bool lane_has_out = (CPL * lane < fp.uo) && (!EDGE || x0 < tp.ow);
-    const bool full8 = lane_has_out && (!EDGE || x0 + CPL <= tp.ow);
+    // interior strips with uo a multiple of 8 (FAST): every lane below uo has its 8 outputs.  Otherwise the last lane with
+    // outputs may hold fewer: the row ends (EDGE), or uo is not a multiple of 8 (strip_layout: a ragged uo that saves a strip)
+    const int xlim = min(xs + fp.uo, tp.ow);
+    const bool lane_has_out = FAST ? CPL * lane < fp.uo : x0 < xlim;
+    const bool full8 = FAST ? lane_has_out : x0 + CPL <= xlim;
     const int far_addr0 = (lane + LO) * 4, far_addr1 = far_addr0 + 4;
     const i32x4 rsrc = page_rsrc(img);
     const int step = (int)istep;
@@ -795,7 +797,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const float K = fmaf(fp.w2f, Qsum[c], -(Ssum[c] * Ssum[c]));
-                if (lane_has_out && (!EDGE || x0 + c < tp.ow)) vmax_lane = fmaxf(vmax_lane, K);
+                if (lane_has_out && (!EDGE || x0 + c < tp.ow)) vmax_lane = fmaxf(vmax_lane, K);  // (Wolf-Jolion: uo is a multiple of 8)
             }
         } else {
         // the compared pixels come as packed bytes (one 8-byte load, 8 v_cvt_f32_ubyte): the kernel leans on the
@@ -832,7 +834,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             if (unsure) {
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
-                    if (EDGE && x0 + c >= tp.ow) continue;
+                    if (!FAST && x0 + c >= xlim) continue;
                     if (pv_cur.v[c] == 0.0f) continue;  // 0 > T8 is false whatever T is
                     float v32;
                     const float t = eval32f<METHOD>(fp, Ssum[c], Qsum[c], fmaf(pv_cur.v[c], kZ, pk.p0), pk, &v32);
@@ -859,8 +861,10 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
                 unsigned b = (((lo & 0x01010101u) * 0x01020408u) >> 24) | ((((hi & 0x01010101u) * 0x01020408u) >> 20) & 0xf0u);
                 if (EDGE && !full8) b &= (1u << (tp.ow - x0)) - 1u;  // pixels past the row end stay 0
                 out[(size_t)y * ostep + (x0 >> 3)] = (uint8_t)b;
-            } else if (EDGE && !full8) {
-                store_tail(out + (size_t)y * ostep + x0, lo, hi, tp.ow - x0);
+            } else if (!FAST && !full8) {
+                // (interior strip: only a ragged uo gets here and the byte count is the same for every strip and row - scalar
+                // branches inside store_tail; a per-lane count costs ~15 instructions a row more)
+                store_tail(out + (size_t)y * ostep + x0, lo, hi, EDGE ? xlim - x0 : fp.uo & 7);
             } else if (FAST || fp.nt_store) {
                 typedef unsigned u2v __attribute__((ext_vector_type(2)));
                 u2v o = {lo, hi};
@@ -986,7 +990,7 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     constexpr bool kFloatOk = METHOD != kWolfCollect;  // (sweep B revisits few segments and queues exact candidates: integer)
     if (kFloatOk && !WIDE && fp.flt) {
         // (wave-uniform dispatch, once per wavefront: the row loop itself is branch-free in the usual configuration)
-        const bool fast = !fp.bit_out && fp.nt_store && !fp.need_p0;
+        const bool fast = !fp.bit_out && fp.nt_store && !fp.need_p0 && !(fp.uo & 7);
 #define PRL_FLT_LOOP(LOV)                                                                                                          \
     do {                                                                                                                           \
         if (!interior) strip_loop_f<METHOD, SH, LOV, false, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);  \
@@ -1506,15 +1510,30 @@ size_t fused_small_bytes(int)
            sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(float) * kSegmaxCap + sizeof(unsigned) * (size_t)kWorkCap;
 }
 
-// Strips of a row: uo output columns each, fetched with w - 1 halo columns.  When everything from the last lane of what would
-// be the last but one strip onwards is right-hand padding (copies of the border column), that strip takes the rest of the
-// row as well: the totals of the lanes beyond the wavefront are known without fetching them (strip_loop, `ext`).  Up to
-// 512 - h - 7 outputs instead of 512 - (w - 1); an A4 row (2479 outputs) at the default w = 101 takes 6 strips instead of
-// 7, a 4096-column row 10 instead of 11.  Wide windows only (the wavefront-scan form of the horizontal sums).
-static int strip_layout(const ThrParams& tp, int uo, int* ext)
+// Strips of a row: uo output columns each, fetched with w - 1 halo columns; uo = 512 - (w - 1) rounded down to a multiple of 8,
+// which keeps a lane's 8 outputs whole (8-byte mask stores, one byte of the bit plane).  Two ways to save the last strip:
+//  * ragged uo (float32 pipeline, byte masks, not Wolf-Jolion whose sweeps count on whole lanes): the unrounded 512 - (w - 1)
+//    when that takes a strip less - the last lane of every strip then stores 2, 4 or 6 bytes.  A4 rows at NICK's default
+//    w = 21 (2459 outputs): 5 strips of 492 instead of 6 of 488.
+//  * extended last strip (wide windows, the wavefront-scan form of the horizontal sums): when everything from the last lane
+//    of what would be the last but one strip onwards is right-hand padding (copies of the border column), that strip takes the
+//    rest of the row as well: the totals of the lanes beyond the wavefront are known without fetching them (strip_loop, `ext`).
+//    Up to 512 - h - 7 outputs instead of 512 - (w - 1); an A4 row (2479 outputs) at the default w = 101 takes 6 strips instead
+//    of 7, a 4096-column row 10 instead of 11.
+static int strip_layout(const ThrParams& tp, bool flt, bool bit_out, int* uo_out, int* ext)
 {
-    int n = (tp.ow + uo - 1) / uo;
+    int uo = ((SW - (tp.w - 1)) / 8) * 8;
     *ext = 0;
+    *uo_out = uo;
+    if (uo <= 0) return 0;
+    int n = (tp.ow + uo - 1) / uo;
+    if (flt && !bit_out && tp.method != PRL_WOLFJOLION && env_knobs().ragged_uo) {
+        const int uo_r = SW - (tp.w - 1), n_r = (tp.ow + uo_r - 1) / uo_r;
+        if (n_r < n) {
+            n = n_r;
+            uo = *uo_out = uo_r;
+        }
+    }
     if (!env_knobs().ext_strip || (tp.w - 1) / 8 < 5 || n < 2) return n;
     const int xs = (n - 2) * uo;  // first output column of the strip that would take over
     if (xs + 1 - tp.half + 8 * 63 >= tp.width - 1 && tp.ow - xs <= SW) {
@@ -1524,17 +1543,18 @@ static int strip_layout(const ThrParams& tp, int uo, int* ext)
     return n;
 }
 
-extern "C" int prl_hip_internal_strip_layout(int w, int width, int ow, int* ext)
+extern "C" int prl_hip_internal_strip_layout(int method, int w, int width, int ow, int bit_out, int* uo_ext)
 {
-    // test hook (not in the public header): strips per row and whether the last one is an extended one
+    // test hook (not in the public header): strips per row; uo_ext[0] = outputs per strip, [1] = the last strip is an extended one
     ThrParams tp{};
+    tp.method = method;
     tp.w = w;
     tp.half = w / 2;
     tp.width = width;
+    tp.height = 1;
     tp.ow = ow;
-    const int uo = ((SW - (w - 1)) / 8) * 8;
-    *ext = 0;
-    return uo > 0 ? strip_layout(tp, uo, ext) : 0;
+    double cq;
+    return strip_layout(tp, flt_usable(tp, (size_t)width, &cq), bit_out != 0, &uo_ext[0], &uo_ext[1]);
 }
 
 // Pages one fused_run call may take.  Wolf-Jolion keeps one float per wavefront of the call (sweep A -> sweep B), kSegmaxCap
@@ -1562,8 +1582,9 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     // non-temporal mask stores: the output stream is never re-read, and keeping it out of L2 leaves the cache to the
     // window rows that ARE re-read (the leaving row, the compared-pixel row): 4.31-4.47 -> 4.15 ms on 256 x 4K pages
     fp.nt_store = env_knobs().nt_store ? 1 : 0;
-    fp.uo = ((SW - (tp.w - 1)) / 8) * 8;
-    fp.n_strips = strip_layout(tp, fp.uo, &fp.ext);
+    double cq = 1.0;
+    fp.flt = flt_usable(tp, src.step, &cq) ? 1 : 0;
+    fp.n_strips = strip_layout(tp, fp.flt != 0, bit_out, &fp.uo, &fp.ext);
     // Row segments.  Long segments amortise the (w-1)-row warm-up, short ones fill the chip and keep the tail short when it
     // drains; workgroups start in index order, so the segments come in TIERS of decreasing length (guided scheduling): each tier
     // takes about half of the rows that are left, in segments sized for ~two rounds of the chip's wavefront slots, down to a
@@ -1637,8 +1658,6 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         fp.xcd_waves = (unsigned)xw;
     }
     fp.lane_off = (tp.w - 1) / 8;
-    double cq = 1.0;
-    fp.flt = flt_usable(tp, src.step, &cq) ? 1 : 0;
     const FusedBounds b = fused_bounds(tp, fp.flt ? cq : 1.0);  // margins of the threshold sweep
     const FusedBounds b1 = fused_bounds(tp);                    // integer-pipeline margins (Wolf-Jolion's sweep B, literal noise terms)
     const double Z = (double)kZ, f = tp.f;

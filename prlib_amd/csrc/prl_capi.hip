@@ -70,6 +70,7 @@ const EnvKnobs& env_knobs()
         if (k.rows_per_seg) k.rows_per_seg = std::max(16, k.rows_per_seg);
         k.tiers = !is0("PRL_HIP_TIERS");
         k.ext_strip = !is0("PRL_HIP_EXT_STRIP");
+        k.ragged_uo = !is0("PRL_HIP_RAGGED_UO");
         k.byte_mask = std::getenv("PRL_HIP_BYTE_MASK") != nullptr;
         k.morph_rps = (int)geti("PRL_MORPH_RPS", 0);
         if (k.morph_rps) k.morph_rps = std::max(8, k.morph_rps);

@@ -92,6 +92,7 @@ struct EnvKnobs {
     int rows_per_seg = 0;         // PRL_HIP_ROWS_PER_SEG (0 = chosen from the batch size)
     bool tiers = true;            // PRL_HIP_TIERS=0      one segment length for the whole call (A/B of the tiered schedule)
     bool ext_strip = true;        // PRL_HIP_EXT_STRIP=0  no extended last strip (binarize_fused.hip strip_layout)
+    bool ragged_uo = true;        // PRL_HIP_RAGGED_UO=0  outputs per strip always a multiple of 8
     bool debug = false;           // PRL_HIP_DEBUG
     bool byte_mask = false;       // PRL_HIP_BYTE_MASK    byte instead of bit-plane hand-off to the morphology pass
     int morph_rps = 0, morph_wpb = 1;   // PRL_MORPH_RPS, PRL_MORPH_WPB

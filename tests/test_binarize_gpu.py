@@ -591,3 +591,20 @@ def test_extended_last_strip(prl, oracle, cuda_device, method, k, win, widths):
         _check(prl, oracle, cuda_device, _pages((ht, wd), kinds, seed=wd), method, win, k, 0)
     # the bit-plane hand-off to the morphology pass on an extended strip
     _check(prl, oracle, cuda_device, _pages((win + 40, widths[1]), ["doc", "noise"], seed=3), method, win, k, 2)
+
+
+@pytest.mark.parametrize("method,k", [(SAUVOLA, 0.2), (NIBLACK, -0.2), (NICK, -0.1), (WOLFJOLION, 0.3), (FENG, 0.0)])
+@pytest.mark.parametrize("win,outs", [
+    (21, (488, 489, 491, 492, 493, 977, 984, 985, 1470, 2459)),   # 488 / 492 outputs per strip
+    (31, (481, 482, 483, 961, 964, 965)),                         # 480 / 482
+    (15, (497, 498, 499, 994, 996, 997)),                         # 496 / 498
+])
+def test_ragged_strips(prl, oracle, cuda_device, method, k, win, outs):
+    """Float32 pipeline with a strip width that is not a multiple of 8 (binarize_fused.hip strip_layout: taken when it saves
+    a strip): the last lane of every strip stores 2, 4 or 6 bytes.  Output widths around every switch point."""
+    for ow in outs:
+        wd = ow + 1 if method in (SAUVOLA, NIBLACK) else ow + win
+        _check(prl, oracle, cuda_device, _pages((win + 45, wd), ["doc", "noise", "dark_corner"], seed=ow), method, win, k, 0)
+    wd = outs[1] + 1 if method in (SAUVOLA, NIBLACK) else outs[1] + win
+    _check(prl, oracle, cuda_device, _pages((win + 45, wd), ["doc", "noise"], seed=5), method, win, k, 2)   # bit plane: multiple of 8
+    _check(prl, oracle, cuda_device, _pages((win + 45, wd), ["doc", "noise"], seed=6), method, win, k, -1)

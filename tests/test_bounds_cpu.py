@@ -154,33 +154,42 @@ def test_float32_pipeline_q_error_bound(prl, w):
 
 
 def test_strip_layout(prl):
-    """Strips per row (binarize_fused.hip strip_layout): the extended last strip saves the seventh strip of an A4 row and the
-    eleventh of a 4096-column row at the default w = 101; narrow windows and rows without a small remainder are untouched;
-    the extended strip never has more than 64 lanes of outputs and its last lane is padding."""
+    """Strips per row (binarize_fused.hip strip_layout).  The extended last strip saves the seventh strip of an A4 row and
+    the eleventh of a 4096-column row at the default w = 101; a ragged uo saves the sixth strip of an A4 row at NICK's
+    default w = 21; rows without a small remainder, bit-plane output and Wolf-Jolion keep uo a multiple of 8; an extended
+    strip never has more than 64 lanes of outputs and its last lane is padding."""
     from prlib_amd import _capi
 
+    SAUVOLA, NIBLACK, WOLFJOLION, NICK, FENG = range(5)
     L = _capi.lib()
-    L.prl_hip_internal_strip_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
-    ext = C.c_int(0)
+    L.prl_hip_internal_strip_layout.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)]
+    out = (C.c_int * 2)()
 
-    def layout(w, width, ow):
-        n = L.prl_hip_internal_strip_layout(w, width, ow, C.byref(ext))
-        return n, ext.value
+    def layout(method, w, width, bit_out=0):
+        ow = width - 1 if method in (SAUVOLA, NIBLACK) else width - w
+        n = L.prl_hip_internal_strip_layout(method, w, width, ow, bit_out, out)
+        return n, out[0], out[1]
 
-    assert layout(101, 2480, 2479) == (6, 1)     # Sauvola / Niblack, A4 at 300 dpi
-    assert layout(101, 4096, 4095) == (10, 1)
-    assert layout(101, 2480, 2480 - 101) == (6, 0)   # Wolf-Jolion / NICK / Feng: 2379 outputs, six plain strips
-    assert layout(31, 4096, 4095) == (9, 0)      # the chain form of the horizontal sums: never
-    assert layout(31, 2480, 2479) == (6, 0)
-    assert layout(41, 486, 485) == (1, 1) and layout(41, 487, 486) == (2, 0)
-    assert layout(101, 456, 455) == (1, 1) and layout(101, 457, 456) == (2, 0)
-    for w in (41, 51, 101, 151, 201, 257):
-        uo, h = ((512 - (w - 1)) // 8) * 8, w // 2
+    assert layout(NIBLACK, 101, 2480) == (6, 408, 1)     # A4 at 300 dpi, the header defaults
+    assert layout(SAUVOLA, 101, 4096) == (10, 408, 1)
+    assert layout(NICK, 101, 2480) == (6, 408, 0)        # 2379 outputs: six plain strips
+    assert layout(SAUVOLA, 31, 4096) == (9, 480, 0)      # the headline: 8.5 strips of work either way
+    assert layout(SAUVOLA, 31, 2480) == (6, 480, 0)
+    assert layout(NICK, 21, 2480) == (5, 492, 0)         # 2459 outputs = 5 x 492 - 1
+    assert layout(NICK, 21, 2480, bit_out=1) == (6, 488, 0)
+    assert layout(WOLFJOLION, 21, 2480) == (6, 488, 0)
+    assert layout(SAUVOLA, 41, 486) == (1, 472, 1) and layout(SAUVOLA, 41, 487) == (2, 472, 0)
+    assert layout(SAUVOLA, 101, 456) == (1, 408, 1) and layout(SAUVOLA, 101, 457) == (2, 408, 0)
+    for w in (9, 15, 21, 31, 41, 51, 101, 151, 201, 257):
+        uo8, h = ((512 - (w - 1)) // 8) * 8, w // 2
         for width in range(w + 2, 2200, 3):
             ow = width - 1
-            n, e = layout(w, width, ow)
+            n, uo, e = layout(SAUVOLA, w, width)
+            assert uo in (uo8, 512 - (w - 1))
             plain = -(-ow // uo)
-            assert n == plain - e
+            assert n == plain - e and n <= -(-ow // uo8)
+            if uo != uo8:
+                assert w <= 31 and not e and n < -(-ow // uo8)
             if e:
                 xs = (n - 1) * uo
                 assert ow - xs <= 512 and xs + 1 - h + 504 >= width - 1
