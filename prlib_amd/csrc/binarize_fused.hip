@@ -1621,7 +1621,10 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         single_tier(rps);
     } else {
         for (int fl = floor_rps;; fl *= 2) {
-            int n = 0, rows_left = tp.oh, row0 = 0, prev = 512;
+            // (Wolf-Jolion: sweep B revisits the few segments that hold a candidate for the variance maximum, one wavefront
+            // each, and lasts as long as its longest segment takes a lone wavefront - shorter first tiers there)
+            int n = 0, rows_left = tp.oh, row0 = 0;
+            int prev = std::max(fl, tp.method == PRL_WOLFJOLION ? env_knobs().wolf_tier_max : 512);
             constexpr int kMaxTiers = (int)(sizeof(fp.tier) / sizeof(fp.tier[0]));
             while (rows_left > 0) {
                 const double want = (double)PS * rows_left / (2.0 * (double)slots);

@@ -71,6 +71,7 @@ const EnvKnobs& env_knobs()
         k.tiers = !is0("PRL_HIP_TIERS");
         k.ext_strip = !is0("PRL_HIP_EXT_STRIP");
         k.ragged_uo = !is0("PRL_HIP_RAGGED_UO");
+        k.wolf_tier_max = (int)std::max(32ll, std::min(512ll, geti("PRL_HIP_WOLF_TIER_MAX", 128)));
         k.byte_mask = std::getenv("PRL_HIP_BYTE_MASK") != nullptr;
         k.morph_rps = (int)geti("PRL_MORPH_RPS", 0);
         if (k.morph_rps) k.morph_rps = std::max(8, k.morph_rps);

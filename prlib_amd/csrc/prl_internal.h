@@ -93,6 +93,7 @@ struct EnvKnobs {
     bool tiers = true;            // PRL_HIP_TIERS=0      one segment length for the whole call (A/B of the tiered schedule)
     bool ext_strip = true;        // PRL_HIP_EXT_STRIP=0  no extended last strip (binarize_fused.hip strip_layout)
     bool ragged_uo = true;        // PRL_HIP_RAGGED_UO=0  outputs per strip always a multiple of 8
+    int wolf_tier_max = 128;      // PRL_HIP_WOLF_TIER_MAX longest row segment of a tiered Wolf-Jolion call (profiles/r03/wolf_tier_max.txt)
     bool debug = false;           // PRL_HIP_DEBUG
     bool byte_mask = false;       // PRL_HIP_BYTE_MASK    byte instead of bit-plane hand-off to the morphology pass
     int morph_rps = 0, morph_wpb = 1;   // PRL_MORPH_RPS, PRL_MORPH_WPB
