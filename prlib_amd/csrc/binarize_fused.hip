@@ -1622,9 +1622,11 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     } else {
         for (int fl = floor_rps;; fl *= 2) {
             // (Wolf-Jolion: sweep B revisits the few segments that hold a candidate for the variance maximum, one wavefront
-            // each, and lasts as long as its longest segment takes a lone wavefront - shorter first tiers there)
+            // each, and lasts as long as its longest segment takes a lone wavefront - shorter first tiers there: 256 A4 pages,
+            // w=31: sweep B 295 -> 99 us, the call 3.97 -> 3.82 ms; with wide windows the extra warm-up rows of the two other
+            // sweeps cost what sweep B saves, so the cap stays two floors up - profiles/r03/wolf_tier_max.txt)
             int n = 0, rows_left = tp.oh, row0 = 0;
-            int prev = std::max(fl, tp.method == PRL_WOLFJOLION ? env_knobs().wolf_tier_max : 512);
+            int prev = std::max(fl, tp.method == PRL_WOLFJOLION ? std::max(env_knobs().wolf_tier_max, 2 * floor_rps) : 512);
             constexpr int kMaxTiers = (int)(sizeof(fp.tier) / sizeof(fp.tier[0]));
             while (rows_left > 0) {
                 const double want = (double)PS * rows_left / (2.0 * (double)slots);
