@@ -375,7 +375,9 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     };
 
     // warm-up: vertical sums over padded rows ys+1 .. ys+w-1
-#pragma unroll 2
+    // (8 rows in flight: a lone wavefront of a small batch waits for each fetch - 4 A4 pages, w=101: 0.090 -> 0.081 ms; 256
+    // pages: -2..-3 %, profiles/r03/warm_unroll.txt)
+#pragma unroll 8
     for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
         const uint2 v = load_win(pr);
         track_min(v);
@@ -717,7 +719,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         if (!SWEEP_A) return;
         pmin = fminf(fminf(pmin, fminf(v.v[0], v.v[1])), fminf(fminf(v.v[2], v.v[3]), fminf(fminf(v.v[4], v.v[5]), fminf(v.v[6], v.v[7]))));
     };
-#pragma unroll 2
+#pragma unroll 4
     for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
         const F8 v = load_win(pr);
         track_min(v);
@@ -1597,8 +1599,10 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     const long long PS = (long long)n_pages * fp.n_strips;   // page-strips
     const long long slots = 5120;                             // 256 CUs x 20 wavefronts
     auto waves_at = [&](int r) { return PS * ((tp.oh + r - 1) / r); };
-    int min_rps = 16;
-    while (min_rps < (tp.w - 1) / 4) min_rps *= 2;
+    // (shortest segment of a small batch: one A4 page, Niblack w=101 - 32 rows 0.067 ms, 16 rows 0.056, 8 rows 0.054; one 4096^2
+    // page, w=15 - 16 / 8 / 4 rows all 0.030-0.033 ms)
+    int min_rps = 8;
+    while (min_rps < (tp.w - 1) / 8) min_rps *= 2;
     int floor_rps = 32;                                       // tiers: shortest segment = pow2ceil(w - 1) in [32, 128]
     while (floor_rps < tp.w - 1 && floor_rps < 128) floor_rps *= 2;
     floor_rps = std::max(floor_rps, min_rps);
@@ -1613,7 +1617,10 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     if (!tiers_on) {
         int rps = 128;
         if (waves_at(128) < 40000 && tp.w - 1 <= 64) rps = 64;   // (64 A4 pages, w=101: 128 rows 0.78 ms, 64 rows 0.80)
-        while (rps > min_rps && waves_at(rps) < 4096) rps /= 2;  // small batches: halve while the chip is far from full
+        // small batches: halve while the chip is far from full (wide windows stop earlier, their warm-up rows weigh more:
+        // 4 A4 pages, w=101 - 32 rows (2630 wavefronts) 0.078 ms, 16 rows 0.091; 2 pages - 0.082 / 0.070, profiles/r03/small_batches_floor8.txt)
+        const long long fill = tp.w - 1 > 64 ? 2048 : 4096;
+        while (rps > min_rps && waves_at(rps) < fill) rps /= 2;
         // (32 x 4K pages: 40 .. 72 rows per segment all measure 0.445-0.478 ms, whole or fractional rounds of the chip's wavefront
         // slots alike - profiles/r03/strong_proxy.txt; a wavefront lives ~160 us of the kernel's 450: ramp-up and drain, not the tail)
         if (env_knobs().rows_per_seg) rps = env_knobs().rows_per_seg;  // tuning knob

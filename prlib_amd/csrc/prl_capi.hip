@@ -67,7 +67,7 @@ const EnvKnobs& env_knobs()
         k.flt = !is0("PRL_HIP_FLT");
         k.nt_store = !is0("PRL_HIP_NT");
         k.rows_per_seg = (int)geti("PRL_HIP_ROWS_PER_SEG", 0);
-        if (k.rows_per_seg) k.rows_per_seg = std::max(16, k.rows_per_seg);
+        if (k.rows_per_seg) k.rows_per_seg = std::max(4, k.rows_per_seg);
         k.tiers = !is0("PRL_HIP_TIERS");
         k.ext_strip = !is0("PRL_HIP_EXT_STRIP");
         k.ragged_uo = !is0("PRL_HIP_RAGGED_UO");
