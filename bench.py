@@ -344,7 +344,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak" if args.scaling == "both" else args.scaling,
             "vs_baseline": None,
-            "dtype": "u8 in/out; exact integer window sums (u32, f32 below 2^24 in interior strips); f32 decision with f64/literal refinement",
+            "dtype": "u8 in/out; exact integer window sums (u32; f32 below 2^24 for windows up to 31); f32 decision with f64/literal refinement",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.pages} x {W}x{H} u8 pages {'in total' if args.scaling == 'strong' else 'per GPU'}, "
