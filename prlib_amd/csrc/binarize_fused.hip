@@ -632,7 +632,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wundefined-internal"
 __device__ f32x4 buf_load_fmt_xyzw(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ void buf_store_x2(i32x2 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
 #pragma clang diagnostic pop
+
+// Raw buffer resource over the first `limit` bytes of ONE row of an output page (the range check of a raw buffer covers the
+// scalar offset too, so the row address goes into the base: two scalar instructions a row).  The check works per dword: an
+// 8-byte store whose second dword starts at `limit` writes its first dword and drops the second - the partial store of a
+// ragged strip's last lane (4 valid bytes) without a divergent branch.
+__device__ __forceinline__ i32x4 clip_rsrc(unsigned long long a, int limit)
+{
+    i32x4 r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((a >> 32) & 0xffffu);
+    r.z = limit;
+    r.w = (4 | (5 << 3) | (6 << 6) | (7 << 9)) | (7 << 12) | (4 << 15);   // 32-bit data, untyped access
+    return r;
+}
 
 // gfx9 buffer resource over one page: raw (stride 0, byte offsets), no range limit, 8_8_8_8 USCALED -> x, y, z, w
 __device__ __forceinline__ i32x4 page_rsrc(gcptr page)
@@ -697,6 +713,9 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     const int step = (int)istep;
     const EdgeFix ew = EDGE ? make_edge(col0, tp.width) : EdgeFix{0, 0u, 0u};
     const EdgeFix ep = EDGE ? make_edge(x0, tp.width) : EdgeFix{0, 0u, 0u};  // lanes without output fetch a clamped (ignored) location
+    // ragged strip whose last lane keeps 4 bytes: range-clipped buffer stores instead of a divergent partial store (wave-uniform)
+    const bool clip4 = !FAST && !EDGE && !fp.bit_out && fp.nt_store && (fp.uo & 7) == 4;
+    unsigned long long orow = (unsigned long long)(uint8_t*)out + (unsigned long long)ys * ostep;   // row y of the output page (clip4)
     auto to_f8 = [](uint2 b) -> F8 {
         F8 r;
 #pragma unroll
@@ -863,6 +882,9 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
                 unsigned b = (((lo & 0x01010101u) * 0x01020408u) >> 24) | ((((hi & 0x01010101u) * 0x01020408u) >> 20) & 0xf0u);
                 if (EDGE && !full8) b &= (1u << (tp.ow - x0)) - 1u;  // pixels past the row end stay 0
                 out[(size_t)y * ostep + (x0 >> 3)] = (uint8_t)b;
+            } else if (!FAST && clip4) {
+                i32x2 o = {(int)lo, (int)hi};
+                buf_store_x2(o, clip_rsrc(orow, xlim), x0, 0, 2);   // aux 2: non-temporal
             } else if (!FAST && !full8) {
                 // (interior strip: only a ragged uo gets here and the byte count is the same for every strip and row - scalar
                 // branches inside store_tail; a per-lane count costs ~15 instructions a row more)
@@ -878,6 +900,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         }
 
         pv_ptr += istep;  // row y + 1 <= H - 1 exists for every output row
+        orow += ostep;
         pvb = gload8(pv_ptr);
         }  // !SWEEP_A
 
