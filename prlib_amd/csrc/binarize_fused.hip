@@ -273,6 +273,32 @@ __device__ __forceinline__ uint2 gload8(gcptr p)
     return v;
 }
 
+// ---- raw buffer access (strip_loop_f) -----------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wundefined-internal"
+__device__ f32x4 buf_load_fmt_xyzw(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ void buf_store_x2(i32x2 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
+__device__ i32x2 buf_load_x2(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2i32");
+#pragma clang diagnostic pop
+
+// Raw buffer resource over the first `limit` bytes of ONE row of an output page (the range check of a raw buffer covers the
+// scalar offset too, so the row address goes into the base: two scalar instructions a row).  The check works per dword: an
+// 8-byte store whose second dword starts at `limit` writes its first dword and drops the second - the partial store of a
+// ragged strip's last lane (4 valid bytes) without a divergent branch.
+__device__ __forceinline__ i32x4 clip_rsrc(unsigned long long a, int limit)
+{
+    i32x4 r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((a >> 32) & 0xffffu);
+    r.z = limit;
+    r.w = (4 | (5 << 3) | (6 << 6) | (7 << 9)) | (7 << 12) | (4 << 15);   // 32-bit data, untyped access
+    return r;
+}
+
+
 // Per-lane constants of the replicate clamp for an 8-byte row fetch: the fetch address is clamped into the row
 // (colc) and the wanted bytes are picked out of the fetched ones afterwards (edge strips only).  Wanted byte c is
 // image column clamp(col + c, 0, W-1) = fetched byte clamp(col + c, 0, W-1) - colc, a fixed byte permutation per
@@ -353,7 +379,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
 
     auto load_win = [&](int padded_row) -> uint2 {
         const size_t ro = (size_t)clampi(padded_row - h, 0, H - 1) * istep;  // wave-uniform
-        uint2 v = gload8(img + ro + ew.colc);
+        uint2 v = gload8(img + ro + ew.colc);   // (through a buffer resource like strip_loop_f's: w=101 +2.5 %, w=51 +8.5 % - slower here)
         if (EDGE) v = apply_edge(v, ew);
         return v;
     };
@@ -627,29 +653,6 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
 // Q = (E_far - E_own) + W can pass 2^24 and round: at most `flt_delta` units in all, and only when Q itself is at
 // least 2^24 - 8 (w-1) 65025 - which fused_bounds() turns into the relative error `cq u` of Q~ that widens eps1.
 // Queued pixels carry no sums: k_refine rebuilds S and Q exactly from the page when fp.flt is set.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wundefined-internal"
-__device__ f32x4 buf_load_fmt_xyzw(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
-typedef int i32x2 __attribute__((ext_vector_type(2)));
-__device__ void buf_store_x2(i32x2 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
-#pragma clang diagnostic pop
-
-// Raw buffer resource over the first `limit` bytes of ONE row of an output page (the range check of a raw buffer covers the
-// scalar offset too, so the row address goes into the base: two scalar instructions a row).  The check works per dword: an
-// 8-byte store whose second dword starts at `limit` writes its first dword and drops the second - the partial store of a
-// ragged strip's last lane (4 valid bytes) without a divergent branch.
-__device__ __forceinline__ i32x4 clip_rsrc(unsigned long long a, int limit)
-{
-    i32x4 r;
-    r.x = (int)(unsigned)a;
-    r.y = (int)((a >> 32) & 0xffffu);
-    r.z = limit;
-    r.w = (4 | (5 << 3) | (6 << 6) | (7 << 9)) | (7 << 12) | (4 << 15);   // 32-bit data, untyped access
-    return r;
-}
-
 // gfx9 buffer resource over one page: raw (stride 0, byte offsets), no range limit, 8_8_8_8 USCALED -> x, y, z, w
 __device__ __forceinline__ i32x4 page_rsrc(gcptr page)
 {
@@ -722,7 +725,12 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         for (int c = 0; c < CPL; ++c) r.v[c] = (float)byte_of(b, c);
         return r;
     };
-    auto edge_row = [&](int off) -> uint2 { return apply_edge(gload8(img + off + ew.colc), ew); };  // bytes in place (EDGE)
+    const i32x4 prsrc = clip_rsrc((unsigned long long)(const uint8_t*)img, -1);   // the page as untyped bytes, no range limit
+    auto bload8 = [&](int col, int off) -> uint2 {   // 8 bytes at column `col` (per lane) of the row at byte offset `off` (scalar)
+        const i32x2 v = buf_load_x2(prsrc, col, off, 0);
+        return make_uint2((unsigned)v.x, (unsigned)v.y);
+    };
+    auto edge_row = [&](int off) -> uint2 { return apply_edge(bload8(ew.colc, off), ew); };  // bytes in place (EDGE)
 
     auto load_win = [&](int padded_row) -> F8 {
         const int off = clampi(padded_row - h, 0, H - 1) * step;
@@ -758,7 +766,6 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     const int off_last = (H - 1) * step;
     int off_new = min((ys + w - h) * step, off_last);   // padded row ys + w
     int off_old = max((ys + 1 - h) * step, 0);          // padded row ys + 1
-    gcptr pv_ptr = img + (size_t)ys * istep + (EDGE ? ep.colc : x0);
     F8 vnew, vold;           // interior: the two window rows as floats (typed loads)
     uint2 bnew = make_uint2(0u, 0u), bold = bnew;  // EDGE: as packed bytes, converted where the slide uses them
     if constexpr (EDGE) {
@@ -770,7 +777,12 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     }
     int off_old_raw = (ys + 1 - h) * step;
     uint2 pvb = make_uint2(0u, 0u);
-    if (!SWEEP_A) pvb = gload8(pv_ptr);
+    // the compared pixels and the mask bytes go through raw buffer resources as well: the per-lane part of the address is
+    // the loop-invariant column, the row travels in a scalar register - no 64-bit vector address arithmetic per row
+    // (headline -0.7 %, 256 A4 pages NICK w=21 -4.9 %, tools/r3/bufpv_ab.sh)
+    const int pv_col = EDGE ? ep.colc : x0;
+    int pv_off = ys * step;
+    if (!SWEEP_A) pvb = bload8(pv_col, pv_off);
 #pragma unroll 1
     for (int y = ys; y < ye; ++y) {
         if constexpr (EDGE) {
@@ -890,18 +902,17 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
                 // branches inside store_tail; a per-lane count costs ~15 instructions a row more)
                 store_tail(out + (size_t)y * ostep + x0, lo, hi, EDGE ? xlim - x0 : fp.uo & 7);
             } else if (FAST || fp.nt_store) {
-                typedef unsigned u2v __attribute__((ext_vector_type(2)));
-                u2v o = {lo, hi};
-                __builtin_nontemporal_store(o, reinterpret_cast<u2v*>((uint8_t*)(out + (size_t)y * ostep + x0)));
+                i32x2 o = {(int)lo, (int)hi};
+                buf_store_x2(o, clip_rsrc(orow, -1), x0, 0, 2);   // (no range limit)
             } else {
                 uint2 o = make_uint2(lo, hi);
                 __builtin_memcpy((uint8_t*)(out + (size_t)y * ostep + x0), &o, 8);
             }
         }
 
-        pv_ptr += istep;  // row y + 1 <= H - 1 exists for every output row
         orow += ostep;
-        pvb = gload8(pv_ptr);
+        pv_off += step;  // row y + 1 <= H - 1 exists for every output row
+        pvb = bload8(pv_col, pv_off);
         }  // !SWEEP_A
 
         // slide the window one row down: new^2 - old^2 = (new - old)(new + old), one exact fma
