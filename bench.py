@@ -55,6 +55,12 @@ def parse():
                     help="1: measure roofline.traffic in this run - two child passes of this benchmark under rocprofv3 --pmc "
                          "(FETCH_SIZE, WRITE_SIZE), started before this process touches the GPU (N=1 only); 0: traffic = null")
     ap.add_argument("--ceilings", type=int, default=1, help="1: time the hand-written read / write / copy kernels on this batch")
+    ap.add_argument("--worst-case", type=int, default=1,
+                    help="1 (N=1 only): after the timed region, the same pages through the literal pipeline and a batch of adversarial "
+                         "pages (every second pixel inside the float32 decision band) through auto mode -> `worst_case`")
+    ap.add_argument("--end-to-end", type=int, default=1,
+                    help="1 (N=1 only): the batch as a host page list in pinned memory through prl_hip_binarize_batch_host "
+                         "(H2D + kernels + D2H) -> `end_to_end` (SURVEY.md 8d's second number; never `value`)")
     ap.add_argument("--lib", default=None, help="A/B tooling: load this build of libprlib_hip.so instead of the in-tree one")
     ap.add_argument("--hooks", type=int, default=0, help="A/B tooling: 1 = load libprlib_hip_testhooks.so (reads the PRL_HIP_* tuning knobs)")
     return ap.parse_args()
@@ -99,7 +105,7 @@ def measure_traffic(args):
                "--gpus", "1", "--steps", "3", "--warmup", "1", "--pages", str(args.pages), "--size", str(args.size),
                "--height", str(args.height), "--method", args.method, "--window", str(args.window), "--k", str(args.k),
                "--morph", str(args.morph), "--mode", args.mode, "--cpu-seconds", "0", "--check-pages", "0", "--traffic", "0",
-               "--ceilings", "0"] + (["--lib", args.lib] if args.lib else []) + (["--hooks", "1"] if args.hooks else [])
+               "--ceilings", "0", "--worst-case", "0", "--end-to-end", "0"] + (["--lib", args.lib] if args.lib else []) + (["--hooks", "1"] if args.hooks else [])
         env = dict(os.environ, TMPDIR="/tmp")
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
@@ -147,6 +153,124 @@ def cpu_baseline(pages_host, params_oracle, budget_s):
         "sample": f"{n} of the benchmark's pages ({w}x{h}) x {reps} passes, oracle/prl_oracle.c with {cores} OpenMP threads, "
                   f"{tn:.1f} s; single-thread 1 page: {px_page / t1 / 1e6:.2f} Mpixels/s",
     }
+
+
+def adversarial_stripes(method, w, k, eps_hint):
+    """Two gray levels (a, b) for a page of vertical stripes of period 2 (a on even columns): every interior (w-1)x(w-1) window
+    holds (w-1)/2 columns of each, so every interior pixel sees the same sums, and for the pixels on the a-columns the
+    exact-arithmetic threshold T* lies as close to a - 0.5 as any integer pair allows - inside the float32 decision band, so
+    the fast test settles none of them.  Closed forms of SURVEY.md A.1 / A.2 / A.4; None for the other methods."""
+    import numpy as np
+
+    n = (w - 1) * (w - 1) // 2                       # pixels of each level in a window ((w-1) even)
+    f = 1.0 / (w * w)
+    a, b = np.meshgrid(np.arange(1, 256, dtype=np.float64), np.arange(0, 256, dtype=np.float64), indexing="ij")
+    m = f * n * (a + b)
+    q = f * n * (a * a + b * b)
+    s = np.sqrt(np.maximum(q - m * m, 0.0))
+    if method == 0:
+        t = m * (s * (k / 128.0) + (1.0 - k))
+    elif method == 1:
+        t = s * k + m
+    elif method == 3:
+        t = m + k * np.sqrt(q)
+    else:
+        return None
+    d = np.abs(t - (a - 0.5))
+    d[a == b] = np.inf                               # (a flat page is a different experiment)
+    i = np.unravel_index(np.argmin(d), d.shape)
+    return int(a[i]), int(b[i]), float(d[i])
+
+
+def _time_steps(prlib_amd, dev, fn, reps):
+    import torch
+
+    fn()
+    prlib_amd.finish(dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    prlib_amd.finish(dev)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / reps
+
+
+def worst_case_legs(args, prlib_amd, _capi, L, dev, pages, out, params, method, g, W, H):
+    """What the same call costs when the input defeats the fast path.  (a) `literal`: the benchmark's own pages through
+    PRL_MODE_LITERAL (float64 integral planes, 16 B per padded pixel, in chunks) - what every page costs that overflows a
+    queue.  (b) `adversarial`: pages of two-level stripes chosen so that half of all pixels sit inside the float32 decision
+    band (adversarial_stripes): the threshold sweep queues them, the queue overflows, the page is flagged and redone by the
+    literal pipeline - auto mode's worst case = fused pass + literal pass + the host round trip per flagged page."""
+    import numpy as np
+    import torch
+
+    res = {}
+    px_page = g.out_w * g.out_h
+    n_lit = min(pages.shape[0], 32)
+    prlib_amd.set_exec_mode(1)
+    try:
+        t = _time_steps(prlib_amd, dev, lambda: prlib_amd.binarize(pages[:n_lit], params, out=out[:n_lit]), 2)
+    finally:
+        prlib_amd.set_exec_mode(0)
+    res["literal"] = {"pages": int(n_lit), "ms_per_step": round(t * 1e3, 3), "value": round(n_lit * px_page / t / 1e6, 1),
+                      "unit": "Mpixels/s", "note": "PRL_MODE_LITERAL on the first pages of the benchmark batch"}
+    adv = adversarial_stripes(method, g.w, args.k, None)
+    if adv is None:
+        res["adversarial"] = None
+        return res
+    a, b, margin = adv
+    b8 = np.zeros(8, np.float64)
+    eps1 = None
+    if hasattr(L, "prl_hip_internal_fused_bounds"):
+        L.prl_hip_internal_fused_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        if L.prl_hip_internal_fused_bounds(C.byref(params), W, H, b8.ctypes.data) == 0:
+            eps1 = float(b8[5])
+    n_adv = min(pages.shape[0], 16)
+    row = torch.tensor([a, b], dtype=torch.uint8, device=dev).repeat((pages.shape[2] + 1) // 2)[: pages.shape[2]]
+    adv_pages = row.expand(n_adv, pages.shape[1], pages.shape[2]).contiguous()
+    t = _time_steps(prlib_amd, dev, lambda: prlib_amd.binarize(adv_pages, params, out=out[:n_adv]), 2)
+    st = prlib_amd.last_stats()
+    from oracle import capi as oc
+
+    want = oc.binarize(adv_pages[0, :, :W].cpu().numpy().copy(), oc.make_params(method, args.window, args.k, args.morph))
+    bad = int((want != out[0, :, : g.out_w].cpu().numpy()).sum())
+    res["adversarial"] = {
+        "pages": int(n_adv), "ms_per_step": round(t * 1e3, 3), "value": round(n_adv * px_page / t / 1e6, 1), "unit": "Mpixels/s",
+        "pattern": f"vertical stripes of period 2, levels {a} / {b}: T* - (p - 0.5) = {margin:.2e} on every interior pixel of the "
+                   f"{a}-columns (decision band eps1 = {eps1})",
+        "literal_pages": int(st.literal_pages), "refined_pixels": int(st.refined_pixels), "exact_pixels": int(st.exact_pixels),
+        "mismatching_pixels_page0": bad,
+    }
+    return res
+
+
+def end_to_end_leg(prlib_amd, dev, pages, params, g, W, H):
+    """SURVEY.md 8d's second number: the same batch as a host page list (pinned memory: the DMA engines read and write the
+    caller's pages directly) through prl_hip_binarize_batch_host on this one GPU - H2D + kernels + D2H."""
+    n = int(pages.shape[0])
+    try:
+        pin_in, pin_out = prlib_amd.PinnedPages(n, H, W), prlib_amd.PinnedPages(n, g.out_h, g.out_w)
+    except Exception as e:   # (not enough lockable host memory on this box)
+        return {"value": None, "note": f"pinned allocation failed: {e!r}"}
+    try:
+        for i0 in range(0, n, 32):
+            pin_in.array[i0:i0 + 32] = pages[i0:i0 + 32, :, :W].cpu().numpy()
+        host_pages = list(pin_in.array)
+        prlib_amd.binarize_pages_host(host_pages[:8], params, 1, out=pin_out.array[:8])   # (workspaces, chunk slots)
+        prlib_amd.binarize_pages_host(host_pages, params, 1, out=pin_out.array)
+        best = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            prlib_amd.binarize_pages_host(host_pages, params, 1, out=pin_out.array)
+            best = min(best, time.perf_counter() - t0)
+        px = n * g.out_w * g.out_h
+        return {"value": round(px / best / 1e6, 1), "unit": "Mpixels/s", "seconds": round(best, 4),
+                "host_gb_per_s": round((n * H * W + px) / best / 1e9, 2), "pages": n,
+                "note": "prl_hip_binarize_batch_host, pages and masks in pinned host memory, one GPU, best of 3; PCIe-bound, never `value`"}
+    finally:
+        pin_in.close()
+        pin_out.close()
 
 
 def main():
@@ -237,15 +361,20 @@ def main():
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)
 
     # dominant-kernel duration: HIP events recorded by the library around k_fused on the launch stream
+    # ... and around everything the call enqueues (prl_hip_last_call_ms): the other sweeps of Wolf-Jolion, refinement, fix-up,
+    # the morphology pass - what one prl::binarize*() call costs on the device
     _capi.check(L.prl_hip_set_profiling(1))
-    kms = []
+    kms, cms = [], []
     for _ in range(max(3, min(args.steps, 10))):
         step()
         ms = C.c_float(0)
         _capi.check(L.prl_hip_last_kernel_ms(C.byref(ms)))
         kms.append(ms.value)
+        _capi.check(L.prl_hip_last_call_ms(C.byref(ms)))
+        cms.append(ms.value)
     _capi.check(L.prl_hip_set_profiling(0))
     kernel_ms = sum(kms) / len(kms)
+    call_ms = sum(cms) / len(cms)
     stats = prlib_amd.last_stats()
 
     # measured ceilings of this box beside the 8 TB/s spec peak: hand-written dwordx4 kernels (16 B per lane,
@@ -273,7 +402,11 @@ def main():
     px_per_step_total = total_pages * g.out_w * g.out_h
     bytes_per_px = 3 if method == prlib_amd.WOLFJOLION else 2
     alg_bytes = n_mine * (H * W * (bytes_per_px - 1) + g.out_w * g.out_h)   # rank 0's launch
-    achieved_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    dominant_gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    call_gbs = alg_bytes / (call_ms * 1e-3) / 1e9
+    # calls with more than one heavy kernel (Wolf-Jolion's three sweeps, a morphology pass) are priced on the WHOLE call
+    multi_kernel = method == prlib_amd.WOLFJOLION or args.morph != 0 or args.mode != "auto"
+    achieved_gbs = call_gbs if multi_kernel else dominant_gbs
 
     # parity spot check (outside the timed region): first pages against the CPU oracle
     mismatches = None
@@ -311,6 +444,14 @@ def main():
         if args.cpu_seconds > 0 and world == 1:   # the CPU baseline leg runs at N=1 only
             n_host = min(n_mine, 64)
             cpu = cpu_baseline(pages[:n_host].cpu().numpy().copy(), po, args.cpu_seconds)
+
+    # ---- worst case and end to end (N = 1, outside the timed region; VERDICT r3 "next" 2) -----------------------------------
+    worst = None
+    e2e = None
+    if rank == 0 and world == 1 and args.worst_case and args.mode == "auto":
+        worst = worst_case_legs(args, prlib_amd, _capi, L, dev, pages, out, params, method, g, W, H)
+    if rank == 0 and world == 1 and args.end_to_end and args.mode == "auto":
+        e2e = end_to_end_leg(prlib_amd, dev, pages, params, g, W, H)
 
     # --scaling both (N > 1): the same job size as one GPU's weak-scaling share, now split over the ranks (strong scaling);
     # every rank re-uses the first pages of its batch, the timing protocol is the one above
@@ -359,10 +500,15 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "frac_basis": "whole call (several heavy kernels: algorithmic bytes / call_ms)" if multi_kernel
+                              else "dominant kernel (algorithmic bytes / kernel_ms; the call's other kernels are in frac_whole_call)",
+                "frac_dominant_kernel": round(dominant_gbs / HBM_PEAK_GBS, 4),
+                "frac_whole_call": round(call_gbs / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "traffic_note": traffic_note,
                 "kernel": "k_fused" if args.mode == "auto" else "literal chain",
                 "kernel_ms": round(kernel_ms, 4),
+                "call_ms": round(call_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "measured_read_gbs": ceil["measured_read_gbs"],
                 "measured_write_gbs": ceil["measured_write_gbs"],
@@ -376,6 +522,8 @@ def main():
         }
         if strong is not None:
             line["strong"] = strong
+        line["worst_case"] = worst
+        line["end_to_end"] = e2e
         print(json.dumps(line), flush=True)
     pdist.finish()
 

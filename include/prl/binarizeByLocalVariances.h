@@ -1,0 +1,8 @@
+// binarizeByLocalVariances.h - drop-in for PRLib's header of the same name (src/binarizations/binarizeByLocalVariances.h:8-12): declares prl::binarizeByLocalVariances, prl::binarizeByLocalVariancesWithoutFilters with the
+// reference's signature, defaults and CV_EXPORTS linkage.  A caller that includes "binarizeByLocalVariances.h" (as
+// samples/binarizations/binarizeSauvola_sample.cpp:25 does) builds against this repository with only its include path
+// changed to include/prl; the declarations themselves live in prl.h.
+#ifndef PRLIB_HIP_DROPIN_binarizeByLocalVariances_h
+#define PRLIB_HIP_DROPIN_binarizeByLocalVariances_h
+#include "prl.h"
+#endif  // PRLIB_HIP_DROPIN_binarizeByLocalVariances_h

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PRL_HIP_ABI_VERSION 2   /* 2: prl_chain_params grew deskew / background_normalization */
+#define PRL_HIP_ABI_VERSION 3   /* 2: prl_chain_params grew deskew / background_normalization; 3: prl_hip_last_call_ms, prl_binarize_stats.wolf_candidates */
 
 typedef enum prl_status {
     PRL_OK = 0,
@@ -100,7 +100,8 @@ typedef struct prl_binarize_stats {
     uint64_t refined_pixels;    /* decided by the in-kernel float64 interval test instead of the float32 one */
     uint64_t exact_pixels;      /* decided by the absolute-integral literal evaluation (fix-up kernel) */
     uint64_t literal_pages;     /* pages that ran the full literal pipeline */
-    uint64_t reserved[4];
+    uint64_t wolf_candidates;   /* Wolf-Jolion: pixels whose deviation was evaluated literally to find devianceMax */
+    uint64_t reserved[3];
 } prl_binarize_stats;
 
 /* ---- library / device ------------------------------------------------------------------- */
@@ -122,6 +123,10 @@ int         prl_hip_release_workspace(void);           /* free cached device scr
  * is launched on; prl_hip_last_kernel_ms() waits for them and returns the elapsed milliseconds. */
 int         prl_hip_set_profiling(int enabled);
 int         prl_hip_last_kernel_ms(float* ms);
+/* Same switch, the WHOLE call: events around everything the last binarize call of this thread enqueued on its stream (every
+ * sweep of Wolf-Jolion, interval refinement, literal fix-up, morphology pass, flag copy) - what one prl::binarize*() costs
+ * on the device.  Calls that were split into page chunks report their last chunk. */
+int         prl_hip_last_call_ms(float* ms);
 /* Deferred completion of prl_hip_binarize_*_device (process-wide switch, default off): see the comment there. */
 int         prl_hip_set_deferred_completion(int enabled);
 /* Completes every binarize call enqueued on `stream` of the current device (flag check, literal redo of overflowing

@@ -40,7 +40,7 @@ MODE_AUTO, MODE_LITERAL = 0, 1
 EXPORTED_SYMBOLS = [
     "prl_hip_abi_version", "prl_hip_strerror", "prl_hip_last_error_detail", "prl_hip_device_count",
     "prl_hip_set_device", "prl_hip_set_exec_mode", "prl_hip_get_exec_mode", "prl_hip_last_stats",
-    "prl_hip_release_workspace", "prl_hip_set_profiling", "prl_hip_last_kernel_ms", "prl_hip_set_deferred_completion", "prl_hip_finish", "prl_hip_default_params", "prl_hip_binarize_geometry",
+    "prl_hip_release_workspace", "prl_hip_set_profiling", "prl_hip_last_kernel_ms", "prl_hip_last_call_ms", "prl_hip_set_deferred_completion", "prl_hip_finish", "prl_hip_default_params", "prl_hip_binarize_geometry",
     "prl_hip_binarize_batch_device", "prl_hip_binarize_pages_device", "prl_hip_binarize_host",
     "prl_hip_morph_batch_device", "prl_hip_nlm_planes_device", "prl_hip_denoise_batch_device",
     "prl_hip_denoise_host", "prl_hip_thin_batch_device", "prl_hip_thin_host",
@@ -87,7 +87,8 @@ class BinarizeStats(C.Structure):
         ("refined_pixels", C.c_uint64),
         ("exact_pixels", C.c_uint64),
         ("literal_pages", C.c_uint64),
-        ("reserved", C.c_uint64 * 4),
+        ("wolf_candidates", C.c_uint64),
+        ("reserved", C.c_uint64 * 3),
     ]
 
 
@@ -126,6 +127,7 @@ def lib() -> C.CDLL:
         L.prl_hip_last_stats.argtypes = [P(BinarizeStats)]
         L.prl_hip_set_profiling.argtypes = [i]
         L.prl_hip_last_kernel_ms.argtypes = [P(C.c_float)]
+        L.prl_hip_last_call_ms.argtypes = [P(C.c_float)]
         L.prl_hip_set_deferred_completion.argtypes = [i]
         L.prl_hip_alloc_host.argtypes = [sz, P(vp)]
         L.prl_hip_free_host.argtypes = [vp]

@@ -93,6 +93,12 @@ class PinnedPages:
     def __exit__(self, *exc):
         self.close()
 
+    def __del__(self):   # a forgotten close() must not leak pinned memory
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 def binarize_pages_host(pages, params: BinarizeParams, n_devices: int = 0, out=None):
     """prl_hip_binarize_batch_host: a list (or N x H x W array) of equal-size uint8 host pages, sharded over the node's

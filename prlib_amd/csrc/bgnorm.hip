@@ -394,6 +394,7 @@ int prl_hip_bgnorm_host(int channels, const uint8_t* src, size_t src_step, int w
     uint8_t* d_in = static_cast<uint8_t*>(ctx->stage);
     uint8_t* d_out = d_in + in_bytes;
     hipStream_t stream = nullptr;
+    DrainOnExit drain_guard{stream};   // (direct DMA from the caller's pinned page: see prl_internal.h)
     st = stage_upload(ctx, 0, src, src_step, in_row, height, d_in, stream);
     if (st != PRL_OK) return st;
     st = prl_hip_bgnorm_batch_device(1, channels, d_in, in_bytes, in_row, width, height, d_out, out_bytes, out_row, stream);

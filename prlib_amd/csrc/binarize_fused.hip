@@ -1265,7 +1265,7 @@ __global__ void __launch_bounds__(256) k_corner_partial(PageSet src, FusedParams
                     fp.ep_host[i] = fp.ep_dev[i];
                     PageGlobals z;
                     z.imin = 255; z.smax_found = 0; z.smax_bits = 0ull; z.coeff = 0.0;
-                    z.n_refined = 0; z.n_exact = 0; z.worklist_overflow = 0; z.v32max_bits = 0;
+                    z.n_refined = 0; z.n_exact = 0; z.worklist_overflow = 0; z.v32max_bits = 0; z.n_cand = 0; z.reserved0 = 0;
                     fp.ep_dev[i] = z;   // = k_init_globals
                 }
                 if (threadIdx.x < 64) fp.ep_counters[threadIdx.x] = 0u;
@@ -1296,6 +1296,7 @@ __global__ void __launch_bounds__(256) k_wolf_final(FusedParams fp, PageGlobals*
         double m, q;
         literal_mq(acc[it], fp.tp.f, &m, &q);
         const double s = dev_from(m, q);
+        atomicAdd(&g[cand[it].page].n_cand, 1u);
         if (s == s) {  // NaN never wins minMaxLoc
             atomicMax(&g[cand[it].page].smax_bits, (unsigned long long)__double_as_longlong(s) & 0x7fffffffffffffffull);
             atomicOr(&g[cand[it].page].smax_found, 1);
@@ -1570,6 +1571,9 @@ static int strip_layout(const ThrParams& tp, bool flt, bool bit_out, int* uo_out
             uo = *uo_out = uo_r;
         }
     }
+    // (the extended strip multiplies the border column's sums with __umul24: both factors must stay below 2^24 - true for every
+    // window fused_supports() admits today (256 * 65025 < 2^24), and tied to it here should that limit ever move)
+    if ((long long)(tp.w - 1) * 65025ll >= (1ll << 24)) return n;
     if (!env_knobs().ext_strip || (tp.w - 1) / 8 < 5 || n < 2) return n;
     const int xs = (n - 2) * uo;  // first output column of the strip that would take over
     if (xs + 1 - tp.half + 8 * 63 >= tp.width - 1 && tp.ow - xs <= SW) {

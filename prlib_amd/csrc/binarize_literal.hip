@@ -48,6 +48,8 @@ __global__ void k_init_globals(PageGlobals* g, int n, unsigned* counters)
         g[i].n_exact = 0;
         g[i].worklist_overflow = 0;
         g[i].v32max_bits = 0;
+        g[i].n_cand = 0;
+        g[i].reserved0 = 0;
     }
 }
 

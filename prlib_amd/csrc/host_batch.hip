@@ -196,7 +196,7 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
     auto chunk_first = [&](int k) { return first + k * chunk; };
     auto chunk_count = [&](int k) { return std::min(chunk, count - k * chunk); };
 
-    std::thread uploader([&] {
+    auto upload_fn = [&] {
         if (hipSetDevice(dev) != hipSuccess) { pipe.fail(PRL_ERR_NO_DEVICE, "uploader: hipSetDevice"); return; }
         for (int k = 0; k < n_chunks; ++k) {
             double t0 = dbg ? Clock::now() : 0;
@@ -227,8 +227,8 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
             { std::lock_guard<std::mutex> lk(pipe.mu); pipe.uploaded = k + 1; }
             pipe.cv.notify_all();
         }
-    });
-    std::thread downloader([&] {
+    };
+    auto download_fn = [&] {
         if (hipSetDevice(dev) != hipSuccess) { pipe.fail(PRL_ERR_NO_DEVICE, "downloader: hipSetDevice"); return; }
         auto finalize = [&](int k) -> bool {   // chunk k's D2H has been enqueued: wait for it, hand the pages over, free the slot
             HostBin::Slot& s = hb.slot[k % HostBin::kSlots];
@@ -266,7 +266,20 @@ int device_worker(int dev, const prl_binarize_params* p, const prl_binarize_geom
             if (k > 0 && !finalize(k - 1)) return;   // the copy-out of chunk k-1 runs beside the DMA of chunk k
         }
         (void)finalize(n_chunks - 1);
-    });
+    };
+    // (thread creation can fail - resource exhaustion; a joinable std::thread must not be destroyed, so the first one is
+    // told to stop and joined before the error goes back to the caller)
+    std::thread uploader, downloader;
+    try {
+        uploader = std::thread(upload_fn);
+        downloader = std::thread(download_fn);
+    } catch (const std::system_error& e) {
+        pipe.fail(PRL_ERR_NOMEM, std::string("host batch: cannot start the copy threads: ") + e.what());
+        if (uploader.joinable()) uploader.join();
+        for (hipStream_t q : {hb.up, hb.run, hb.down}) (void)hipStreamSynchronize(q);
+        set_error_detail(pipe.detail);
+        return PRL_ERR_NOMEM;
+    }
 
     {
         DeferredScope deferred;  // binarize only enqueues; prl_hip_finish below closes every chunk

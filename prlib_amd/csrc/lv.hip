@@ -415,6 +415,7 @@ int prl_hip_binarize_lv_host(int with_filters, double coeff, int min_result_vari
     uint8_t* d_in = static_cast<uint8_t*>(ctx->stage);
     uint8_t* d_out = d_in + in_bytes;
     hipStream_t stream = nullptr;
+    DrainOnExit drain_guard{stream};   // (direct DMA from the caller's pinned page: see prl_internal.h)
     st = stage_upload(ctx, 0, src, src_step, in_row, height, d_in, stream);
     if (st != PRL_OK) return st;
     st = prl_hip_binarize_lv_batch_device(1, with_filters, coeff, min_result_variance, gamma, d_in, in_bytes, in_row, width, height,

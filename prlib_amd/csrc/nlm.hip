@@ -1008,6 +1008,7 @@ int prl_hip_denoise_host(int channels, float strength, const uint8_t* src, size_
     if (st != PRL_OK) return st;
     uint8_t* d_in = static_cast<uint8_t*>(ctx->stage);
     uint8_t* d_out = d_in + bytes;
+    DrainOnExit drain_guard{nullptr};   // (direct DMA from the caller's pinned page: see prl_internal.h)
     st = stage_upload(ctx, 0, src, src_step, row, height, d_in, nullptr);
     if (st != PRL_OK) return st;
     st = prl_hip_denoise_batch_device(1, channels, strength, d_in, bytes, row, width, height, d_out, bytes, row, nullptr);

@@ -14,6 +14,8 @@
 // window, binarizeSauvola.cpp:38-47) and side effects: the caller's input Mat is converted to gray
 // (:51) and replaced by the replicate-padded page (:65); the output Mat is (re)allocated (:122).
 // Define PRL_KEEP_INPUT before including to opt out of the input mutation.
+// include/prl/ holds one forwarding header per reference header (binarizeSauvola.h, ..., denoiseNLM.h), so a caller keeps
+// its #include lines and only changes the include path.
 #pragma once
 
 #if defined(__has_include)
@@ -25,54 +27,57 @@
 #ifndef PRL_HAVE_OPENCV
 #include "cvmat_shim.h"
 #endif
+#ifndef CV_EXPORTS   // (OpenCV defines it; the shim build exports the same way)
+#define CV_EXPORTS __attribute__((visibility("default")))
+#endif
 
 namespace prl {
 
-void binarizeSauvola(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 101,
+CV_EXPORTS void binarizeSauvola(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 101,
                      double thresholdCoefficient = 0.01, int morphIterationCount = 2);
 
-void binarizeNiblack(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 101,
+CV_EXPORTS void binarizeNiblack(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 101,
                      double thresholdCoefficient = 0.01, int morphIterationCount = 2);
 
-void binarizeWolfJolion(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 101,
+CV_EXPORTS void binarizeWolfJolion(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 101,
                         double thresholdCoefficient = 0.01, int morphIterationCount = 2);
 
-void binarizeNICK(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 21,
+CV_EXPORTS void binarizeNICK(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 21,
                   double thresholdCoefficient = -0.01, int morphIterationCount = 0);
 
-void binarizeFeng(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 21,
+CV_EXPORTS void binarizeFeng(cv::Mat& inputImage, cv::Mat& outputImage, int windowSize = 21,
                   double thresholdCoefficient_alpha1 = 0.75, double thresholdCoefficient_k1 = 0.2,
                   double thresholdCoefficient_k2 = 0.03, double thresholdCoefficient_gamma = 2.0,
                   int morphIterationCount = 2);
 
-void denoise(const cv::Mat& inputImage, cv::Mat& outputImage, double strength = 5.5);
+CV_EXPORTS void denoise(const cv::Mat& inputImage, cv::Mat& outputImage, double strength = 5.5);
 
 // SURVEY.md §8f rank 1 — src/thinning/thinZhangSuen.h, src/thinning/thinGuoHall.h.  8UC1 or 8UC3 (BGR is
 // converted to gray first, thinZhangSuen.cpp:78-81); foreground = pixels with bit 0 set; output 0/255.
 // std::invalid_argument for an empty image or another type (:59-68).
-void thinZhangSuen(cv::Mat& inputImage, cv::Mat& outputImage);
-void thinGuoHall(cv::Mat& inputImage, cv::Mat& outputImage);
+CV_EXPORTS void thinZhangSuen(cv::Mat& inputImage, cv::Mat& outputImage);
+CV_EXPORTS void thinGuoHall(cv::Mat& inputImage, cv::Mat& outputImage);
 
 // SURVEY.md §8f rank 4b — src/binarizations/binarizeByLocalVariances.h:8-12.  8UC3 input (the reference reads three
 // variance planes); std::invalid_argument for an empty image (binarizeByLocalVariances.cpp:16-19, :151-154).
-void binarizeByLocalVariances(cv::Mat& inputImage, cv::Mat& outputImage, double varianceThresholdCoeff = 0.125,
+CV_EXPORTS void binarizeByLocalVariances(cv::Mat& inputImage, cv::Mat& outputImage, double varianceThresholdCoeff = 0.125,
                               int minResultVariance = 25, double gamma = 2.0);
-void binarizeByLocalVariancesWithoutFilters(cv::Mat& inputImage, cv::Mat& outputImage, double varianceThresholdCoeff = 0.125,
+CV_EXPORTS void binarizeByLocalVariancesWithoutFilters(cv::Mat& inputImage, cv::Mat& outputImage, double varianceThresholdCoeff = 0.125,
                                             int minResultVariance = 10);
 
 // SURVEY.md §8f rank 3 — src/backgroundNormalization.h:40.  8UC1 -> 8UC1; 8UC3 / 8UC4 -> 8UC3 (the reference's
 // Leptonica round trip drops a fourth channel, src/formatConvert.cpp:193-206).  std::invalid_argument for an empty image
 // (src/backgroundNormalization.cpp:40-43).
-void backgroundNormalization(const cv::Mat& inputImage, cv::Mat& outputImage);
+CV_EXPORTS void backgroundNormalization(const cv::Mat& inputImage, cv::Mat& outputImage);
 
 // SURVEY.md §8f rank 4a — src/deskew/deskew.h:42, src/rotate.h:39.  deskew: gray -> Otsu -> HoughLinesP angle vote ->
 // rotate; the result is max(cols, rows) square when an angle was found (src/rotate.cpp:64-68), a clone otherwise.
 // The orientation step (src/deskew/deskew.cpp:238) is a no-op for the page the reference hands it.
-bool deskew(const cv::Mat& inputImage, cv::Mat& outputImage);
-void rotate(const cv::Mat& inputImage, cv::Mat& outputImage, double angle);
+CV_EXPORTS bool deskew(const cv::Mat& inputImage, cv::Mat& outputImage);
+CV_EXPORTS void rotate(const cv::Mat& inputImage, cv::Mat& outputImage, double angle);
 
 // BASELINE config 1 (plumbing, host only): global Otsu, the one global threshold the reference uses
 // (cv::threshold(..., THRESH_BINARY | THRESH_OTSU), src/deskew/deskew.cpp:224).  Not a GPU path.
-void binarize(cv::Mat& inputImage, cv::Mat& outputImage);
+CV_EXPORTS void binarize(cv::Mat& inputImage, cv::Mat& outputImage);
 
 }  // namespace prl

@@ -117,7 +117,7 @@ struct PendingCall {
 };
 
 struct CallStats {
-    uint64_t seq = 0, pixels = 0, refined = 0, exact = 0, literal_pages = 0;
+    uint64_t seq = 0, pixels = 0, refined = 0, exact = 0, literal_pages = 0, wolf_candidates = 0;
 };
 
 struct StreamWs {
@@ -133,6 +133,7 @@ struct StreamWs {
     std::deque<PendingCall> pending;
     CallStats last;           // the most recent call whose numbers are known
     hipEvent_t prof_start = nullptr, prof_stop = nullptr;
+    hipEvent_t call_start = nullptr, call_stop = nullptr;   // around everything the call enqueues (prl_hip_last_call_ms)
     bool prof_valid = false;
     // The last call's final kernel left the first `clean_pages` PageGlobals and the counter block of `small` in their
     // initial state (FusedParams::ep_host): a following call with the same page count needs no k_init_globals.
@@ -175,10 +176,12 @@ void ws_free(StreamWs* ws)
     for (auto& e : ws->ev) if (e) (void)hipEventDestroy(e);
     if (ws->prof_start) (void)hipEventDestroy(ws->prof_start);
     if (ws->prof_stop) (void)hipEventDestroy(ws->prof_stop);
+    if (ws->call_start) (void)hipEventDestroy(ws->call_start);
+    if (ws->call_stop) (void)hipEventDestroy(ws->call_stop);
     ws->small = ws->mask = ws->scratch = ws->pinned = nullptr;
     ws->small_bytes = ws->mask_bytes = ws->scratch_bytes = ws->slot_bytes = 0;
     for (auto& e : ws->ev) e = nullptr;
-    ws->prof_start = ws->prof_stop = nullptr;
+    ws->prof_start = ws->prof_stop = ws->call_start = ws->call_stop = nullptr;
     ws->prof_valid = false;
     ws->pending.clear();
     ws->next_slot = 0;
@@ -428,6 +431,24 @@ bool host_range_pinned(const void* p, size_t bytes)
         }
         if (at.type != hipMemoryTypeHost) return false;
     }
+    // both ends are pinned; they must also belong to ONE allocation (two pinned blocks with pageable memory between them
+    // would pass the test above).  The runtime knows the extent of the allocation a pointer lies in ...
+    void* base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t*>(&base), &size, const_cast<void*>(p)) == hipSuccess && base && size) {
+        const uint8_t* b = static_cast<const uint8_t*>(base);
+        return b <= static_cast<const uint8_t*>(p) && static_cast<const uint8_t*>(p) + bytes <= b + size;
+    }
+    (void)hipGetLastError();
+    // ... and where it does not say (registered memory on some stacks), the range is walked in 2 MiB steps
+    for (size_t off = (size_t)2 << 20; off < bytes; off += (size_t)2 << 20) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, static_cast<const uint8_t*>(p) + off) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (at.type != hipMemoryTypeHost) return false;
+    }
     return true;
 }
 
@@ -646,6 +667,7 @@ int resolve_front(StreamWs* ws)
     for (int i = 0; i < pc.n_pages; ++i) {
         cs.refined += hg[(size_t)i].n_refined;
         cs.exact += hg[(size_t)i].n_exact;
+        cs.wolf_candidates += hg[(size_t)i].n_cand;
         if (hg[(size_t)i].worklist_overflow) {
             cs.literal_pages += 1;
             if (st == PRL_OK) st = redo_page_literal(ws, pc, i);
@@ -790,6 +812,19 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         thr_dst.step = bit_mask ? bit_step : mask_step;
     }
 
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ws->prof_valid = false;
+    if (g_profiling.load()) {
+        if (!ws->prof_start) {
+            PRL_HIP_CHECK(hipEventCreate(&ws->prof_start));
+            PRL_HIP_CHECK(hipEventCreate(&ws->prof_stop));
+            PRL_HIP_CHECK(hipEventCreate(&ws->call_start));
+            PRL_HIP_CHECK(hipEventCreate(&ws->call_stop));
+        }
+        ev0 = ws->prof_start;
+        ev1 = ws->prof_stop;
+        PRL_HIP_CHECK(hipEventRecord(ws->call_start, stream));   // everything this call enqueues lies between call_start and call_stop
+    }
     // small batches: the fused pipeline's last kernel delivers the flags and re-initialises globals and counters itself
     const bool epilogue = use_fused && n_pages <= kEpilogueMaxPages;
     if (!(epilogue && was_clean)) {
@@ -797,16 +832,6 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         if (st != PRL_OK) return st;
     }
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    ws->prof_valid = false;
-    if (g_profiling.load()) {
-        if (!ws->prof_start) {
-            PRL_HIP_CHECK(hipEventCreate(&ws->prof_start));
-            PRL_HIP_CHECK(hipEventCreate(&ws->prof_stop));
-        }
-        ev0 = ws->prof_start;
-        ev1 = ws->prof_stop;
-    }
     if (use_fused) {
         // threshold sweep, float64 interval test of what it left open, literal fix-up of what THAT left open: all enqueued,
         // the last two find their queues on the device and do nothing when they are empty.  Pages whose fix-up queue
@@ -846,6 +871,7 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         }
         if (st != PRL_OK) return st;
     }
+    if (ev0) PRL_HIP_CHECK(hipEventRecord(ws->call_stop, stream));
     ws->prof_valid = (ev0 != nullptr);
     t_last.device = dev;
     t_last.stream = stream;
@@ -958,6 +984,20 @@ int prl_hip_last_kernel_ms(float* ms)
     return PRL_OK;
 }
 
+int prl_hip_last_call_ms(float* ms)
+{
+    if (!ms) return PRL_ERR_BAD_ARG;
+    *ms = 0.0f;
+    if (!t_last.valid) return PRL_ERR_BAD_ARG;
+    PRL_HIP_CHECK(hipSetDevice(t_last.device));
+    StreamWs* ws = stream_ws(device_ctx(t_last.device), t_last.stream);
+    std::lock_guard<std::mutex> lk(ws->mu);
+    if (!ws->prof_valid) return PRL_ERR_BAD_ARG;
+    PRL_HIP_CHECK(hipEventSynchronize(ws->call_stop));
+    PRL_HIP_CHECK(hipEventElapsedTime(ms, ws->call_start, ws->call_stop));
+    return PRL_OK;
+}
+
 int prl_hip_set_deferred_completion(int enabled)
 {
     g_deferred.store(enabled != 0);
@@ -1053,6 +1093,7 @@ int prl_hip_last_stats(prl_binarize_stats* out)
     out->refined_pixels = ws->last.refined;
     out->exact_pixels = ws->last.exact;
     out->literal_pages = ws->last.literal_pages;
+    out->wolf_candidates = ws->last.wolf_candidates;
     return PRL_OK;
 }
 
@@ -1158,6 +1199,7 @@ int prl_hip_binarize_host(const prl_binarize_params* p, const uint8_t* src, size
     uint8_t* d_in = static_cast<uint8_t*>(ctx->stage);
     uint8_t* d_out = d_in + in_bytes;
     hipStream_t stream = nullptr;
+    DrainOnExit drain_guard{stream};   // (direct DMA from the caller's pinned page: see prl_internal.h)
     st = stage_upload(ctx, 0, src, src_step, (size_t)width, height, d_in, stream);
     if (st != PRL_OK) return st;
     st = prl_hip_binarize_batch_device(p, 1, d_in, in_bytes, in_pitch, width, height, d_out, out_bytes, out_pitch, stream);

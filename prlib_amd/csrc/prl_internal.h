@@ -31,6 +31,14 @@ void set_error_detail(const std::string& s);
 
 struct StreamWs;  // per-(device, stream) workspace of the binarizers (prl_capi.hip)
 
+// The *_host entries may start a DMA straight from / into the CALLER's pinned pixels (stage_upload / stage_download).  Whatever
+// way such an entry returns - also early, on an error of a later step - nothing may still be reading or writing that memory:
+// the stream is drained at scope exit (a no-op after the success path's own wait).
+struct DrainOnExit {
+    hipStream_t s;
+    ~DrainOnExit() { (void)hipStreamSynchronize(s); }
+};
+
 // ---- per-device context: cached scratch memory ------------------------------------------------
 struct DeviceCtx {
     std::mutex streams_mu;  // guards `streams` only (never held across device work: deskew holds `mu` for seconds)
@@ -199,6 +207,8 @@ struct PageGlobals {
     unsigned int n_exact;           // pixels sent to the absolute-integral fix-up
     unsigned int worklist_overflow; // fix-up list overflowed -> page must rerun literally
     unsigned int v32max_bits;       // Wolf fused sweep A: float32 bits of the page's largest variance estimate
+    unsigned int n_cand;            // Wolf: pixels whose deviation was evaluated literally for devianceMax (statistics)
+    unsigned int reserved0;
 };
 
 // ---- literal pipeline (binarize_literal.hip) ---------------------------------------------------

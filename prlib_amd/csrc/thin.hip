@@ -404,6 +404,7 @@ int prl_hip_thin_host(int method, const uint8_t* src, size_t src_step, int width
     st = ensure_stage_pinned(ctx, bytes);
     if (st != PRL_OK) return st;
     uint8_t* d = static_cast<uint8_t*>(ctx->stage);
+    DrainOnExit drain_guard{nullptr};   // (direct DMA from the caller's pinned page: see prl_internal.h)
     st = stage_upload(ctx, 0, src, src_step, (size_t)width, height, d, nullptr);
     if (st != PRL_OK) return st;
     st = prl_hip_thin_batch_device(method, 1, d, bytes, (size_t)width, width, height, d, bytes, (size_t)width, nullptr);
