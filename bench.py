@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--end-to-end", type=int, default=1,
                     help="1 (N=1 only): the batch as a host page list in pinned memory through prl_hip_binarize_batch_host "
                          "(H2D + kernels + D2H) -> `end_to_end` (SURVEY.md 8d's second number; never `value`)")
+    ap.add_argument("--digest", type=int, default=0,
+                    help="1: the line carries `page_digests`, the CRC-32 of every page's mask in page-list order (all ranks) - "
+                         "lets a test compare an N-rank run with the single-process run of the same page list")
     ap.add_argument("--lib", default=None, help="A/B tooling: load this build of libprlib_hip.so instead of the in-tree one")
     ap.add_argument("--hooks", type=int, default=0, help="A/B tooling: 1 = load libprlib_hip_testhooks.so (reads the PRL_HIP_* tuning knobs)")
     return ap.parse_args()
@@ -453,6 +456,13 @@ def main():
     if rank == 0 and world == 1 and args.end_to_end and args.mode == "auto":
         e2e = end_to_end_leg(prlib_amd, dev, pages, params, g, W, H)
 
+    page_digests = None
+    if args.digest:   # (small test batches: the masks go through the host)
+        import zlib
+
+        mine_d = [zlib.crc32(out[i, :, : g.out_w].cpu().numpy().tobytes()) for i in range(n_mine)]
+        page_digests = pdist.gather_lists(mine_d)
+
     # --scaling both (N > 1): the same job size as one GPU's weak-scaling share, now split over the ranks (strong scaling);
     # every rank re-uses the first pages of its batch, the timing protocol is the one above
     strong = None
@@ -493,6 +503,7 @@ def main():
                 "pages_per_gpu": n_mine,
                 "pages_total": total_pages,
                 "parallelism": f"pages sharded over {world} GPU(s), no collectives",
+                "dist_backend": pdist.backend_name(),   # only the barrier and the max-over-ranks of the time go through it
             },
             "roofline": {
                 "bound": "hbm",
@@ -522,6 +533,8 @@ def main():
         }
         if strong is not None:
             line["strong"] = strong
+        if page_digests is not None:
+            line["page_digests"] = page_digests
         line["worst_case"] = worst
         line["end_to_end"] = e2e
         print(json.dumps(line), flush=True)

@@ -39,14 +39,16 @@ namespace {
 constexpr int kWave = 64;
 constexpr int CPL = 8;                 // columns per lane
 constexpr int SW = kWave * CPL;        // padded columns per wavefront strip
-constexpr unsigned kRefineCap = 1u << 20;  // pixels the float32 test may leave undecided per call
+constexpr unsigned kRefBucketCap = 1u << 13;                      // entries per refine-queue bucket (a wavefront queues into bucket wid % kRefBuckets)
+constexpr unsigned kRefineCap = kRefBuckets * kRefBucketCap;      // pixels the float32 test may leave undecided per call (2^21)
 constexpr unsigned kWorkCap = 1u << 14;    // pixels the float64 interval test may leave undecided (more: literal page)
 constexpr size_t kSegmaxCap = 1u << 20;    // wavefronts per call whose sweep-A maxima can be kept (Wolf)
 
-struct RefItem {   // undecided after the float32 test: exact window sums travel with the pixel
+struct RefItem {   // undecided after the float32 test: the window sums travel with the pixel
     int page, y, x;
-    unsigned S, Q, p;
+    unsigned S, Q, p;   // p bit 31 (kRefApprox): Q is the float32 pipeline's sum, within FusedParams::flt_dq of the exact one
 };
+constexpr unsigned kRefApprox = 0x80000000u;
 struct WorkItem {  // undecided after the float64 interval test
     int page, y, x;
     int pad;
@@ -101,6 +103,9 @@ struct FusedParams {
     // Epilogue of the call (small batches: a launch costs ~4 us, which is what the flag copy and the next call's
     // k_init_globals cost each): the last workgroup of the last kernel (k_corner_partial<true>) writes the per-page flags
     // straight into the caller's pinned slot and leaves globals and counters in their initial state.  ep_host == null: off.
+    double flt_dq;     // float32 pipeline: |Q~ - Q| <= flt_dq (absolute, flt_usable's delta) for the sums queued pixels carry
+    int wolf_est;      // Wolf threshold sweep: the coefficient is estimated from sweep A's float32 variance maximum (the literal
+                       // devianceMax is being computed on the side stream meanwhile; k_refine uses the literal one)
     PageGlobals* ep_host;
     PageGlobals* ep_dev;
     unsigned* ep_counters;
@@ -195,8 +200,9 @@ __device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsig
 // T* is the threshold in exact arithmetic from the exact window sums; the literal sequence differs
 // from it by at most ET (propagated from Em, Eq, the host-side bounds on the 4-tap rounding noise).
 template <int METHOD>
+// eq_extra: additional uncertainty of q = f Q (the float32 pipeline's Q~ is within flt_dq of the exact sum: f flt_dq; else 0)
 __device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, unsigned Q, unsigned p, double imin,
-                                             double coeff)
+                                             double coeff, double eq_extra = 0.0)
 {
     if (p == 0) return 0;  // 0 > T8 is false for every T8 (also for NaN -> 0)
     const ThrParams& tp = fp.tp;
@@ -204,7 +210,8 @@ __device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, 
     const double m = (double)S * tp.f;
     const double q = (double)Q * tp.f;
     const double v = q - m * m;
-    const double Ev = fp.Eq + 2.0 * m * fp.Em + fp.Em * fp.Em + tiny * (q + m * m);
+    const double Eq = fp.Eq + eq_extra;
+    const double Ev = Eq + 2.0 * m * fp.Em + fp.Em * fp.Em + tiny * (q + m * m);
     if (!(v > 4.0 * Ev)) return 2;  // literal sqrt may be NaN / arbitrarily far
     const double s = sqrt(v);
     const double Es = 1.001 * Ev / sqrt(v - Ev) + tiny * s;
@@ -219,7 +226,7 @@ __device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, 
         ET = fabs(tp.k) * Es + fp.Em + tiny * (fabs(T) + m);
     } else if (METHOD == PRL_NICK) {
         // literal: C = fl(fl(m*m) + fl(s*s)) = q_literal up to a few ulp
-        const double EC = fp.Eq + tiny * q;
+        const double EC = Eq + tiny * q;
         const double c = sqrt(q);
         const double Ec = 1.001 * EC / sqrt(q - EC) + tiny * c;
         T = m + c * tp.k;
@@ -261,6 +268,16 @@ __device__ __forceinline__ void store_decision(const PageSetOut& dst, int bit_ou
         if (r) atomicOr(w, m);
         else atomicAnd(w, ~m);
     }
+}
+
+// queue a pixel the float32 test left open: bucket = wavefront id mod kRefBuckets (see kRefBuckets in prl_internal.h)
+__device__ __forceinline__ void ref_push(RefItem* __restrict__ rl, unsigned* __restrict__ counters, PageGlobals* __restrict__ g,
+                                         unsigned wid, const RefItem& it)
+{
+    const unsigned b = wid & (unsigned)(kRefBuckets - 1);
+    const unsigned idx = atomicAdd(&counters[64 + kRefCounterStride * b], 1u);
+    if (idx < kRefBucketCap) rl[(size_t)b * kRefBucketCap + idx] = it;
+    else atomicOr(&g[it.page].worklist_overflow, 1u);
 }
 
 typedef const uint8_t __attribute__((address_space(1)))* gcptr;  // known-global pointers: global_load, not flat_load
@@ -580,19 +597,14 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                         float v32;
                         const float t = eval32<METHOD, WIDE>(fp, S, Q, fmaf((float)p, kZ, pk.p0), pk, &v32);
                         if ((fabsf(t) > pk.eps1) && (v32 > fp.vthr32)) continue;
-                        const unsigned idx = atomicAdd(&counters[0], 1u);
-                        if (idx < fp.ref_cap) {
-                            RefItem it;
-                            it.page = page;
-                            it.y = y;
-                            it.x = x0 + c;
-                            it.S = S - sbias;
-                            it.Q = Q;
-                            it.p = p;
-                            rl[idx] = it;
-                        } else {
-                            atomicOr(&g[page].worklist_overflow, 1u);
-                        }
+                        RefItem it;
+                        it.page = page;
+                        it.y = y;
+                        it.x = x0 + c;
+                        it.S = S - sbias;
+                        it.Q = Q;
+                        it.p = p;
+                        ref_push(rl, counters, g, wid, it);
                     }
                 }
             }
@@ -865,26 +877,34 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         const bool unsure = lane_has_out && !((tmin > pk.eps1) && (vmin > fp.vthr32));
         if (__ballot(unsure) != 0ull) {
             if (unsure) {
+                unsigned qm = 0u;   // this lane's pixels to queue, one bit each
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     if (!FAST && x0 + c >= xlim) continue;
                     if (pv_cur.v[c] == 0.0f) continue;  // 0 > T8 is false whatever T is
                     float v32;
                     const float t = eval32f<METHOD>(fp, Ssum[c], Qsum[c], fmaf(pv_cur.v[c], kZ, pk.p0), pk, &v32);
-                    if ((fabsf(t) > pk.eps1) && (v32 > fp.vthr32)) continue;
-                    const unsigned idx = atomicAdd(&counters[0], 1u);
-                    if (idx < fp.ref_cap) {
-                        RefItem it;
-                        it.page = page;
-                        it.y = y;
-                        it.x = x0 + c;
-                        it.S = 0;
-                        it.Q = 0;
-                        it.p = (unsigned)pv_cur.v[c];
-                        rl[idx] = it;
-                    } else {
-                        atomicOr(&g[page].worklist_overflow, 1u);
-                    }
+                    if (!((fabsf(t) > pk.eps1) && (v32 > fp.vthr32))) qm |= 1u << c;
+                }
+                // the sums travel with the pixel: S is exact, Q within fp.flt_dq of the exact sum - k_refine's interval test
+                // takes that uncertainty first and only rebuilds the sums of what it leaves open.  (One push site, values
+                // picked by select chains: eight unrolled pushes cost the whole kernel 5-7 registers.)
+#pragma unroll 1
+                while (qm) {
+                    const int c = __builtin_ctz(qm);
+                    qm &= qm - 1u;
+                    const float Sv = c == 0 ? Ssum[0] : c == 1 ? Ssum[1] : c == 2 ? Ssum[2] : c == 3 ? Ssum[3]
+                                   : c == 4 ? Ssum[4] : c == 5 ? Ssum[5] : c == 6 ? Ssum[6] : Ssum[7];
+                    const float Qv = c == 0 ? Qsum[0] : c == 1 ? Qsum[1] : c == 2 ? Qsum[2] : c == 3 ? Qsum[3]
+                                   : c == 4 ? Qsum[4] : c == 5 ? Qsum[5] : c == 6 ? Qsum[6] : Qsum[7];
+                    RefItem it;
+                    it.page = page;
+                    it.y = y;
+                    it.x = x0 + c;
+                    it.S = (unsigned)Sv;
+                    it.Q = (unsigned)Qv;
+                    it.p = byte_of(pvb, c) | kRefApprox;
+                    ref_push(rl, counters, g, wid, it);
                 }
             }
         }
@@ -1006,12 +1026,33 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
         const double c3 = (tp.k2 * imin + (-imin)) + 0.0;  // binarizeFeng.cpp:137 with r2 = c2 = 1
         pk.p0 = (float)((-0.5 - c3) * (double)kZ);
     } else if (METHOD == PRL_WOLFJOLION) {
-        const double coeff = g[page].coeff;                // k / devianceMax, binarizeWolfJolion.cpp:121
-        pk.c1 = (float)(coeff * tp.f);
         pk.imin = (float)g[page].imin * kZ;
-        // |T_literal - T*| grows with |coeff| through the sqrt noise; not finite -> nothing is settled here
-        const float ac = fabsf((float)coeff);
-        pk.eps1 = (ac < 3.0e38f) ? fp.eps1 + kZ * 2.02f * 255.0f * ac * fp.es_max : __builtin_inff();
+        if (!fp.wolf_est) {
+            const double coeff = g[page].coeff;                // k / devianceMax, binarizeWolfJolion.cpp:121
+            pk.c1 = (float)(coeff * tp.f);
+            // |T_literal - T*| grows with |coeff| through the sqrt noise; not finite -> nothing is settled here
+            const float ac = fabsf((float)coeff);
+            pk.eps1 = (ac < 3.0e38f) ? fp.eps1 + kZ * 2.02f * 255.0f * ac * fp.es_max : __builtin_inff();
+        } else {
+            // The literal devianceMax is still on its way (side stream): this sweep uses an ESTIMATE of k / devianceMax from
+            // sweep A's float32 variance maximum and widens the margin by what the estimate can be off.  K~max is within rho
+            // of the exact-arithmetic maximum Kmax (every K~ is within rho of its K), the literal variance within Ev of
+            // f^2 K, so devianceMax = f sqrt(Kmax) (1 +- delta), delta <= rho/2 + Ev / (2 f^2 Kmax) + roundings; T moves by
+            // |dc| s |m - Imin| <= |k| (s / devianceMax) delta 255.  k_refine decides what this leaves open with the literal one.
+            const float kmax = __uint_as_float(g[page].v32max_bits);
+            const float klow = kmax / (1.0f + fp.rho);
+            const float fl = (float)tp.f;
+            if (klow > fp.vthr32 && klow > 64.0f * fp.ev2) {
+                const float c = (float)tp.k / (__builtin_amdgcn_sqrtf(kmax) * fl);
+                const float delta = 0.51f * fp.rho + 0.26f * fp.ev2 / klow + 4.8e-7f;   // (+ 8 u: sqrt, product, quotient, c * f)
+                const float ac = fabsf(c) * (1.0f + delta);
+                pk.c1 = c * fl;
+                pk.eps1 = fp.eps1 + kZ * (2.02f * 255.0f * ac * fp.es_max + 1.02f * 255.0f * fabsf((float)tp.k) * delta);
+            } else {  // (no deviation to speak of on this page: nothing is settled here, k_refine / the literal pipeline decide)
+                pk.c1 = 0.0f;
+                pk.eps1 = __builtin_inff();
+            }
+        }
     } else if (METHOD == kWolfCollect) {
         // a pixel can only carry the literal maximum if K~ >= (1-rho) (Kmax/(1+rho) - 2 Ev / f^2)
         const float vmax = __uint_as_float(g[page].v32max_bits);
@@ -1048,62 +1089,92 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
 }
 
 // ---- second stage: float64 interval test of the queued pixels ------------------------------------------------------
-// One thread per pixel when the exact window sums travel with it (integer pipeline only); one wavefront per pixel when
-// they have to be rebuilt from the page (fp.flt: the float32 pipeline queues pixels without sums, and edge strips of
-// the same launch are simply recomputed too): lanes take the window's columns, 64-lane reduction, lane 0 decides.
+// One thread per queued pixel, on the window sums that travel with it: exact ones from the integer pipeline; from the
+// float32 pipeline an exact S and a Q~ within flt_dq of the exact sum, which enters the interval as extra uncertainty of q
+// (round 4: the first version rebuilt the sums of EVERY queued pixel, a wavefront each - 0.85 ms for the 3.9 10^5 pixels a
+// batch of real scans queues).  Only what that test leaves open has its sums rebuilt exactly (a wavefront per pixel).
+// The queue is kRefBuckets lists with their own counters (see ref_push).
 template <int METHOD>
 __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, FusedParams fp, PageGlobals* __restrict__ g,
                                                const RefItem* __restrict__ rl, WorkItem* __restrict__ wl,
                                                unsigned* __restrict__ counters, CornerAcc* __restrict__ acc,
                                                unsigned* __restrict__ done)
 {
-    const unsigned n = min(counters[0], fp.ref_cap);
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
-    const unsigned first = fp.flt ? tid >> 6 : tid, stride = fp.flt ? nthreads >> 6 : nthreads;
     const int lane = threadIdx.x & 63;
-    for (unsigned i = first; i < n; i += stride) {
-        RefItem it = rl[i];
-        if (fp.flt) {
-            // padded rows y+1 .. y+w-1, columns x+1 .. x+w-1 of the replicate-padded page, exact in u32
-            const ThrParams& tp = fp.tp;
-            const uint8_t* pg = src.page(it.page);
-            unsigned S = 0, Q = 0;
-            for (int pc = it.x + 1 + lane; pc <= it.x + tp.w - 1; pc += 64) {
-                const uint8_t* col = pg + clampi(pc - tp.half, 0, tp.width - 1);
-                for (int pr = it.y + 1; pr <= it.y + tp.w - 1; ++pr) {
-                    const unsigned b = col[(size_t)clampi(pr - tp.half, 0, tp.height - 1) * src.step];
-                    S += b;
-                    Q += b * b;
+    const ThrParams& tp = fp.tp;
+    const double eq_approx = fp.flt_dq * tp.f;
+    // the bucket lengths: four per lane, fetched at once (an empty queue - the rule for small calls - costs one round trip)
+    static_assert(kRefBuckets == 4 * kWave, "one load per lane and quarter");
+    unsigned len4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) len4[k] = min(counters[64 + kRefCounterStride * (lane + kWave * k)], kRefBucketCap);
+    if (__ballot((len4[0] | len4[1] | len4[2] | len4[3]) != 0u) == 0ull) return;
+#pragma unroll 1
+    for (unsigned b = 0; b < (unsigned)kRefBuckets; ++b) {
+        const unsigned lsel = (b >> 6) == 0 ? len4[0] : (b >> 6) == 1 ? len4[1] : (b >> 6) == 2 ? len4[2] : len4[3];
+        const unsigned n = (unsigned)__shfl((int)lsel, (int)(b & 63u), kWave);
+        if (n == 0u) continue;
+        // (whole wavefronts go round together: the rebuild below is a wavefront's job; tid - lane is wave-uniform)
+        for (unsigned i = tid; i - lane < n; i += nthreads) {
+            const bool valid = i < n;
+            RefItem it = rl[(size_t)b * kRefBucketCap + (valid ? i : 0u)];
+            const bool approx = (it.p & kRefApprox) != 0u;
+            it.p &= 0xffu;
+            unsigned r = 2;
+            double imin = 0.0, coeff = 0.0;
+            if (valid) {
+                imin = (double)g[it.page].imin;
+                coeff = g[it.page].coeff;
+                // one thread per pixel: float64 interval test on the sums the sweep sent along (the float32 pipeline's Q~ with
+                // its rounding bound as extra uncertainty of q)
+                r = refine64<METHOD>(fp, it.S, it.Q, it.p, imin, coeff, approx ? eq_approx : 0.0);
+            }
+            // what that leaves open and has an approximate Q: the wavefront rebuilds S and Q exactly from the page - padded rows
+            // y+1 .. y+w-1, columns x+1 .. x+w-1 of the replicate-padded page, exact in u32 - one pixel at a
+            // time, and the owner lane repeats the test with exact sums
+            unsigned long long todo = __ballot(valid && r == 2 && approx);
+            while (todo) {
+                const int owner = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int pg_i = __shfl(it.page, owner, kWave), yy = __shfl(it.y, owner, kWave), xx = __shfl(it.x, owner, kWave);
+                const uint8_t* pg = src.page(pg_i);
+                unsigned S = 0, Q = 0;
+                for (int pc = xx + 1 + lane; pc <= xx + tp.w - 1; pc += 64) {
+                    const uint8_t* col = pg + clampi(pc - tp.half, 0, tp.width - 1);
+                    for (int pr = yy + 1; pr <= yy + tp.w - 1; ++pr) {
+                        const unsigned bb = col[(size_t)clampi(pr - tp.half, 0, tp.height - 1) * src.step];
+                        S += bb;
+                        Q += bb * bb;
+                    }
                 }
-            }
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                S += __shfl_xor(S, d, kWave);
-                Q += __shfl_xor(Q, d, kWave);
+                for (int d = 32; d > 0; d >>= 1) {
+                    S += __shfl_xor(S, d, kWave);
+                    Q += __shfl_xor(Q, d, kWave);
+                }
+                if (lane == owner) r = refine64<METHOD>(fp, S, Q, it.p, imin, coeff);
             }
-            if (lane != 0) continue;
-            it.S = S;
-            it.Q = Q;
-        }
-        const unsigned r = refine64<METHOD>(fp, it.S, it.Q, it.p, (double)g[it.page].imin, g[it.page].coeff);
-        if (r != 2) {
-            store_decision(dst, fp.bit_out, it.page, it.y, it.x, r);
-            atomicAdd(&g[it.page].n_refined, 1u);
-        } else {
-            atomicAdd(&g[it.page].n_exact, 1u);
-            const unsigned idx = atomicAdd(&counters[1], 1u);
-            if (idx < fp.wl_cap) {
-                WorkItem w;
-                w.page = it.page;
-                w.y = it.y;
-                w.x = it.x;
-                w.pad = 0;
-                wl[idx] = w;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[idx].a[k] = 0ull;  // (instead of a 1 MB memset per call: nothing is queued as a rule)
-                done[idx] = 0u;
+            if (!valid) continue;
+            if (r != 2) {
+                store_decision(dst, fp.bit_out, it.page, it.y, it.x, r);
+                atomicAdd(&g[it.page].n_refined, 1u);
             } else {
-                atomicOr(&g[it.page].worklist_overflow, 1u);
+                atomicAdd(&g[it.page].n_exact, 1u);
+                const unsigned idx = atomicAdd(&counters[1], 1u);
+                if (idx < fp.wl_cap) {
+                    WorkItem w;
+                    w.page = it.page;
+                    w.y = it.y;
+                    w.x = it.x;
+                    w.pad = 0;
+                    wl[idx] = w;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[idx].a[k] = 0ull;  // (instead of a 1 MB memset per call: nothing is queued as a rule)
+                    done[idx] = 0u;
+                } else {
+                    atomicOr(&g[it.page].worklist_overflow, 1u);
+                }
             }
         }
     }
@@ -1269,6 +1340,7 @@ __global__ void __launch_bounds__(256) k_corner_partial(PageSet src, FusedParams
                     fp.ep_dev[i] = z;   // = k_init_globals
                 }
                 if (threadIdx.x < 64) fp.ep_counters[threadIdx.x] = 0u;
+                for (int b = threadIdx.x; b < kRefBuckets; b += blockDim.x) fp.ep_counters[64 + kRefCounterStride * b] = 0u;
             }
         }
     }
@@ -1374,12 +1446,13 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
 template <int METHOD>
 int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
                  PageGlobals* g, RefItem* rl, WorkItem* wl, WorkItem* cand, CornerAcc* acc, unsigned* cnt,
-                 hipEvent_t ev_start, hipEvent_t ev_stop, bool with_fixup)
+                 hipEvent_t ev_start, hipEvent_t ev_stop, bool with_fixup, hipEvent_t before_refine = nullptr)
 {
     if (ev_start) PRL_HIP_CHECK(hipEventRecord(ev_start, stream));
     int st = launch_sweep<METHOD>(sh, stream, src, dst, fp, g, rl, cand, cnt);
     if (st != PRL_OK) return st;
     if (ev_stop) PRL_HIP_CHECK(hipEventRecord(ev_stop, stream));
+    if (before_refine) PRL_HIP_CHECK(hipStreamWaitEvent(stream, before_refine, 0));   // (Wolf-Jolion: the literal k / devianceMax of the side stream)
     unsigned* done = reinterpret_cast<unsigned*>(fp.segmax + kSegmaxCap);  // arrivals per queued pixel (see fused_small_bytes)
     // (float pipeline: a wavefront per queued pixel, a few microseconds each; big batches queue ~10^4 of them: 4096 wavefronts
     // instead of 1024 took k_refine from 0.14 to 0.05 ms on 256 A4 pages (Niblack w=31); small calls keep the cheaper launch)
@@ -1542,8 +1615,8 @@ extern "C" int prl_hip_internal_flt_q_error(int w, double* delta_qmin_cq)
 
 size_t fused_small_bytes(int)
 {
-    // [counters 256 B][refine list][fix-up list][Wolf candidate list][corner sums][Wolf per-wavefront maxima][arrival counters]
-    return 256 + sizeof(RefItem) * (size_t)kRefineCap + 2 * sizeof(WorkItem) * (size_t)kWorkCap +
+    // [counters][refine list: kRefBuckets x kRefBucketCap][fix-up list][Wolf candidate list][corner sums][Wolf per-wavefront maxima][arrival counters]
+    return kFusedCounterBytes + sizeof(RefItem) * (size_t)kRefineCap + 2 * sizeof(WorkItem) * (size_t)kWorkCap +
            sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(float) * kSegmaxCap + sizeof(unsigned) * (size_t)kWorkCap;
 }
 
@@ -1614,7 +1687,7 @@ int fused_max_pages(const ThrParams& tp)
 // and skips phase 2 - two launches and a 1 MB memset - when nothing was queued, the usual case)
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst, void* small,
               PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool bit_out, int phase,
-              bool counters_zeroed, PageGlobals* host_globals)
+              bool counters_zeroed, PageGlobals* host_globals, const WolfSide* wolf_side)
 {
     FusedParams fp{};
     fp.tp = tp;
@@ -1622,8 +1695,9 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     // non-temporal mask stores: the output stream is never re-read, and keeping it out of L2 leaves the cache to the
     // window rows that ARE re-read (the leaving row, the compared-pixel row): 4.31-4.47 -> 4.15 ms on 256 x 4K pages
     fp.nt_store = env_knobs().nt_store ? 1 : 0;
-    double cq = 1.0;
-    fp.flt = flt_usable(tp, src.step, &cq) ? 1 : 0;
+    double cq = 1.0, dq = 0.0;
+    fp.flt = flt_usable(tp, src.step, &cq, &dq) ? 1 : 0;
+    fp.flt_dq = fp.flt ? dq : 0.0;
     fp.n_strips = strip_layout(tp, fp.flt != 0, bit_out, &fp.uo, &fp.ext);
     // Row segments.  Long segments amortise the (w-1)-row warm-up, short ones fill the chip and keep the tail short when it
     // drains; workgroups start in index order, so the segments come in TIERS of decreasing length (guided scheduling): each tier
@@ -1743,8 +1817,8 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         fp.ep_counters = cnt;
         fp.ep_pages = n_pages;
     }
-    auto* rl = reinterpret_cast<RefItem*>(static_cast<uint8_t*>(small) + 256);
-    auto* wl = reinterpret_cast<WorkItem*>(static_cast<uint8_t*>(small) + 256 + sizeof(RefItem) * (size_t)kRefineCap);
+    auto* rl = reinterpret_cast<RefItem*>(static_cast<uint8_t*>(small) + kFusedCounterBytes);
+    auto* wl = reinterpret_cast<WorkItem*>(static_cast<uint8_t*>(small) + kFusedCounterBytes + sizeof(RefItem) * (size_t)kRefineCap);
     auto* cand = wl + kWorkCap;
     auto* acc = reinterpret_cast<CornerAcc*>(cand + kWorkCap);
     fp.segmax = reinterpret_cast<float*>(acc + kWorkCap);
@@ -1755,7 +1829,7 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         return PRL_OK;
     }
     const bool with_fixup = phase == 0;
-    if (!counters_zeroed) PRL_HIP_CHECK(hipMemsetAsync(cnt, 0, 256, stream));
+    if (!counters_zeroed) PRL_HIP_CHECK(hipMemsetAsync(cnt, 0, kFusedCounterBytes, stream));
 
     if (tp.method == PRL_FENG) {
         int st = page_min_run(tp, src, n_pages, d_globals, stream);
@@ -1773,35 +1847,66 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         // (cv::minMaxLoc(imageInput) rides on sweep A - every window row a wavefront fetches goes into a running
         // minimum - plus a small kernel for the bottom rows / right columns the sweeps never fetch; Feng, which has no
         // sweep, uses k_page_min)
-        int st = launch_sweep<kWolfMax>(sh, stream, src, dst, fp, d_globals, rl, cand, cnt);
-        if (st != PRL_OK) return st;
-        {
+        // Schedule (round 4).  Only the two big sweeps are on the caller's stream: sweep A (variance maximum, float32) and the
+        // threshold sweep, which takes its coefficient from sweep A's maximum with a margin for the difference (k_fused,
+        // fp.wolf_est).  Everything that exists to reproduce the LITERAL devianceMax - the candidate sweep B, the absolute
+        // corner sums of its candidates, the literal deviations, k / devianceMax - and the page minimum of the border bands
+        // run on the workspace's side stream beside them; k_refine (float64 intervals with the literal coefficient) waits
+        // for it.  256 A4 pages at the header defaults: 5.5 -> see profiles/r04/wolf_schedule_ab.txt.  Without a side stream
+        // (PRL_HIP_WOLF_SIDE=0 in the hooks build): everything in order on one stream, literal coefficient in every sweep.
+        hipStream_t ss = wolf_side ? wolf_side->stream : stream;
+        auto border_min = [&](hipStream_t q) -> int {
             const int band = std::min(std::max(tp.w + 8, 16), std::max(tp.width, tp.height));
             for (int first = 0; first < n_pages; first += 32768) {  // grid.y limit
                 PageSet part = src;
                 if (part.table) part.table += first; else part.base += (size_t)first * part.page_stride;
-                hipLaunchKernelGGL(k_page_min_border, dim3(16, std::min(32768, n_pages - first)), dim3(256), 0, stream, part,
+                hipLaunchKernelGGL(k_page_min_border, dim3(16, std::min(32768, n_pages - first)), dim3(256), 0, q, part,
                                    tp.width, tp.height, band, d_globals + first);
             }
             PRL_HIP_CHECK(hipGetLastError());
+            return PRL_OK;
+        };
+        int st;
+        if (wolf_side) {
+            PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_fork, stream));          // (globals and counters are initialised)
+            PRL_HIP_CHECK(hipStreamWaitEvent(ss, wolf_side->ev_fork, 0));
+            st = border_min(ss);
+            if (st != PRL_OK) return st;
+            PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_min, ss));
         }
-        st = launch_sweep<kWolfCollect>(sh, stream, src, dst, fp, d_globals, rl, cand, cnt);
+        st = launch_sweep<kWolfMax>(sh, stream, src, dst, fp, d_globals, rl, cand, cnt);
         if (st != PRL_OK) return st;
-        PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, stream));
-        hipLaunchKernelGGL(k_corner_partial<false>, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, cand, cnt, 2, acc, dst, d_globals,
+        if (wolf_side) {
+            PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_a, stream));
+            PRL_HIP_CHECK(hipStreamWaitEvent(ss, wolf_side->ev_a, 0));
+        } else {
+            st = border_min(ss);
+            if (st != PRL_OK) return st;
+        }
+        st = launch_sweep<kWolfCollect>(sh, ss, src, dst, fp, d_globals, rl, cand, cnt);
+        if (st != PRL_OK) return st;
+        PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, ss));
+        hipLaunchKernelGGL(k_corner_partial<false>, dim3(kSplit, 128), dim3(256), 0, ss, src, fp, cand, cnt, 2, acc, dst, d_globals,
                            static_cast<unsigned*>(nullptr));
         PRL_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(k_wolf_final, dim3(16), dim3(256), 0, stream, fp, d_globals, cand, acc, cnt);
+        hipLaunchKernelGGL(k_wolf_final, dim3(16), dim3(256), 0, ss, fp, d_globals, cand, acc, cnt);
         PRL_HIP_CHECK(hipGetLastError());
         if (env_knobs().debug) {
             unsigned hc[4] = {0, 0, 0, 0};
-            (void)hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, stream);
-            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, ss);
+            (void)hipStreamSynchronize(ss);
             std::fprintf(stderr, "[prl_hip] Wolf-Jolion: %u maximum-deviation candidates on %d pages (cap %u)\n", hc[2], n_pages, fp.wl_cap);
         }
-        st = wolf_coeff_run(tp, d_globals, 0, n_pages, stream);
+        st = wolf_coeff_run(tp, d_globals, 0, n_pages, ss);
         if (st != PRL_OK) return st;
-        return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);
+        hipEvent_t before_refine = nullptr;
+        if (wolf_side) {
+            PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_coeff, ss));
+            PRL_HIP_CHECK(hipStreamWaitEvent(stream, wolf_side->ev_min, 0));   // the threshold sweep needs the whole page minimum
+            fp.wolf_est = 1;
+            before_refine = wolf_side->ev_coeff;
+        }
+        return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, before_refine);
     }
     switch (tp.method) {
     case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);

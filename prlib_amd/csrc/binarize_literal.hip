@@ -38,7 +38,8 @@ __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v)
 __global__ void k_init_globals(PageGlobals* g, int n, unsigned* counters)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (counters && i < 64) counters[i] = 0u;  // the fused pipeline's 256-byte counter block (one launch instead of two)
+    if (counters)   // the fused pipeline's counter block (one launch instead of two)
+        for (int j = i; j < kFusedCounterWords; j += gridDim.x * blockDim.x) counters[j] = 0u;
     if (i < n) {
         g[i].imin = 255;
         g[i].smax_found = 0;

@@ -71,6 +71,7 @@ const EnvKnobs& env_knobs()
         k.tiers = !is0("PRL_HIP_TIERS");
         k.ext_strip = !is0("PRL_HIP_EXT_STRIP");
         k.ragged_uo = !is0("PRL_HIP_RAGGED_UO");
+        k.wolf_side = !is0("PRL_HIP_WOLF_SIDE");
         k.wolf_tier_max = (int)std::max(32ll, std::min(512ll, geti("PRL_HIP_WOLF_TIER_MAX", 128)));
         k.byte_mask = std::getenv("PRL_HIP_BYTE_MASK") != nullptr;
         k.morph_rps = (int)geti("PRL_MORPH_RPS", 0);
@@ -135,6 +136,7 @@ struct StreamWs {
     hipEvent_t prof_start = nullptr, prof_stop = nullptr;
     hipEvent_t call_start = nullptr, call_stop = nullptr;   // around everything the call enqueues (prl_hip_last_call_ms)
     bool prof_valid = false;
+    WolfSide wolf;            // Wolf-Jolion's side stream and its events, created on the first Wolf-Jolion call
     // The last call's final kernel left the first `clean_pages` PageGlobals and the counter block of `small` in their
     // initial state (FusedParams::ep_host): a following call with the same page count needs no k_init_globals.
     int clean_pages = 0;
@@ -178,6 +180,12 @@ void ws_free(StreamWs* ws)
     if (ws->prof_stop) (void)hipEventDestroy(ws->prof_stop);
     if (ws->call_start) (void)hipEventDestroy(ws->call_start);
     if (ws->call_stop) (void)hipEventDestroy(ws->call_stop);
+    if (ws->wolf.stream) {
+        (void)hipStreamSynchronize(ws->wolf.stream);
+        (void)hipStreamDestroy(ws->wolf.stream);
+        for (hipEvent_t e : {ws->wolf.ev_fork, ws->wolf.ev_min, ws->wolf.ev_a, ws->wolf.ev_coeff}) if (e) (void)hipEventDestroy(e);
+        ws->wolf = WolfSide{};
+    }
     ws->small = ws->mask = ws->scratch = ws->pinned = nullptr;
     ws->small_bytes = ws->mask_bytes = ws->scratch_bytes = ws->slot_bytes = 0;
     for (auto& e : ws->ev) e = nullptr;
@@ -837,7 +845,16 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         // the last two find their queues on the device and do nothing when they are empty.  Pages whose fix-up queue
         // overflowed are flagged; the flags travel to the pinned slot and are looked at in resolve_front().
         auto* h_globals = reinterpret_cast<PageGlobals*>(pin + 2 * sl.table_bytes);
-        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask, 0, true, epilogue ? h_globals : nullptr);
+        const WolfSide* wolf_side = nullptr;
+        if (tp.method == PRL_WOLFJOLION && env_knobs().wolf_side) {
+            if (!ws->wolf.stream) {
+                PRL_HIP_CHECK(hipStreamCreateWithFlags(&ws->wolf.stream, hipStreamNonBlocking));
+                for (hipEvent_t* e : {&ws->wolf.ev_fork, &ws->wolf.ev_min, &ws->wolf.ev_a, &ws->wolf.ev_coeff})
+                    PRL_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            }
+            wolf_side = &ws->wolf;
+        }
+        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask, 0, true, epilogue ? h_globals : nullptr, wolf_side);
         if (st != PRL_OK) return st;
         if (epilogue) ws->clean_pages = n_pages;
         else PRL_HIP_CHECK(hipMemcpyAsync(h_globals, d_globals, sizeof(PageGlobals) * (size_t)n_pages, hipMemcpyDeviceToHost, stream));

@@ -101,6 +101,7 @@ struct EnvKnobs {
     bool tiers = true;            // PRL_HIP_TIERS=0      one segment length for the whole call (A/B of the tiered schedule)
     bool ext_strip = true;        // PRL_HIP_EXT_STRIP=0  no extended last strip (binarize_fused.hip strip_layout)
     bool ragged_uo = true;        // PRL_HIP_RAGGED_UO=0  outputs per strip always a multiple of 8
+    bool wolf_side = true;        // PRL_HIP_WOLF_SIDE=0  Wolf-Jolion on one stream, the threshold sweep after the literal devianceMax (round-3 schedule)
     int wolf_tier_max = 128;      // PRL_HIP_WOLF_TIER_MAX longest row segment of a tiered Wolf-Jolion call (profiles/r03/wolf_tier_max.txt)
     bool debug = false;           // PRL_HIP_DEBUG
     bool byte_mask = false;       // PRL_HIP_BYTE_MASK    byte instead of bit-plane hand-off to the morphology pass
@@ -217,12 +218,27 @@ int literal_run(const ThrParams& tp, const PageSet& src, int first_page, int n_p
                 const PageSetOut& dst, void* scratch, PageGlobals* d_globals, hipStream_t stream);
 
 // ---- fused pipeline (binarize_fused.hip) -------------------------------------------------------
+// Counter block at the start of the fused work area: words 0..63 = list lengths and the epilogue's arrival counter, then
+// one counter per refine-queue bucket on its own 128-byte line (kRefBuckets of them): every queued pixel costs a device-scope
+// atomic, and 4 * 10^5 of them on ONE address serialised (2.8 ns each: the threshold sweep of 256 real 4K scans took 4.27 ms
+// instead of 3.18) - a wavefront adds to the bucket its id selects.
+constexpr int kRefBuckets = 256;
+constexpr int kRefCounterStride = 32;                                             // words
+constexpr int kFusedCounterWords = 64 + kRefBuckets * kRefCounterStride;
+constexpr size_t kFusedCounterBytes = ((size_t)kFusedCounterWords * 4 + 255) / 256 * 256;
+// Wolf-Jolion's side stream (per workspace): the literal devianceMax - candidate sweep, absolute corner sums of the
+// candidates, k / devianceMax - and the page minimum of the border bands run here, beside the two big sweeps on the caller's
+// stream (see fused_run).
+struct WolfSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_min = nullptr, ev_a = nullptr, ev_coeff = nullptr;
+};
 size_t fused_small_bytes(int n_pages);
 // bit_out: dst is a bit plane (rows of dst.step bytes, 1 bit per output pixel) instead of a 0/255 byte mask
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst,
               void* small, PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start,
               hipEvent_t ev_stop, bool bit_out = false, int phase = 0, bool counters_zeroed = false,
-              PageGlobals* host_globals = nullptr);  // host_globals (pinned, n_pages entries): see FusedParams::ep_host
+              PageGlobals* host_globals = nullptr, const WolfSide* wolf_side = nullptr);  // host_globals (pinned, n_pages entries): see FusedParams::ep_host
 bool fused_supports(const ThrParams& tp);
 int fused_max_pages(const ThrParams& tp);  // pages one fused_run call can take (Wolf-Jolion: per-wavefront maxima storage)
 

@@ -59,7 +59,9 @@ def max_over_ranks(value: float, device=None) -> float:
 
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    if device is None and dist.get_backend() == "nccl":
+    if dist.get_backend() != "nccl":
+        device = None   # (gloo: host tensors, also when the ranks hold GPUs - PRL_DIST_BACKEND=gloo)
+    elif device is None:
         device = torch.device("cuda", torch.cuda.current_device())
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -72,11 +74,30 @@ def sum_over_ranks(value: float, device=None) -> float:
 
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    if device is None and dist.get_backend() == "nccl":
+    if dist.get_backend() != "nccl":
+        device = None   # (gloo: host tensors, also when the ranks hold GPUs - PRL_DIST_BACKEND=gloo)
+    elif device is None:
         device = torch.device("cuda", torch.cuda.current_device())
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def backend_name():
+    import torch.distributed as dist
+
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+
+
+def gather_lists(items: list) -> list:
+    """Concatenation over the ranks (in rank order) of each rank's list of small picklable items."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return list(items)
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, list(items))
+    return [x for part in parts for x in part]
 
 
 def finish():

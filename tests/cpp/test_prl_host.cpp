@@ -77,6 +77,29 @@ static void test_validation()
     std::vector<unsigned char> ob(64 * 64);
     prl_oracle_otsu(bi.data, bi.step, 64, 64, ob.data(), 64);
     CHECK(std::memcmp(ob.data(), bo.data, ob.size()) == 0);
+    // BASELINE config 1 at its stated size: global Otsu on one 512 x 512 grayscale page via prl::binarize (host plumbing, no GPU),
+    // on a document-like page and on a BGR page (the reference converts with cvtColor first)
+    for (int ch : {1, 3}) {
+        cv::Mat pg = synth_page(512, 512, 77, ch), res;
+        cv::Mat gray;
+        if (ch == 1) gray = pg.clone();
+        else {
+            gray.create(512, 512, CV_8UC1);
+            prl_oracle_bgr2gray(pg.data, pg.step, 512, 512, ch, gray.data, gray.step);
+        }
+        std::vector<unsigned char> want((size_t)512 * 512);
+        const int thr = prl_oracle_otsu(gray.data, gray.step, 512, 512, want.data(), 512);
+        CHECK(thr > 60 && thr < 200);   // between the stroke and the paper mode
+        prl::binarize(pg, res);
+        CHECK(res.rows == 512 && res.cols == 512 && res.type() == CV_8UC1);
+        size_t bad = 0, white = 0;
+        for (int y = 0; y < 512 && res.cols == 512; ++y) {
+            bad += std::memcmp(res.ptr(y), &want[(size_t)y * 512], 512) != 0;
+            for (int x = 0; x < 512; ++x) white += res.ptr(y)[x] == 255;
+        }
+        CHECK(bad == 0);
+        CHECK(white > 512 * 512 / 2 && white < 512 * 512);   // paper white, strokes black
+    }
 }
 
 static void test_no_device_is_loud()

@@ -37,6 +37,33 @@ def test_cpp_host_parity_on_device():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def _build_dropin():
+    _build()
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s", "test_dropin_sample"], check=True)
+    return os.path.join(ROOT, "tests", "cpp", "test_dropin_sample")
+
+
+def test_dropin_headers_compile_the_sample_pattern_and_fail_loudly_without_device():
+    """include/prl/binarizeSauvola.h ... denoiseNLM.h: a caller that keeps the reference's #include lines
+    (samples/binarizations/binarizeSauvola_sample.cpp:25) builds with only -I include/prl."""
+    import torch
+
+    exe = _build_dropin()
+    if torch.cuda.is_available():
+        pytest.skip("a device is present; the no-device behaviour is checked on the CPU box")
+    r = subprocess.run([exe, "cpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "dropin sample: OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_dropin_sample_defaults_on_device():
+    exe = os.path.join(ROOT, "tests", "cpp", "test_dropin_sample")
+    if not os.path.exists(exe):
+        exe = _build_dropin()
+    r = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "dropin sample: OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_work_pool_many_callers():
     """prlib_amd/csrc/prl/work_pool.h (copy threads of the host-list entries): five callers inside parallel_for at once, every
     index run exactly once (plain C++, no device; tools/sanitize_cpu.sh runs the same program under ThreadSanitizer)."""

@@ -71,7 +71,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--defaults", type=int, default=0, help="1: also the five header-default calls")
+    ap.add_argument("--only", default="", help="comma-separated configuration names (default: all selected)")
+    ap.add_argument("--lib", default=None, help="A/B tooling: another build of libprlib_hip.so")
+    ap.add_argument("--hooks", type=int, default=0, help="A/B tooling: 1 = libprlib_hip_testhooks.so (reads the PRL_HIP_* knobs)")
     a = ap.parse_args()
+    if a.lib or a.hooks:
+        _capi.use_library(a.lib or _capi.HOOKS_LIB_PATH)
     H, W = a.height or a.size, a.size
     dev = torch.device("cuda:0")
     scans = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "scans", "*.npz")))
@@ -89,6 +94,8 @@ def main():
                   ("nick", prlib_amd.NICK), ("feng", prlib_amd.FENG))]
     from oracle import capi as oc
 
+    if a.only:
+        cfgs = [c for c in cfgs if c[0] in a.only.split(",")]
     for name, p in cfgs:
         out, g, r_real = run(real, p, a.steps, a.warmup, dev)
         po = oc.make_params(p.method, p.window_size, p.k, p.morph_iterations, p.feng_alpha1, p.feng_k1, p.feng_k2, p.feng_gamma)
