@@ -104,8 +104,6 @@ struct FusedParams {
     // k_init_globals cost each): the last workgroup of the last kernel (k_corner_partial<true>) writes the per-page flags
     // straight into the caller's pinned slot and leaves globals and counters in their initial state.  ep_host == null: off.
     double flt_dq;     // float32 pipeline: |Q~ - Q| <= flt_dq (absolute, flt_usable's delta) for the sums queued pixels carry
-    int wolf_est;      // Wolf threshold sweep: the coefficient is estimated from sweep A's float32 variance maximum (the literal
-                       // devianceMax is being computed on the side stream meanwhile; k_refine uses the literal one)
     PageGlobals* ep_host;
     PageGlobals* ep_dev;
     unsigned* ep_counters;
@@ -155,6 +153,13 @@ __device__ __forceinline__ float eval32f(const FusedParams& fp, float Sf, float 
 {
     // returns the NEGATED margin tn = Z (T~ - (p - 0.5)): white <=> tn < 0 <=> sign bit set, which pack_signs() turns
     // into the 0xFF mask byte; the settled test only uses |tn|
+    if (METHOD == PRL_NICK) {
+        // T only needs sqrt(Q); the "variance is not tiny" guard of the settled test rides on Q itself: v* >= q* / (1 + R)
+        // always ((w-1)^2 pixels divided by w^2), so Q above (1 + R) vthr / f implies v* > vthr (fp.vthr32 is that floor for NICK).
+        // Two instructions per pixel and two registers less than K~ (NICK sat at 98 VGPRs = 4 wavefronts per SIMD).
+        *k_out = Qf;
+        return fmaf(Sf, fp.c1, fmaf(__builtin_amdgcn_sqrtf(Qf), fp.c0, -P2));
+    }
     const float K = fmaf(fp.w2f, Qf, -(Sf * Sf));
     *k_out = K;
     if (METHOD == PRL_SAUVOLA) {
@@ -162,8 +167,6 @@ __device__ __forceinline__ float eval32f(const FusedParams& fp, float Sf, float 
         return fmaf(Sf, d, -P2);
     } else if (METHOD == PRL_NIBLACK) {
         return fmaf(Sf, fp.c1, fmaf(__builtin_amdgcn_sqrtf(K), fp.c0, -P2));
-    } else if (METHOD == PRL_NICK) {
-        return fmaf(Sf, fp.c1, fmaf(__builtin_amdgcn_sqrtf(Qf), fp.c0, -P2));
     } else if (METHOD == PRL_WOLFJOLION) {
         const float d = fmaf(__builtin_amdgcn_sqrtf(K), pk.c1, -fp.c0);
         const float e = fmaf(Sf, fp.c1, -pk.imin);
@@ -201,8 +204,9 @@ __device__ __forceinline__ float eval32(const FusedParams& fp, unsigned S, unsig
 // from it by at most ET (propagated from Em, Eq, the host-side bounds on the 4-tap rounding noise).
 template <int METHOD>
 // eq_extra: additional uncertainty of q = f Q (the float32 pipeline's Q~ is within flt_dq of the exact sum: f flt_dq; else 0)
+// coeff_rel (Wolf-Jolion): the literal k / devianceMax lies within coeff_rel |coeff| of `coeff` (k_wolf_interval)
 __device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, unsigned Q, unsigned p, double imin,
-                                             double coeff, double eq_extra = 0.0)
+                                             double coeff, double eq_extra = 0.0, double coeff_rel = 0.0)
 {
     if (p == 0) return 0;  // 0 > T8 is false for every T8 (also for NaN -> 0)
     const ThrParams& tp = fp.tp;
@@ -232,9 +236,9 @@ __device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, 
         T = m + c * tp.k;
         ET = fp.Em + fabs(tp.k) * Ec + tiny * (fabs(T) + m);
     } else if (METHOD == PRL_WOLFJOLION) {
-        if (!(fabs(coeff) < 1e300)) return 2;  // devianceMax == 0 or no finite deviation: literal decides
+        if (!(fabs(coeff) < 1e300) || !(coeff_rel < 1.0)) return 2;  // devianceMax == 0 / no finite deviation / no usable bound: literal decides
         const double d = s * coeff + (-tp.k);
-        const double Ed = fabs(coeff) * Es + tiny * (fabs(coeff) * s + fabs(tp.k));
+        const double Ed = fabs(coeff) * (Es + coeff_rel * (s + Es)) + tiny * (fabs(coeff) * s + fabs(tp.k));
         const double e = m - imin;
         const double Ee = fp.Em + tiny * (m + imin);
         const double gg = d * e;
@@ -540,9 +544,17 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                 if (lane_has_out && (x0 + c < tp.ow)) vm = fmaxf(vm, vv[c]);
             }
             if (__ballot(vm >= pk.c1) != 0ull) {
+                // the EXACT maximum of K = w^2 Q - S^2 (u64: S^2 < 2^48, w^2 Q < 2^49) bounds the literal devianceMax to a few
+                // parts in 10^9 (k_wolf_interval) - all the sweeps and k_refine need; the candidates themselves are only
+                // evaluated literally when a pixel of the page reaches the literal fix-up (k_wolf_literal)
+                unsigned long long kbest = 0ull;
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     if (lane_has_out && (x0 + c < tp.ow) && vv[c] >= pk.c1) {
+                        const unsigned long long s64 = (unsigned long long)(Ssum[c] - sbias);
+                        const unsigned long long k64 = (unsigned long long)(unsigned)(w * w) * (unsigned long long)Qsum[c] - s64 * s64;
+                        kbest = k64 > kbest ? k64 : kbest;
+                        atomicAdd(&g[page].n_cand, 1u);
                         const unsigned idx = atomicAdd(&counters[2], 1u);
                         if (idx < fp.wl_cap) {
                             WorkItem it;
@@ -552,10 +564,17 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                             it.pad = 0;
                             cand[idx] = it;
                         } else {
-                            atomicOr(&g[page].worklist_overflow, 1u);
+                            atomicOr(&g[page].cand_overflow, 1u);
                         }
                     }
                 }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const unsigned long long o = ((unsigned long long)(unsigned)__shfl_xor((int)(kbest >> 32), d, kWave) << 32) |
+                                                 (unsigned)__shfl_xor((int)(unsigned)kbest, d, kWave);
+                    kbest = o > kbest ? o : kbest;
+                }
+                if (lane == 0 && kbest) atomicMax(&g[page].kmax_bits, kbest);
             }
         } else {
             // float32 decision; tmin/vmin track the smallest margin / variance of the lane's 8 pixels.
@@ -1027,31 +1046,25 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
         pk.p0 = (float)((-0.5 - c3) * (double)kZ);
     } else if (METHOD == PRL_WOLFJOLION) {
         pk.imin = (float)g[page].imin * kZ;
-        if (!fp.wolf_est) {
-            const double coeff = g[page].coeff;                // k / devianceMax, binarizeWolfJolion.cpp:121
-            pk.c1 = (float)(coeff * tp.f);
-            // |T_literal - T*| grows with |coeff| through the sqrt noise; not finite -> nothing is settled here
-            const float ac = fabsf((float)coeff);
-            pk.eps1 = (ac < 3.0e38f) ? fp.eps1 + kZ * 2.02f * 255.0f * ac * fp.es_max : __builtin_inff();
-        } else {
-            // The literal devianceMax is still on its way (side stream): this sweep uses an ESTIMATE of k / devianceMax from
-            // sweep A's float32 variance maximum and widens the margin by what the estimate can be off.  K~max is within rho
-            // of the exact-arithmetic maximum Kmax (every K~ is within rho of its K), the literal variance within Ev of
-            // f^2 K, so devianceMax = f sqrt(Kmax) (1 +- delta), delta <= rho/2 + Ev / (2 f^2 Kmax) + roundings; T moves by
-            // |dc| s |m - Imin| <= |k| (s / devianceMax) delta 255.  k_refine decides what this leaves open with the literal one.
-            const float kmax = __uint_as_float(g[page].v32max_bits);
-            const float klow = kmax / (1.0f + fp.rho);
-            const float fl = (float)tp.f;
-            if (klow > fp.vthr32 && klow > 64.0f * fp.ev2) {
-                const float c = (float)tp.k / (__builtin_amdgcn_sqrtf(kmax) * fl);
-                const float delta = 0.51f * fp.rho + 0.26f * fp.ev2 / klow + 4.8e-7f;   // (+ 8 u: sqrt, product, quotient, c * f)
-                const float ac = fabsf(c) * (1.0f + delta);
-                pk.c1 = c * fl;
-                pk.eps1 = fp.eps1 + kZ * (2.02f * 255.0f * ac * fp.es_max + 1.02f * 255.0f * fabsf((float)tp.k) * delta);
-            } else {  // (no deviation to speak of on this page: nothing is settled here, k_refine / the literal pipeline decide)
-                pk.c1 = 0.0f;
-                pk.eps1 = __builtin_inff();
-            }
+        // The sweep takes k / devianceMax from sweep A's float32 variance maximum (the exact maximum and the literal one are
+        // being worked out on the side stream meanwhile) and widens its margin by what that estimate can be off.  K~max is
+        // within rho of the exact-arithmetic maximum Kmax (every K~ is within rho of its K), every literal variance within Ev
+        // of f^2 K, so devianceMax = f sqrt(Kmax) (1 +- delta), delta <= rho/2 + Ev / (2 f^2 Kmax) + roundings; T moves by
+        // |dc| s |m - Imin| <= |k| (s / devianceMax) delta 255.  k_refine decides what this leaves open (coefficient interval
+        // from the exact Kmax), the literal fix-up what THAT leaves open (literal devianceMax).
+        const float kmax = __uint_as_float(g[page].v32max_bits);
+        const float klow = kmax / (1.0f + fp.rho);
+        const float fl = (float)tp.f;
+        if (klow > fp.vthr32 && klow > 64.0f * fp.ev2) {
+            const float c = (float)tp.k / (__builtin_amdgcn_sqrtf(kmax) * fl);
+            const float delta = 0.51f * fp.rho + 0.26f * fp.ev2 / klow + 4.8e-7f;   // (+ 8 u: sqrt, product, quotient, c * f)
+            const float ac = fabsf(c) * (1.0f + delta);
+            pk.c1 = c * fl;
+            // (|T_literal - T*| grows with |coeff| through the sqrt noise: es_max)
+            pk.eps1 = fp.eps1 + kZ * (2.02f * 255.0f * ac * fp.es_max + 1.02f * 255.0f * fabsf((float)tp.k) * delta);
+        } else {  // (no deviation to speak of on this page: nothing is settled here, k_refine / the literal pipeline decide)
+            pk.c1 = 0.0f;
+            pk.eps1 = __builtin_inff();
         }
     } else if (METHOD == kWolfCollect) {
         // a pixel can only carry the literal maximum if K~ >= (1-rho) (Kmax/(1+rho) - 2 Ev / f^2)
@@ -1104,31 +1117,29 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
     const int lane = threadIdx.x & 63;
     const ThrParams& tp = fp.tp;
     const double eq_approx = fp.flt_dq * tp.f;
-    // the bucket lengths: four per lane, fetched at once (an empty queue - the rule for small calls - costs one round trip)
-    static_assert(kRefBuckets == 4 * kWave, "one load per lane and quarter");
-    unsigned len4[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) len4[k] = min(counters[64 + kRefCounterStride * (lane + kWave * k)], kRefBucketCap);
-    if (__ballot((len4[0] | len4[1] | len4[2] | len4[3]) != 0u) == 0ull) return;
-#pragma unroll 1
-    for (unsigned b = 0; b < (unsigned)kRefBuckets; ++b) {
-        const unsigned lsel = (b >> 6) == 0 ? len4[0] : (b >> 6) == 1 ? len4[1] : (b >> 6) == 2 ? len4[2] : len4[3];
-        const unsigned n = (unsigned)__shfl((int)lsel, (int)(b & 63u), kWave);
-        if (n == 0u) continue;
-        // (whole wavefronts go round together: the rebuild below is a wavefront's job; tid - lane is wave-uniform)
-        for (unsigned i = tid; i - lane < n; i += nthreads) {
+    // Wavefront W serves bucket W mod kRefBuckets, as the (W / kRefBuckets)-th of the wavefronts that do (the launch has a
+    // multiple of kRefBuckets wavefronts): one counter load per wavefront, an empty bucket - the rule for small calls - ends it.
+    const unsigned wave_id = tid >> 6, n_waves = nthreads >> 6;
+    const unsigned per_bucket = n_waves / (unsigned)kRefBuckets;   // >= 1
+    if (wave_id >= per_bucket * (unsigned)kRefBuckets) return;
+    {
+        const unsigned b = wave_id & (unsigned)(kRefBuckets - 1);
+        const unsigned n = min(counters[64 + kRefCounterStride * b], kRefBucketCap);
+        // (whole wavefronts go round together: the rebuild below is a wavefront's job; i - lane is wave-uniform)
+        for (unsigned i = (wave_id / (unsigned)kRefBuckets) * kWave + lane; i - lane < n; i += per_bucket * kWave) {
             const bool valid = i < n;
             RefItem it = rl[(size_t)b * kRefBucketCap + (valid ? i : 0u)];
             const bool approx = (it.p & kRefApprox) != 0u;
             it.p &= 0xffu;
             unsigned r = 2;
-            double imin = 0.0, coeff = 0.0;
+            double imin = 0.0, coeff = 0.0, crel = 0.0;
             if (valid) {
                 imin = (double)g[it.page].imin;
                 coeff = g[it.page].coeff;
+                if (METHOD == PRL_WOLFJOLION) crel = g[it.page].coeff_rel;
                 // one thread per pixel: float64 interval test on the sums the sweep sent along (the float32 pipeline's Q~ with
                 // its rounding bound as extra uncertainty of q)
-                r = refine64<METHOD>(fp, it.S, it.Q, it.p, imin, coeff, approx ? eq_approx : 0.0);
+                r = refine64<METHOD>(fp, it.S, it.Q, it.p, imin, coeff, approx ? eq_approx : 0.0, crel);
             }
             // what that leaves open and has an approximate Q: the wavefront rebuilds S and Q exactly from the page - padded rows
             // y+1 .. y+w-1, columns x+1 .. x+w-1 of the replicate-padded page, exact in u32 - one pixel at a
@@ -1153,7 +1164,7 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
                     S += __shfl_xor(S, d, kWave);
                     Q += __shfl_xor(Q, d, kWave);
                 }
-                if (lane == owner) r = refine64<METHOD>(fp, S, Q, it.p, imin, coeff);
+                if (lane == owner) r = refine64<METHOD>(fp, S, Q, it.p, imin, coeff, 0.0, crel);
             }
             if (!valid) continue;
             if (r != 2) {
@@ -1161,6 +1172,7 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
                 atomicAdd(&g[it.page].n_refined, 1u);
             } else {
                 atomicAdd(&g[it.page].n_exact, 1u);
+                if (METHOD == PRL_WOLFJOLION) atomicOr(&g[it.page].need_literal, 1u);   // the fix-up evaluates with the LITERAL devianceMax (k_wolf_literal)
                 const unsigned idx = atomicAdd(&counters[1], 1u);
                 if (idx < fp.wl_cap) {
                     WorkItem w;
@@ -1248,11 +1260,15 @@ __global__ void __launch_bounds__(256) k_corner_partial(PageSet src, FusedParams
                                                        const PageGlobals* __restrict__ g, unsigned* __restrict__ done)
 {
     const ThrParams& tp = fp.tp;
+    // (Wolf-Jolion's candidates, which == 2: only when some pixel reached the literal fix-up - counters[1] - and then only
+    // the candidates of the pages concerned; the rule is an immediate return)
+    if (!FINAL && counters[1] == 0u) return;
     const unsigned n = min(counters[which], fp.wl_cap);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
     const int W = tp.width, H = tp.height, h = tp.half;
     for (unsigned it = blockIdx.y; it < n; it += gridDim.y) {
         const WorkItem wi = items[it];
+        if (!FINAL && !g[wi.page].need_literal) continue;   // (uniform over the workgroup)
         const uint8_t* img = src.page(wi.page);
         const int Y0 = wi.y, X0 = wi.x, Y1 = wi.y + tp.w - 1, X1 = wi.x + tp.w - 1;
         // page rows that appear in padded rows [0..Y1], split over the kSplit workgroups of this pixel
@@ -1336,7 +1352,7 @@ __global__ void __launch_bounds__(256) k_corner_partial(PageSet src, FusedParams
                     fp.ep_host[i] = fp.ep_dev[i];
                     PageGlobals z;
                     z.imin = 255; z.smax_found = 0; z.smax_bits = 0ull; z.coeff = 0.0;
-                    z.n_refined = 0; z.n_exact = 0; z.worklist_overflow = 0; z.v32max_bits = 0; z.n_cand = 0; z.reserved0 = 0;
+                    z.n_refined = 0; z.n_exact = 0; z.worklist_overflow = 0; z.v32max_bits = 0; z.n_cand = 0; z.need_literal = 0; z.kmax_bits = 0ull; z.coeff_rel = 0.0; z.cand_overflow = 0; z.reserved0 = 0;
                     fp.ep_dev[i] = z;   // = k_init_globals
                 }
                 if (threadIdx.x < 64) fp.ep_counters[threadIdx.x] = 0u;
@@ -1357,23 +1373,64 @@ __device__ __forceinline__ void literal_mq(const CornerAcc& c, double f, double*
     *q = box4_literal(AQ, BQ, CQ, DQ, f);
 }
 
-// Wolf-Jolion: literal deviation of every candidate of sweep B; their maximum is exactly
-// cv::minMaxLoc(localDevianceValues)'s devianceMax (binarizeWolfJolion.cpp:118-119).
+// Wolf-Jolion, devianceMax (binarizeWolfJolion.cpp:118-121) in two precisions.
+// k_wolf_interval: from the exact integer maximum Kmax of K = w^2 Q - S^2 (sweep B).  The exact-arithmetic variance maximum is
+// v* = f^2 Kmax; every literal variance is within Ev of its exact value and the literal sqrt is correctly rounded, so
+// devianceMax_literal lies in [sqrt(v* - Ev), sqrt(v* + Ev)] (1 +- 2^-52): coeff = k / sqrt(v*) and a relative bound
+// coeff_rel on its distance from the literal k / devianceMax - all the threshold sweep's margin and k_refine's intervals need.
+__global__ void k_wolf_interval(FusedParams fp, PageGlobals* __restrict__ g, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PageGlobals& pg = g[i];
+    const double f = fp.tp.f;
+    const double v = (double)pg.kmax_bits * f * f;          // (Kmax < 2^49: exact conversion; two roundings + f's own)
+    const double Ev = fp.Eq + 2.0 * 255.0 * fp.Em + fp.Em * fp.Em + 8.9e-16 * 2.0 * 65025.0 + 4e-15 * v;
+    if (v > 64.0 * Ev) {
+        pg.coeff = fp.tp.k / sqrt(v);
+        pg.coeff_rel = 0.51 * Ev / (v - Ev) + 1e-14;
+    } else {   // no deviation to speak of (or no candidate at all): nothing can be said about the literal maximum
+        pg.coeff = 0.0;
+        pg.coeff_rel = 2.0;   // refine64 refuses; the pixels go to the literal fix-up, which computes the literal maximum
+    }
+}
+
+// k_wolf_literal: the LITERAL maximum, for the pages that need it (a pixel reached the literal fix-up: need_literal) - the
+// literal deviation of every candidate of sweep B from its absolute integral corners (k_corner_partial<false>); their maximum
+// is exactly cv::minMaxLoc(localDevianceValues)'s devianceMax.  Two small kernels behind k_refine, which return at once when
+// no pixel of the call reached the fix-up (counters[1] == 0).
 __global__ void __launch_bounds__(256) k_wolf_final(FusedParams fp, PageGlobals* __restrict__ g,
                                                    const WorkItem* __restrict__ cand, const CornerAcc* __restrict__ acc,
                                                    const unsigned* __restrict__ counters)
 {
+    if (counters[1] == 0u) return;
     const unsigned n = min(counters[2], fp.wl_cap);
     for (unsigned it = blockIdx.x * blockDim.x + threadIdx.x; it < n; it += gridDim.x * blockDim.x) {
+        if (!g[cand[it].page].need_literal) continue;
         double m, q;
         literal_mq(acc[it], fp.tp.f, &m, &q);
         const double s = dev_from(m, q);
-        atomicAdd(&g[cand[it].page].n_cand, 1u);
         if (s == s) {  // NaN never wins minMaxLoc
             atomicMax(&g[cand[it].page].smax_bits, (unsigned long long)__double_as_longlong(s) & 0x7fffffffffffffffull);
             atomicOr(&g[cand[it].page].smax_found, 1);
         }
     }
+}
+
+__global__ void k_wolf_literal_coeff(FusedParams fp, PageGlobals* __restrict__ g, int n, const unsigned* __restrict__ counters)
+{
+    if (counters[1] == 0u) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PageGlobals& pg = g[i];
+    if (!pg.need_literal) return;
+    if (pg.cand_overflow) {   // the candidate list does not hold every candidate of this page: the literal pipeline redoes it
+        pg.worklist_overflow = 1u;
+        return;
+    }
+    const double smax = pg.smax_found ? __longlong_as_double((long long)pg.smax_bits)
+                                      : -1.7976931348623157e308;  // minMaxLoc's initial -DBL_MAX
+    pg.coeff = fp.tp.k / smax;   // double coeff = k / devianceMax  - binarizeWolfJolion.cpp:121 (IEEE division on the device)
 }
 
 // Page minimum of the part of the page no sweep-A wavefront fetches: the sweeps stop h rows above the bottom and may
@@ -1446,7 +1503,8 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
 template <int METHOD>
 int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
                  PageGlobals* g, RefItem* rl, WorkItem* wl, WorkItem* cand, CornerAcc* acc, unsigned* cnt,
-                 hipEvent_t ev_start, hipEvent_t ev_stop, bool with_fixup, hipEvent_t before_refine = nullptr)
+                 hipEvent_t ev_start, hipEvent_t ev_stop, bool with_fixup, hipEvent_t before_refine = nullptr,
+                 CornerAcc* cacc = nullptr, int n_pages = 0)
 {
     if (ev_start) PRL_HIP_CHECK(hipEventRecord(ev_start, stream));
     int st = launch_sweep<METHOD>(sh, stream, src, dst, fp, g, rl, cand, cnt);
@@ -1459,6 +1517,14 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     const unsigned refine_blocks = fp.flt ? (fp.total_waves > 20000u ? 1024u : 256u) : 64u;
     hipLaunchKernelGGL((k_refine<METHOD>), dim3(refine_blocks), dim3(256), 0, stream, src, dst, fp, g, rl, wl, cnt, acc, done);
     PRL_HIP_CHECK(hipGetLastError());
+    if (METHOD == PRL_WOLFJOLION) {
+        // the literal devianceMax of the pages whose pixels reached the fix-up list (none, as a rule: three immediate returns)
+        hipLaunchKernelGGL(k_corner_partial<false>, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, cand, cnt, 2, cacc, dst, g,
+                           static_cast<unsigned*>(nullptr));
+        hipLaunchKernelGGL(k_wolf_final, dim3(16), dim3(256), 0, stream, fp, g, cand, cacc, cnt);
+        hipLaunchKernelGGL(k_wolf_literal_coeff, dim3((n_pages + 63) / 64), dim3(64), 0, stream, fp, g, n_pages, cnt);
+        PRL_HIP_CHECK(hipGetLastError());
+    }
     if (!with_fixup) return PRL_OK;
     // literal fix-up of what k_refine queued: the kernel reads the queue length on the device and does nothing when it is
     // empty (the usual case), so no host round trip decides whether it runs; k_refine zeroed the accumulators it uses; the
@@ -1616,8 +1682,10 @@ extern "C" int prl_hip_internal_flt_q_error(int w, double* delta_qmin_cq)
 size_t fused_small_bytes(int)
 {
     // [counters][refine list: kRefBuckets x kRefBucketCap][fix-up list][Wolf candidate list][corner sums][Wolf per-wavefront maxima][arrival counters]
+    // [... arrival counters][corner sums of Wolf-Jolion's candidates]
     return kFusedCounterBytes + sizeof(RefItem) * (size_t)kRefineCap + 2 * sizeof(WorkItem) * (size_t)kWorkCap +
-           sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(float) * kSegmaxCap + sizeof(unsigned) * (size_t)kWorkCap;
+           sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(float) * kSegmaxCap + sizeof(unsigned) * (size_t)kWorkCap +
+           sizeof(CornerAcc) * (size_t)kWorkCap;
 }
 
 // Strips of a row: uo output columns each, fetched with w - 1 halo columns; uo = 512 - (w - 1) rounded down to a multiple of 8,
@@ -1790,6 +1858,10 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.Eq = b.Eq;
     fp.vthr = b.vthr;
     fp.vthr32 = (float)(b.vthr / (f * f) * (1.0 + 2.0 * b.rho + 1e-5));
+    if (tp.method == PRL_NICK) {   // a floor on Q~ instead (eval32f): Q > (1 + R) vthr / f  =>  v* >= q* / (1 + R) > vthr
+        const double n1 = tp.w - 1.0, R = n1 * n1 / (2.0 * tp.w - 1.0);
+        fp.vthr32 = (float)((1.0 + R) * b.vthr / f * (1.0 + 2.0 * (fp.flt ? cq : 1.0) * std::ldexp(1.0, -24) + 1e-5));
+    }
     fp.eps1 = (float)(b.eps1 * 1.01 * Z);
     fp.ref_cap = kRefineCap;
     fp.wl_cap = kWorkCap;
@@ -1822,6 +1894,7 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     auto* cand = wl + kWorkCap;
     auto* acc = reinterpret_cast<CornerAcc*>(cand + kWorkCap);
     fp.segmax = reinterpret_cast<float*>(acc + kWorkCap);
+    auto* cacc = reinterpret_cast<CornerAcc*>(reinterpret_cast<unsigned*>(fp.segmax + kSegmaxCap) + kWorkCap);   // (behind the arrival counters)
     if (phase == 2) {  // (kept for callers that split the pipeline; k_refine of phase 1 zeroed what this uses)
         unsigned* done = reinterpret_cast<unsigned*>(fp.segmax + kSegmaxCap);
         hipLaunchKernelGGL(k_corner_partial<true>, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc, dst, d_globals, done);
@@ -1847,13 +1920,16 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         // (cv::minMaxLoc(imageInput) rides on sweep A - every window row a wavefront fetches goes into a running
         // minimum - plus a small kernel for the bottom rows / right columns the sweeps never fetch; Feng, which has no
         // sweep, uses k_page_min)
-        // Schedule (round 4).  Only the two big sweeps are on the caller's stream: sweep A (variance maximum, float32) and the
-        // threshold sweep, which takes its coefficient from sweep A's maximum with a margin for the difference (k_fused,
-        // fp.wolf_est).  Everything that exists to reproduce the LITERAL devianceMax - the candidate sweep B, the absolute
-        // corner sums of its candidates, the literal deviations, k / devianceMax - and the page minimum of the border bands
-        // run on the workspace's side stream beside them; k_refine (float64 intervals with the literal coefficient) waits
-        // for it.  256 A4 pages at the header defaults: 5.5 -> see profiles/r04/wolf_schedule_ab.txt.  Without a side stream
-        // (PRL_HIP_WOLF_SIDE=0 in the hooks build): everything in order on one stream, literal coefficient in every sweep.
+        // Schedule (round 4).  On the caller's stream: sweep A (float32 variance maximum per page and per wavefront), the
+        // threshold sweep - its coefficient comes from sweep A's maximum with a margin for the difference (k_fused) -, k_refine
+        // and the fix-up.  On the workspace's side stream, beside the two sweeps: the page minimum of the border bands, sweep B
+        // (revisits the wavefronts that can hold the maximum: EXACT integer maximum of K, and the candidate pixels) and
+        // k_wolf_interval (k / devianceMax with a bound of a few 10^-9 on its distance from the literal one), for which
+        // k_refine waits.  The literal devianceMax itself - absolute integral corners of every candidate, the part that cost
+        // 0.2-13 ms - is only computed when a pixel reaches the literal fix-up, and then for that page only (k_corner_partial
+        // <false>, k_wolf_final, k_wolf_literal_coeff: they return at once otherwise).  256 A4 pages at the header defaults:
+        // profiles/r04/wolf_schedule_ab.txt.  Without a side stream (PRL_HIP_WOLF_SIDE=0, hooks build): the same kernels in
+        // order on one stream.
         hipStream_t ss = wolf_side ? wolf_side->stream : stream;
         auto border_min = [&](hipStream_t q) -> int {
             const int band = std::min(std::max(tp.w + 8, 16), std::max(tp.width, tp.height));
@@ -1870,26 +1946,20 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         if (wolf_side) {
             PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_fork, stream));          // (globals and counters are initialised)
             PRL_HIP_CHECK(hipStreamWaitEvent(ss, wolf_side->ev_fork, 0));
-            st = border_min(ss);
-            if (st != PRL_OK) return st;
-            PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_min, ss));
         }
+        PRL_HIP_CHECK(hipMemsetAsync(cacc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, ss));   // (only the lazy literal path uses it)
+        st = border_min(ss);
+        if (st != PRL_OK) return st;
+        if (wolf_side) PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_min, ss));
         st = launch_sweep<kWolfMax>(sh, stream, src, dst, fp, d_globals, rl, cand, cnt);
         if (st != PRL_OK) return st;
         if (wolf_side) {
             PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_a, stream));
             PRL_HIP_CHECK(hipStreamWaitEvent(ss, wolf_side->ev_a, 0));
-        } else {
-            st = border_min(ss);
-            if (st != PRL_OK) return st;
         }
         st = launch_sweep<kWolfCollect>(sh, ss, src, dst, fp, d_globals, rl, cand, cnt);
         if (st != PRL_OK) return st;
-        PRL_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, ss));
-        hipLaunchKernelGGL(k_corner_partial<false>, dim3(kSplit, 128), dim3(256), 0, ss, src, fp, cand, cnt, 2, acc, dst, d_globals,
-                           static_cast<unsigned*>(nullptr));
-        PRL_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(k_wolf_final, dim3(16), dim3(256), 0, ss, fp, d_globals, cand, acc, cnt);
+        hipLaunchKernelGGL(k_wolf_interval, dim3((n_pages + 63) / 64), dim3(64), 0, ss, fp, d_globals, n_pages);
         PRL_HIP_CHECK(hipGetLastError());
         if (env_knobs().debug) {
             unsigned hc[4] = {0, 0, 0, 0};
@@ -1897,16 +1967,14 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
             (void)hipStreamSynchronize(ss);
             std::fprintf(stderr, "[prl_hip] Wolf-Jolion: %u maximum-deviation candidates on %d pages (cap %u)\n", hc[2], n_pages, fp.wl_cap);
         }
-        st = wolf_coeff_run(tp, d_globals, 0, n_pages, ss);
-        if (st != PRL_OK) return st;
         hipEvent_t before_refine = nullptr;
         if (wolf_side) {
             PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_coeff, ss));
             PRL_HIP_CHECK(hipStreamWaitEvent(stream, wolf_side->ev_min, 0));   // the threshold sweep needs the whole page minimum
-            fp.wolf_est = 1;
             before_refine = wolf_side->ev_coeff;
         }
-        return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, before_refine);
+        return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, before_refine,
+                                            cacc, n_pages);
     }
     switch (tp.method) {
     case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);

@@ -50,6 +50,10 @@ __global__ void k_init_globals(PageGlobals* g, int n, unsigned* counters)
         g[i].worklist_overflow = 0;
         g[i].v32max_bits = 0;
         g[i].n_cand = 0;
+        g[i].need_literal = 0;
+        g[i].kmax_bits = 0ull;
+        g[i].coeff_rel = 0.0;
+        g[i].cand_overflow = 0;
         g[i].reserved0 = 0;
     }
 }

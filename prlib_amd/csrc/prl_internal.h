@@ -208,7 +208,11 @@ struct PageGlobals {
     unsigned int n_exact;           // pixels sent to the absolute-integral fix-up
     unsigned int worklist_overflow; // fix-up list overflowed -> page must rerun literally
     unsigned int v32max_bits;       // Wolf fused sweep A: float32 bits of the page's largest variance estimate
-    unsigned int n_cand;            // Wolf: pixels whose deviation was evaluated literally for devianceMax (statistics)
+    unsigned int n_cand;            // Wolf: candidate pixels for the literal devianceMax (sweep B; statistics)
+    unsigned int need_literal;      // Wolf: a pixel of this page reached the literal fix-up -> the literal devianceMax is computed (lazily)
+    unsigned long long kmax_bits;   // Wolf: exact integer maximum of K = w^2 Q - S^2 over the output region (sweep B)
+    double coeff_rel;               // Wolf: |k / devianceMax_literal - coeff| <= coeff_rel |coeff| (coeff = k / (f sqrt(Kmax)) until need_literal)
+    unsigned int cand_overflow;     // Wolf: the candidate list overflowed: the literal devianceMax is not available for this page
     unsigned int reserved0;
 };
 

@@ -252,8 +252,46 @@ def test_wolf_runs_fused(prl, oracle, cuda_device):
     assert st.literal_pages == 0
     st = _check(prl, oracle, cuda_device, pages, WOLFJOLION, 101, 0.01, 2)   # header defaults
     assert st.literal_pages == 0
-    # degenerate page (no deviation anywhere): every pixel is a maximum candidate -> literal pipeline
+    # degenerate pages (no deviation anywhere, or the same everywhere): every pixel is a maximum candidate.  Round 4: the
+    # sweeps only need the EXACT maximum of K (one atomicMax per wavefront), the candidate list may overflow - the page
+    # stays on the fast path (round 3 sent it through the literal pipeline)
     st = _check(prl, oracle, cuda_device, [np.zeros((700, 600), np.uint8)], WOLFJOLION, 15, 0.3, 0)
+    assert st.literal_pages == 0
+    st = _check(prl, oracle, cuda_device, [np.full((700, 600), 7, np.uint8), np.full((700, 600), 255, np.uint8)], WOLFJOLION, 15, 0.3, 2)
+    assert st.literal_pages == 0
+
+
+def _wolf_boundary_page_and_k(oracle, w, c, flat, seed, shape=(200, 260)):
+    """A page with a noisy half (it holds the deviation maximum) and a flat square of value c, and the k for which the
+    exact-arithmetic Wolf-Jolion threshold on the flat square equals c - 0.5: T = m + (s k / smax - k)(m - Imin)."""
+    rng = np.random.default_rng(seed)
+    h, wd = shape
+    page = rng.integers(0, 256, (h, wd), dtype=np.uint8)
+    y0, x0 = 20, wd // 2
+    page[y0:y0 + flat + w, x0:x0 + flat + w] = c
+    page[0, 0] = 0   # Imin = 0
+    m, s = oracle.mean_dev(page, oracle.make_params(WOLFJOLION, w, 0.3, 0))
+    smax = np.nanmax(s)
+    half = w // 2
+    yy, xx = y0 + half + 2, x0 + half + 2   # an output pixel whose window lies inside the flat square
+    mf, sf = m[yy, xx], s[yy, xx]
+    k = (c - 0.5 - mf) / ((sf / smax - 1.0) * (mf - 0.0))
+    return page, k, (yy, xx)
+
+
+def test_wolf_literal_maximum_is_computed_when_a_pixel_needs_it(prl, oracle, cuda_device):
+    """Pixels within ~1e-13 of their threshold defeat the float64 interval test, so the literal fix-up decides them - and for
+    Wolf-Jolion that needs the LITERAL devianceMax, which round 4 only computes then (absolute corner sums of sweep B's
+    candidates of that page): the lazy path, on the page that needs it, beside pages that do not."""
+    w, c = 15, 120
+    page, k, _ = _wolf_boundary_page_and_k(oracle, w, c, flat=24, seed=61)
+    others = _pages(page.shape, ["doc", "noise"], seed=62)
+    for morph in (0, 2):
+        st = _check(prl, oracle, cuda_device, [others[0], page, others[1]], WOLFJOLION, w, k, morph)
+        assert st.exact_pixels >= 24 * 24 // 2 and st.literal_pages == 0
+    # the same with so many such pixels that the fix-up list overflows: that page (only) goes through the literal pipeline
+    big, kb, _ = _wolf_boundary_page_and_k(oracle, w, c, flat=160, seed=63, shape=(420, 520))
+    st = _check(prl, oracle, cuda_device, [big, _pages(big.shape, ["doc"], seed=64)[0]], WOLFJOLION, w, kb, 0)
     assert st.literal_pages == 1
 
 
