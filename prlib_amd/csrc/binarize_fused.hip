@@ -103,6 +103,8 @@ struct FusedParams {
     // Epilogue of the call (small batches: a launch costs ~4 us, which is what the flag copy and the next call's
     // k_init_globals cost each): the last workgroup of the last kernel (k_corner_partial<true>) writes the per-page flags
     // straight into the caller's pinned slot and leaves globals and counters in their initial state.  ep_host == null: off.
+    int flt_a;         // Wolf sweep A runs the float32 loop for this (wide) window too: no decision there, only K~ (flt_a_usable)
+    float kabs;        // ... whose K~ then carries an ABSOLUTE error bound (w^2 times the rounding of the wide Q sums), in K units
     double flt_dq;     // float32 pipeline: |Q~ - Q| <= flt_dq (absolute, flt_usable's delta) for the sums queued pixels carry
     PageGlobals* ep_host;
     PageGlobals* ep_dev;
@@ -742,7 +744,11 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     const int xlim = min(xs + fp.uo, tp.ow);
     const bool lane_has_out = FAST ? CPL * lane < fp.uo : x0 < xlim;
     const bool full8 = FAST ? lane_has_out : x0 + CPL <= xlim;
-    const int far_addr0 = (lane + LO) * 4, far_addr1 = far_addr0 + 4;
+    // LO 0..3: the number of whole lanes between a window's two edges, W gathered by that many DPP steps.  LO == 4 (sweep A
+    // with wide windows): fp.lane_off lanes, W by doubling (see below)
+    constexpr bool SCAN = LO == 4;
+    const int loff = SCAN ? fp.lane_off : LO;
+    const int far_addr0 = (lane + loff) * 4, far_addr1 = far_addr0 + 4;
     const i32x4 rsrc = page_rsrc(img);
     const int step = (int)istep;
     const EdgeFix ew = EDGE ? make_edge(col0, tp.width) : EdgeFix{0, 0u, 0u};
@@ -844,9 +850,49 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         w1s = tot_s + lane_up1f(w1s);     \
         w1q = tot_q + lane_up1f(w1q);     \
     } while (0)
-        if (LO >= 1) PRL_W_STEP();  // w - 1 <= 30: at most 3 steps
-        if (LO >= 2) PRL_W_STEP();
-        if (LO >= 3) PRL_W_STEP();
+        if (!SCAN) {
+            if (LO >= 1) PRL_W_STEP();  // w - 1 <= 30: at most 3 steps
+            if (LO >= 2) PRL_W_STEP();
+            if (LO >= 3) PRL_W_STEP();
+        } else {
+            // W over `loff` (5..16) lanes starting at this one: sums of 2, 4, 8 (16) consecutive lanes by doubling - the
+            // operand of lane + 2^k comes through ds_bpermute (the LDS pipe has room, the vector ALU has not) - then the
+            // binary digits of loff pick the pieces.  Every S quantity stays exact (<= 17 lanes x 8 columns x 128 rows x 255
+            // < 2^24); the Q roundings are bounded by flt_a_usable() and only widen sweep B's candidate band.
+            const int l4 = lane * 4;
+            const float s2 = tot_s + lane_up1f(tot_s), q2 = tot_q + lane_up1f(tot_q);
+            const float s4 = s2 + bpermf(l4 + 8, s2), q4 = q2 + bpermf(l4 + 8, q2);
+            const float s8 = s4 + bpermf(l4 + 16, s4), q8 = q4 + bpermf(l4 + 16, q4);
+            int off = 0;
+            w0s = w0q = 0.0f;
+            if (loff & 16) {
+                w0s = s8 + bpermf(l4 + 32, s8);
+                w0q = q8 + bpermf(l4 + 32, q8);
+                off = 16;
+            }
+            if (loff & 8) {
+                w0s += off ? bpermf(l4 + 4 * off, s8) : s8;
+                w0q += off ? bpermf(l4 + 4 * off, q8) : q8;
+                off += 8;
+            }
+            if (loff & 4) {
+                w0s += off ? bpermf(l4 + 4 * off, s4) : s4;
+                w0q += off ? bpermf(l4 + 4 * off, q4) : q4;
+                off += 4;
+            }
+            if (loff & 2) {
+                w0s += off ? bpermf(l4 + 4 * off, s2) : s2;
+                w0q += off ? bpermf(l4 + 4 * off, q2) : q2;
+                off += 2;
+            }
+            if (loff & 1) {
+                w0s += off ? bpermf(l4 + 4 * off, tot_s) : tot_s;
+                w0q += off ? bpermf(l4 + 4 * off, tot_q) : tot_q;
+                off += 1;
+            }
+            w1s = w0s + bpermf(l4 + 4 * off, tot_s);
+            w1q = w0q + bpermf(l4 + 4 * off, tot_q);
+        }
 #undef PRL_W_STEP
 #pragma unroll
         for (int c = 0; c < CPL; ++c) Ssum[c] = bpermf((c + SH) >= 8 ? far_addr1 : far_addr0, ES[(c + SH) & 7]);
@@ -1053,11 +1099,11 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
         // |dc| s |m - Imin| <= |k| (s / devianceMax) delta 255.  k_refine decides what this leaves open (coefficient interval
         // from the exact Kmax), the literal fix-up what THAT leaves open (literal devianceMax).
         const float kmax = __uint_as_float(g[page].v32max_bits);
-        const float klow = kmax / (1.0f + fp.rho);
+        const float klow = kmax / (1.0f + fp.rho) - fp.kabs;
         const float fl = (float)tp.f;
         if (klow > fp.vthr32 && klow > 64.0f * fp.ev2) {
             const float c = (float)tp.k / (__builtin_amdgcn_sqrtf(kmax) * fl);
-            const float delta = 0.51f * fp.rho + 0.26f * fp.ev2 / klow + 4.8e-7f;   // (+ 8 u: sqrt, product, quotient, c * f)
+            const float delta = 0.51f * fp.rho + (0.26f * fp.ev2 + 0.51f * fp.kabs) / klow + 4.8e-7f;   // (+ 8 u: sqrt, product, quotient, c * f)
             const float ac = fabsf(c) * (1.0f + delta);
             pk.c1 = c * fl;
             // (|T_literal - T*| grows with |coeff| through the sqrt noise: es_max)
@@ -1069,7 +1115,7 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     } else if (METHOD == kWolfCollect) {
         // a pixel can only carry the literal maximum if K~ >= (1-rho) (Kmax/(1+rho) - 2 Ev / f^2)
         const float vmax = __uint_as_float(g[page].v32max_bits);
-        pk.c1 = (1.0f - fp.rho) * (vmax / (1.0f + fp.rho) - fp.ev2) * 0.999999f;
+        pk.c1 = (1.0f - fp.rho) * (vmax / (1.0f + fp.rho) - fp.ev2 - 2.0f * fp.kabs) * 0.999999f;   // (kabs: sweep A's absolute error, once for the maximum, once for the segment maxima)
         if (!(fp.segmax[wid] >= pk.c1)) return;            // nothing in this wavefront's segment qualifies
     }
 
@@ -1078,7 +1124,11 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     const int first_col = xs + 1 - tp.half;
     const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
     constexpr bool kFloatOk = METHOD != kWolfCollect;  // (sweep B revisits few segments and queues exact candidates: integer)
-    if (kFloatOk && !WIDE && fp.flt) {
+    if (METHOD == kWolfMax && !WIDE && !fp.flt && fp.flt_a && !(fp.ext && strip == fp.n_strips - 1)) {
+        // sweep A with a wide window: the float32 loop in its doubling form (the extended last strip stays on the integer loop)
+        if (!interior) strip_loop_f<METHOD, SH, 4, false, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
+        else strip_loop_f<METHOD, SH, 4, false, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
+    } else if (kFloatOk && !WIDE && fp.flt) {
         // (wave-uniform dispatch, once per wavefront: the row loop itself is branch-free in the usual configuration)
         const bool fast = !fp.bit_out && fp.nt_store && !fp.need_p0 && !(fp.uo & 7);
 #define PRL_FLT_LOOP(LOV)                                                                                                          \
@@ -1669,6 +1719,39 @@ static bool flt_usable(const ThrParams& tp, size_t src_step, double* cq, double*
     return true;
 }
 
+// Wolf-Jolion's sweep A with windows wider than 31 on the float32 loop (LO == 4 form).  There is no decision in sweep A, only
+// K~ = fma(w^2, Q~, -S^2) for the variance maximum, so an ABSOLUTE bound on |Q~ - Q| is enough: it widens the band in which
+// sweep B looks for the exact maximum and the margin of the threshold sweep's estimated coefficient.  S: every partial sum
+// covers at most 17 lanes x 8 columns x (w-1) rows of 255 < 2^24 for w - 1 <= 128: exact.  Q: each addition rounds by at most
+// half an ulp of the largest value its result can take; the bound below follows the additions of the loop one by one.
+static bool flt_a_usable(const ThrParams& tp, size_t src_step, double* dq_out)
+{
+    if (!env_knobs().flt) return false;
+    const int n1 = tp.w - 1;
+    if (n1 <= 30 || n1 > 128 || (n1 & 1)) return false;
+    if ((unsigned long long)src_step * (unsigned long long)tp.height >= 0x7fffffffull) return false;  // 32-bit buffer offsets
+    auto half_ulp = [](double x) { return x < 16777216.0 ? 0.0 : std::ldexp(1.0, (int)std::floor(std::log2(x)) - 24); };
+    const double col = (double)n1 * 65025.0;   // largest column sum of squares (exact: < 2^24)
+    double e_tot = 0.0;                          // error of an in-lane prefix / of a lane total
+    for (int j = 2; j <= 8; ++j) e_tot += half_ulp(j * col);
+    const double T = 8.0 * col;
+    const int L = n1 / 8;
+    double e2 = 2 * e_tot + half_ulp(2 * T), e4 = 2 * e2 + half_ulp(4 * T), e8 = 2 * e4 + half_ulp(8 * T), e16 = 2 * e8 + half_ulp(16 * T);
+    double ew = 0.0;   // error of w1 (w0 is one piece less)
+    int lanes = 0;
+    for (int bit = 16; bit >= 1; bit >>= 1)
+        if (L & bit) {
+            ew += bit == 16 ? e16 : bit == 8 ? e8 : bit == 4 ? e4 : bit == 2 ? e2 : e_tot;
+            lanes += bit;
+            ew += half_ulp(lanes * T);
+        }
+    ew += e_tot + half_ulp((lanes + 1) * T);
+    // Q = (E_far - E_own) + W
+    const double dq = 2 * e_tot + half_ulp(T) + ew + half_ulp((lanes + 2) * T);
+    *dq_out = dq;
+    return true;
+}
+
 extern "C" int prl_hip_internal_flt_q_error(int w, double* delta_qmin_cq)
 {
     // test hook (not in the public header): the float32 pipeline's bound on |Q~ - Q| for window w -
@@ -1880,6 +1963,12 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.es_max = (float)(b.Es * 1.01);
     fp.rho = (float)(std::fmax(b1.rho, b.rho) * 1.01);  // sweep A runs the float32 pipeline on interior strips, sweep B the integer one
     fp.ev2 = (float)(2.0 * b1.Ev * 1.01 / (f * f));  // in K units
+    {
+        double dqa = 0.0;
+        fp.flt_a = (tp.method == PRL_WOLFJOLION && !fp.flt && flt_a_usable(tp, src.step, &dqa)) ? 1 : 0;
+        // |K~ - K| <= w^2 |Q~ - Q| (+ the relative part, rho: S^2 and the fma round as in the integer pipeline's conversion)
+        fp.kabs = fp.flt_a ? (float)((double)(tp.w * tp.w) * dqa * 1.01) : 0.0f;
+    }
 
     // [0] refine-list length, [1] fix-up-list length, [2] Wolf candidate-list length
     auto* cnt = static_cast<unsigned*>(small);

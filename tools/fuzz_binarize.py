@@ -17,10 +17,12 @@ from oracle import capi as oc
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--methods", default="0,1,2,3,4", help="comma-separated method ids to draw from (2 = Wolf-Jolion)")
+ap.add_argument("--wide", type=float, default=0.0, help="probability of a window from {41..129} (the wide-window paths)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 dev = torch.device("cuda:0")
-METHODS = [prlib_amd.SAUVOLA, prlib_amd.NIBLACK, prlib_amd.WOLFJOLION, prlib_amd.NICK, prlib_amd.FENG]
+METHODS = [int(m) for m in a.methods.split(",")]
 
 
 def page(h, w, kind, i):
@@ -45,8 +47,10 @@ calls = pixels = bad_calls = 0
 first_bad = None
 stats = {"refined": 0, "exact": 0, "literal_pages": 0}
 while time.time() < t_end:
-    method = METHODS[int(rng.integers(0, 5))]
+    method = METHODS[int(rng.integers(0, len(METHODS)))]
     win = int(rng.choice([3, 5, 9, 15, 21, 31, 41, 63, 101])) if rng.random() < 0.9 else int(rng.integers(1, 60)) * 2 + 1
+    if rng.random() < a.wide:
+        win = int(rng.integers(20, 65)) * 2 + 1
     h = int(rng.integers(win + 2, 700)); w = int(rng.integers(win + 2, 1500))
     n = int(rng.choice([1, 1, 2, 3, 5, 8]))
     k = float(rng.choice([0.34, 0.2, -0.2, 0.01, -0.1, 0.5, 0.0])) if rng.random() < 0.8 else float(rng.normal(0, 0.4))
