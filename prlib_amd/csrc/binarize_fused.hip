@@ -41,7 +41,10 @@ constexpr int CPL = 8;                 // columns per lane
 constexpr int SW = kWave * CPL;        // padded columns per wavefront strip
 constexpr unsigned kRefBucketCap = 1u << 13;                      // entries per refine-queue bucket (a wavefront queues into bucket wid % kRefBuckets)
 constexpr unsigned kRefineCap = kRefBuckets * kRefBucketCap;      // pixels the float32 test may leave undecided per call (2^21)
-constexpr unsigned kWorkCap = 1u << 14;    // pixels the float64 interval test may leave undecided (more: literal page)
+constexpr unsigned kWorkCap = 1u << 17;    // pixels the float64 interval test may leave undecided (more: literal page); also Wolf-Jolion's candidates
+constexpr unsigned kPageMajorMin = 64;     // from this many queued pixels on, their corner sums are built page by page (k_corner_rows)
+constexpr int kPageMajorMaxW = 8160;       // ... for pages whose row prefixes fit 64 KB of LDS (two u32 per column)
+constexpr int kRowChunks = 64;             // workgroups per page of k_corner_rows
 constexpr size_t kSegmaxCap = 1u << 20;    // wavefronts per call whose sweep-A maxima can be kept (Wolf)
 
 struct RefItem {   // undecided after the float32 test: the window sums travel with the pixel
@@ -69,6 +72,7 @@ struct PageK {  // per-page constants of the float32 test
     float imin;  // Wolf: Z * cv::minMaxLoc(imageInput) minimum
     float p0;    // P2 = fma(p, Z, p0) = Z (p - 0.5) [Feng: minus Z (k2*Imin - Imin)]
     float eps1;  // Z * decision margin (Wolf: page dependent through k / devianceMax)
+    float eps1w; // the same for the float32 loop of a wide window (k_fused MODE 2)
 };
 
 struct FusedParams {
@@ -103,6 +107,11 @@ struct FusedParams {
     // Epilogue of the call (small batches: a launch costs ~4 us, which is what the flag copy and the next call's
     // k_init_globals cost each): the last workgroup of the last kernel (k_corner_partial<true>) writes the per-page flags
     // straight into the caller's pinned slot and leaves globals and counters in their initial state.  ep_host == null: off.
+    int flt_w;         // threshold sweep with a wide window (30 < w - 1 <= 128) on the float32 loop (LO == 4 form), with the per-
+                       // wavefront switch to the integer loop where a window's variance falls below vthr32_w
+    float vthr32_w;    // ... its floor on K~ (on Q~ for NICK) and its margin (the absolute rounding bound of the wide Q sums
+    float eps1_w;      //     enters through 1 / sqrt(variance): a floor of 4 keeps that term small, darker flats switch)
+    float ds_w;        //     Wolf-Jolion: the bound on |ds| itself (its factor |k / devianceMax| 255 is per page)
     int flt_a;         // Wolf sweep A runs the float32 loop for this (wide) window too: no decision there, only K~ (flt_a_usable)
     float kabs;        // ... whose K~ then carries an ABSOLUTE error bound (w^2 times the rounding of the wide Q sums), in K units
     double flt_dq;     // float32 pipeline: |Q~ - Q| <= flt_dq (absolute, flt_usable's delta) for the sums queued pixels carry
@@ -112,6 +121,7 @@ struct FusedParams {
     int ep_pages;
 };
 constexpr int kEpArrive = 60;  // counter word counting the workgroups of the last kernel that are done
+constexpr int kCntPageMajor = 5;   // counter word: number of pages k_corner_rows has to walk (0: k_corner_partial does the work)
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -378,8 +388,11 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                                            const FusedParams& fp, int page, int xs, int ys, int ye, int lane,
                                            const PageK& pk, unsigned wid, PageGlobals* __restrict__ g,
                                            RefItem* __restrict__ rl, WorkItem* __restrict__ cand,
-                                           unsigned* __restrict__ counters, bool last_ext = false)
+                                           unsigned* __restrict__ counters, bool last_ext = false,
+                                           bool resume = false, const float* vs0 = nullptr, const float* vq0 = nullptr)
 {
+    // resume: the float32 loop of a wide window handed this segment over at output row ys (strip_loop_f, SCAN): its column sums
+    // vs0 / vq0 (exact integers) replace the warm-up
     constexpr bool SWEEP = (METHOD == kWolfMax || METHOD == kWolfCollect);
     // WIDE: w - 1 > 181, S does not fit the mantissa trick (eval32)
     const ThrParams& tp = fp.tp;
@@ -426,15 +439,23 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     // warm-up: vertical sums over padded rows ys+1 .. ys+w-1
     // (8 rows in flight: a lone wavefront of a small batch waits for each fetch - 4 A4 pages, w=101: 0.090 -> 0.081 ms; 256
     // pages: -2..-3 %, profiles/r03/warm_unroll.txt)
-#pragma unroll 8
-    for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
-        const uint2 v = load_win(pr);
-        track_min(v);
+    if (resume) {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            const unsigned b = byte_of(v, c);
-            VS[c] += b;
-            VQ[c] += b * b;
+            VS[c] = (unsigned)vs0[c];
+            VQ[c] = (unsigned)vq0[c];
+        }
+    } else {
+#pragma unroll 8
+        for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
+            const uint2 v = load_win(pr);
+            track_min(v);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const unsigned b = byte_of(v, c);
+                VS[c] += b;
+                VQ[c] += b * b;
+            }
         }
     }
 
@@ -728,11 +749,14 @@ __device__ __forceinline__ float bpermf(int addr, float v)
 // come as packed bytes from a clamped address, are put in place by strip_loop's two v_perm_b32 and converted when the
 // slide uses them (16 conversions a row more than an interior strip, still a quarter fewer vector instructions than the
 // integer loop: 2 of the 9 strips of a 4096-column page, 2 of the 6 of an A4 page); partial stores at the row end.
+// Returns the output row at which the segment was handed over to the integer loop (ye: it was not).  LO == 4 threshold sweeps
+// only: when a window of the row has a variance below fp.vthr32_w the wavefront stops BEFORE deciding that row and leaves its
+// column sums in vs_out / vq_out (float, exact integers) - strip_loop takes it from there.
 template <int METHOD, int SH, int LO, bool FAST, bool EDGE>
-__device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, size_t ostep, const FusedParams& fp,
-                                             int page, int xs, int ys, int ye, int lane, const PageK& pk, unsigned wid,
-                                             PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
-                                             unsigned* __restrict__ counters)
+__device__ __forceinline__ int strip_loop_f(gcptr img, gptr out, size_t istep, size_t ostep, const FusedParams& fp,
+                                            int page, int xs, int ys, int ye, int lane, const PageK& pk, unsigned wid,
+                                            PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
+                                            unsigned* __restrict__ counters, float* vs_out = nullptr, float* vq_out = nullptr)
 {
     constexpr bool SWEEP_A = METHOD == kWolfMax;  // Wolf-Jolion's variance-maximum sweep: sums and K~ only, no decision
     const ThrParams& tp = fp.tp;
@@ -928,6 +952,19 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             vmin = fminf(vmin, v32);
         }
         unsigned lo = pack_signs(tn[0], tn[1], tn[2], tn[3]), hi = pack_signs(tn[4], tn[5], tn[6], tn[7]);
+        const float eps_row = SCAN ? pk.eps1w : pk.eps1, vth_row = SCAN ? fp.vthr32_w : fp.vthr32;
+        if constexpr (SCAN) {
+            // wide window: a variance this small makes the absolute rounding bound of Q~ matter (dark flats: scanner borders) -
+            // the rest of the segment runs the integer loop, this row first
+            if (__ballot(lane_has_out && !(vmin > vth_row)) != 0ull) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    vs_out[c] = VS[c];
+                    vq_out[c] = VQ[c];
+                }
+                return y;
+            }
+        }
 
         if (!FAST && fp.need_p0) {
             // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative); on the packed bytes
@@ -939,7 +976,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
         const F8 pv_cur = pv;
 
         // rare: some pixel of this lane is not settled by the float32 test -> queue it (k_refine rebuilds its sums)
-        const bool unsure = lane_has_out && !((tmin > pk.eps1) && (vmin > fp.vthr32));
+        const bool unsure = lane_has_out && !((tmin > eps_row) && (vmin > vth_row));
         if (__ballot(unsure) != 0ull) {
             if (unsure) {
                 unsigned qm = 0u;   // this lane's pixels to queue, one bit each
@@ -949,7 +986,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
                     if (pv_cur.v[c] == 0.0f) continue;  // 0 > T8 is false whatever T is
                     float v32;
                     const float t = eval32f<METHOD>(fp, Ssum[c], Qsum[c], fmaf(pv_cur.v[c], kZ, pk.p0), pk, &v32);
-                    if (!((fabsf(t) > pk.eps1) && (v32 > fp.vthr32))) qm |= 1u << c;
+                    if (!((fabsf(t) > eps_row) && (v32 > vth_row))) qm |= 1u << c;
                 }
                 // the sums travel with the pixel: S is exact, Q within fp.flt_dq of the exact sum - k_refine's interval test
                 // takes that uncertainty first and only rebuilds the sums of what it leaves open.  (One push site, values
@@ -1034,13 +1071,18 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             atomicMin(&g[page].imin, (int)pmin);
         }
     }
+    return ye;
 }
 
-template <int METHOD, int SH, bool WIDE>
+// MODE 0: windows up to 181 columns; 1: wider ones (S no longer fits the mantissa trick, eval32 WIDE); 2: threshold sweep with
+// 30 < w - 1 <= 128 on the float32 loop with the switch to the integer loop (fp.flt_w) - its own instantiation, because a kernel
+// is allocated the registers of its hungriest path and this one would cost every narrow-window sweep a wavefront of occupancy.
+template <int METHOD, int SH, int MODE>
 __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, FusedParams fp,
                                               PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
                                               WorkItem* __restrict__ cand, unsigned* __restrict__ counters)
 {
+    constexpr bool WIDE = MODE == 1;
     const ThrParams& tp = fp.tp;
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned wpb = blockDim.x >> 6;  // wavefronts per block
@@ -1086,6 +1128,7 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     pk.imin = 0.0f;
     pk.p0 = -0.5f * kZ;
     pk.eps1 = fp.eps1;
+    pk.eps1w = fp.eps1_w;
     if (METHOD == PRL_FENG) {
         const double imin = (double)g[page].imin;
         const double c3 = (tp.k2 * imin + (-imin)) + 0.0;  // binarizeFeng.cpp:137 with r2 = c2 = 1
@@ -1108,9 +1151,10 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
             pk.c1 = c * fl;
             // (|T_literal - T*| grows with |coeff| through the sqrt noise: es_max)
             pk.eps1 = fp.eps1 + kZ * (2.02f * 255.0f * ac * fp.es_max + 1.02f * 255.0f * fabsf((float)tp.k) * delta);
+            pk.eps1w = pk.eps1 + kZ * 2.02f * 255.0f * ac * fp.ds_w;
         } else {  // (no deviation to speak of on this page: nothing is settled here, k_refine / the literal pipeline decide)
             pk.c1 = 0.0f;
-            pk.eps1 = __builtin_inff();
+            pk.eps1 = pk.eps1w = __builtin_inff();
         }
     } else if (METHOD == kWolfCollect) {
         // a pixel can only carry the literal maximum if K~ >= (1-rho) (Kmax/(1+rho) - 2 Ev / f^2)
@@ -1128,6 +1172,17 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
         // sweep A with a wide window: the float32 loop in its doubling form (the extended last strip stays on the integer loop)
         if (!interior) strip_loop_f<METHOD, SH, 4, false, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
         else strip_loop_f<METHOD, SH, 4, false, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
+    } else if (MODE == 2 && !(fp.ext && strip == fp.n_strips - 1)) {
+        // threshold sweep with a wide window: the float32 loop in its doubling form until a window's variance falls below its floor
+        // (dark flats, where the absolute rounding bound of the wide Q sums would matter), the integer loop from that row on
+        float vs_h[CPL], vq_h[CPL];
+        int yr;
+        if (!interior) yr = strip_loop_f<METHOD, SH, 4, false, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters, vs_h, vq_h);
+        else yr = strip_loop_f<METHOD, SH, 4, false, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters, vs_h, vq_h);
+        if (yr < ye) {
+            if (interior) strip_loop<METHOD, SH, false, false>(img, out, src.step, dst.step, fp, page, xs, yr, ye, lane, pk, wid, g, rl, cand, counters, false, true, vs_h, vq_h);
+            else strip_loop<METHOD, SH, true, false>(img, out, src.step, dst.step, fp, page, xs, yr, ye, lane, pk, wid, g, rl, cand, counters, false, true, vs_h, vq_h);
+        }
     } else if (kFloatOk && !WIDE && fp.flt) {
         // (wave-uniform dispatch, once per wavefront: the row loop itself is branch-free in the usual configuration)
         const bool fast = !fp.bit_out && fp.nt_store && !fp.need_p0 && !(fp.uo & 7);
@@ -1313,7 +1368,8 @@ __global__ void __launch_bounds__(256) k_corner_partial(PageSet src, FusedParams
     // (Wolf-Jolion's candidates, which == 2: only when some pixel reached the literal fix-up - counters[1] - and then only
     // the candidates of the pages concerned; the rule is an immediate return)
     if (!FINAL && counters[1] == 0u) return;
-    const unsigned n = min(counters[which], fp.wl_cap);
+    const unsigned n_list = min(counters[which], fp.wl_cap);
+    const unsigned n = counters[kCntPageMajor] != 0u ? 0u : n_list;   // (non-zero: k_corner_rows has built the sums of this list page by page)
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
     const int W = tp.width, H = tp.height, h = tp.half;
     for (unsigned it = blockIdx.y; it < n; it += gridDim.y) {
@@ -1389,7 +1445,7 @@ __global__ void __launch_bounds__(256) k_corner_partial(PageSet src, FusedParams
             // workgroup (0, 0) can run the epilogue without waiting for anybody.  Otherwise the last one to finish runs it
             // (1024 arrivals on one word cost ~50 us: acceptable for the rare page that reaches the literal fix-up).
             __shared__ unsigned s_last;
-            if (n == 0) {
+            if (n_list == 0) {   // (not `n`: with a non-empty list the other workgroups still read the counters this epilogue resets)
                 if (threadIdx.x == 0) s_last = (blockIdx.x == 0 && blockIdx.y == 0) ? 1u : 0u;
             } else {
                 __threadfence();
@@ -1483,6 +1539,210 @@ __global__ void k_wolf_literal_coeff(FusedParams fp, PageGlobals* __restrict__ g
     pg.coeff = fp.tp.k / smax;   // double coeff = k / devianceMax  - binarizeWolfJolion.cpp:121 (IEEE division on the device)
 }
 
+// ---- corner sums, page by page (round 4) ---------------------------------------------------------------------------------
+// k_corner_partial rebuilds the absolute integral corners of ONE queued pixel from scratch: every page row above it is read
+// (up to the whole page, 8 MB on average for a 4K page).  Fine for the handful of pixels a call queues as a rule; but Feng's
+// threshold (1 + (1 - alpha1)) m + c3 meets p - 0.5 EXACTLY for about 5 pixels in 10^6 (rational coincidences of the integer
+// window sum: 21 153 pixels on 256 synthetic 4K pages, 2 508 on the real scans: 28 - 750 ms), and a Wolf-Jolion page that
+// needs its literal devianceMax has up to thousands of candidates.  From kPageMajorMin queued pixels on the work is organised
+// by PAGE instead: the pixels are grouped by page (k_group_items), and a workgroup walks a chunk of a page's rows ONCE - row
+// prefix sums of P and P^2 in LDS - while each of its threads owns one queued pixel of that page and adds the row's
+// contribution to its eight sums (the same multiplicity arithmetic as k_corner_partial, range sums as differences of two
+// prefix values).  One pass over a page serves all its pixels.
+struct GroupArrays {
+    unsigned* sidx;     // item indices grouped by page
+    unsigned* pstart;   // [n_pages + 1] first position of each page's items in sidx
+    unsigned* pcur;     // [n_pages] scatter cursors
+    unsigned* plist;    // pages that have items
+};
+
+// one workgroup of 1024 threads; `which`: 1 = the fix-up list, 2 = Wolf-Jolion's candidates (only those of pages with need_literal)
+__global__ void __launch_bounds__(1024) k_group_items(const WorkItem* __restrict__ items, unsigned* __restrict__ counters, int which,
+                                                      const PageGlobals* __restrict__ g, int n_pages, int width, unsigned cap, GroupArrays ga)
+{
+    __shared__ unsigned s_cnt[1024], s_nz[1024];
+    const unsigned t = threadIdx.x;
+    const unsigned n = min(counters[which], cap);
+    const bool lazy = which == 2;
+    if ((lazy && counters[1] == 0u) || n < kPageMajorMin || width > kPageMajorMaxW) {   // (uniform)
+        if (t == 0) counters[kCntPageMajor] = 0u;
+        return;
+    }
+    for (unsigned p = t; p < (unsigned)n_pages; p += 1024u) ga.pcur[p] = 0u;
+    __syncthreads();
+    for (unsigned i = t; i < n; i += 1024u) {
+        const int page = items[i].page;
+        if (lazy && !g[page].need_literal) continue;
+        atomicAdd(&ga.pcur[page], 1u);
+    }
+    __threadfence();
+    __syncthreads();
+    // exclusive prefix over the pages (each thread a contiguous run of pages) + compaction of the pages that have items
+    const unsigned run = ((unsigned)n_pages + 1023u) / 1024u, p0 = t * run, p1 = min(p0 + run, (unsigned)n_pages);
+    unsigned c = 0, z = 0;
+    for (unsigned p = p0; p < p1; ++p) {
+        const unsigned k = atomicAdd(&ga.pcur[p], 0u);
+        c += k;
+        z += k != 0u;
+    }
+    s_cnt[t] = c;
+    s_nz[t] = z;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024u; d <<= 1) {
+        const unsigned a = t >= d ? s_cnt[t - d] : 0u, b = t >= d ? s_nz[t - d] : 0u;
+        __syncthreads();
+        s_cnt[t] += a;
+        s_nz[t] += b;
+        __syncthreads();
+    }
+    unsigned pos = s_cnt[t] - c, zi = s_nz[t] - z;
+    for (unsigned p = p0; p < p1; ++p) {
+        const unsigned k = atomicAdd(&ga.pcur[p], 0u);
+        ga.pstart[p] = pos;
+        if (k) ga.plist[zi++] = p;
+        pos += k;
+    }
+    if (t == 1023u) {
+        ga.pstart[n_pages] = s_cnt[1023];
+        counters[kCntPageMajor] = s_nz[1023];
+    }
+    __threadfence();
+    __syncthreads();
+    for (unsigned p = p0; p < p1; ++p) ga.pcur[p] = ga.pstart[p];   // scatter cursors
+    __threadfence();
+    __syncthreads();
+    for (unsigned i = t; i < n; i += 1024u) {
+        const int page = items[i].page;
+        if (lazy && !g[page].need_literal) continue;
+        ga.sidx[atomicAdd(&ga.pcur[page], 1u)] = i;
+    }
+}
+
+// grid (kRowChunks, page slots); 256 threads.  Thread t of a workgroup owns the t-th queued pixel of the page (256 at a time).
+template <bool FINAL>
+__global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp, const WorkItem* __restrict__ items, GroupArrays ga,
+                                                    const unsigned* __restrict__ counters, CornerAcc* __restrict__ acc, PageSetOut dst,
+                                                    const PageGlobals* __restrict__ g, unsigned* __restrict__ done)
+{
+    extern __shared__ unsigned s_prefix[];   // [W] inclusive row prefix of P, [W] of P*P
+    __shared__ unsigned s_ws[4], s_wq[4];
+    const ThrParams& tp = fp.tp;
+    const unsigned n_slots = counters[kCntPageMajor];
+    if (n_slots == 0u) return;
+    const int W = tp.width, H = tp.height, h = tp.half;
+    unsigned* ps = s_prefix;
+    unsigned* pq = s_prefix + W;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    // this thread's columns of a row: 32 each (the whole-segment fast path) whenever 256 x 32 covers the row
+    const int seg = W <= 8192 ? 32 : (W + 255) / 256, c0 = min(t * seg, W), c1 = min(c0 + seg, W);
+    const int per = (H + kRowChunks - 1) / kRowChunks;
+    const int r_begin = blockIdx.x * per, r_stop = min(r_begin + per, H);
+    for (unsigned slot = blockIdx.y; slot < n_slots; slot += gridDim.y) {
+        const int page = (int)ga.plist[slot];
+        const uint8_t* img = src.page(page);
+        const unsigned i0 = ga.pstart[page], i1 = ga.pstart[page + 1];
+        for (unsigned g0 = i0; g0 < i1; g0 += 256u) {
+            const bool has = g0 + (unsigned)t < i1;
+            const unsigned idx = has ? ga.sidx[g0 + t] : 0u;
+            const WorkItem wi = items[idx];
+            // constants of this thread's pixel (k_corner_partial's arithmetic)
+            const int Y0 = wi.y, X0 = wi.x, Y1 = wi.y + tp.w - 1, X1 = wi.x + tp.w - 1;
+            const int r_last = clampi(Y1 - h, 0, H - 1);
+            const int lcb = clampi(X0 - h, 0, W - 1);
+            const int rca = clampi(X0 + 1 - h, 0, W - 1), rcb = clampi(X1 - h, 0, W - 1);
+            const int l_m0 = pad_count(0, X0, 0, W, h), l_mW = pad_count(0, X0, W - 1, W, h);
+            const int r_m0 = pad_count(X0 + 1, X1, 0, W, h), r_mW = pad_count(X0 + 1, X1, W - 1, W, h);
+            unsigned long long a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            // rows this workgroup has to walk for this group: none beyond the largest r_last (wave / block uniform via LDS-free max)
+            for (int r = r_begin; r < r_stop; ++r) {
+                const uint8_t* row = img + (size_t)r * src.step;
+                // inclusive prefix of the row in LDS: every thread sums its columns (up to 32: two 16-byte loads when it has all
+                // of them - byte loads made this kernel 3x slower), block scan of the totals, second pass writes
+                unsigned s = 0, q = 0;
+                unsigned d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const bool whole = c1 - c0 == 32;
+                if (whole) {
+                    uint4 v0, v1;
+                    __builtin_memcpy(&v0, row + c0, 16);
+                    __builtin_memcpy(&v1, row + c0 + 16, 16);
+                    d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        s = __builtin_amdgcn_udot4(d[k], 0x01010101u, s, false);
+                        q = __builtin_amdgcn_udot4(d[k], d[k], q, false);
+                    }
+                } else {
+                    for (int c = c0; c < c1; ++c) {
+                        const unsigned b = row[c];
+                        s += b;
+                        q += b * b;
+                    }
+                }
+                const unsigned si = wave_scan_incl(s), qi = wave_scan_incl(q);
+                if (lane == 63) { s_ws[wv] = si; s_wq[wv] = qi; }
+                __syncthreads();
+                unsigned so = si - s, qo = qi - q;
+                for (int k = 0; k < wv; ++k) { so += s_ws[k]; qo += s_wq[k]; }
+                if (whole) {
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) {
+                        const unsigned b = (d[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                        so += b;
+                        qo += b * b;
+                        ps[c0 + k] = so;
+                        pq[c0 + k] = qo;
+                    }
+                } else {
+                    for (int c = c0; c < c1; ++c) {
+                        const unsigned b = row[c];
+                        so += b;
+                        qo += b * b;
+                        ps[c] = so;
+                        pq[c] = qo;
+                    }
+                }
+                __syncthreads();
+                if (has && r <= r_last) {
+                    const unsigned e0 = ps[0], eW = ps[W - 1] - (W > 1 ? ps[W - 2] : 0u);
+                    const unsigned e0q = e0 * e0, eWq = eW * eW;
+                    unsigned sl = ps[lcb], ql = pq[lcb];                                             // columns 0 .. lcb
+                    unsigned sr = ps[rcb] - (rca > 0 ? ps[rca - 1] : 0u), qr = pq[rcb] - (rca > 0 ? pq[rca - 1] : 0u);
+                    if (l_m0 > 0) { sl += (unsigned)(l_m0 - 1) * e0; ql += (unsigned)(l_m0 - 1) * e0q; }
+                    if (l_mW > 0 && lcb == W - 1) { sl += (unsigned)(l_mW - 1) * eW; ql += (unsigned)(l_mW - 1) * eWq; }
+                    if (r_m0 > 0 && rca == 0) { sr += (unsigned)(r_m0 - 1) * e0; qr += (unsigned)(r_m0 - 1) * e0q; }
+                    if (r_mW > 0) { sr += (unsigned)(r_mW - 1) * eW; qr += (unsigned)(r_mW - 1) * eWq; }
+                    const unsigned long long ct = (unsigned long long)pad_count(0, Y0, r, H, h);
+                    const unsigned long long cb2 = (unsigned long long)pad_count(Y0 + 1, Y1, r, H, h);
+                    a[0] += ct * sl;  a[1] += ct * sr;  a[2] += cb2 * sl;  a[3] += cb2 * sr;
+                    a[4] += ct * ql;  a[5] += ct * qr;  a[6] += cb2 * ql;  a[7] += cb2 * qr;
+                }
+                __syncthreads();
+            }
+            if (has) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (a[k] != 0ull) atomicAdd(&acc[idx].a[k], a[k]);
+                if constexpr (FINAL) {
+                    __threadfence();   // this workgroup's sums are visible before its arrival is
+                    if (atomicAdd(&done[idx], 1u) == gridDim.x - 1) {   // the last of the page's row chunks: the literal evaluation
+                        __threadfence();
+                        CornerAcc c;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) c.a[k] = atomicAdd(&acc[idx].a[k], 0ull);
+                        double m, q2;
+                        literal_mq(c, tp.f, &m, &q2);
+                        const double sdev = dev_from(m, q2);
+                        const PageGlobals& pg = g[wi.page];
+                        const double T = threshold_literal(tp, m, sdev, (double)pg.imin, pg.coeff);
+                        const unsigned p = img[(size_t)wi.y * src.step + wi.x];
+                        store_decision(dst, fp.bit_out, wi.page, wi.y, wi.x, decide_literal(p, T));
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Page minimum of the part of the page no sweep-A wavefront fetches: the sweeps stop h rows above the bottom and may
 // stop short of the right border, so the last `band` rows and columns are reduced here (band = w is generous).
 __global__ void __launch_bounds__(256) k_page_min_border(PageSet src, int width, int height, int band, PageGlobals* g)
@@ -1531,12 +1791,15 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     const unsigned blocks = 8u * ((fp.xcd_waves + wpb - 1) / wpb);   // each XCD: its share of every tier
     const dim3 grid(blocks), block(64 * wpb);
     const bool wide = fp.tp.w - 1 > 181;  // S no longer fits the mantissa of 2^23 (eval32)
+    constexpr bool kHasMode2 = METHOD >= 0 && METHOD <= PRL_FENG;
 #define PRL_LAUNCH_FUSED(SHV)                                                                                    \
     do {                                                                                                         \
         if (wide)                                                                                                \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, true>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);    \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, 1>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);    \
+        else if (kHasMode2 && fp.flt_w)                                                                          \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, kHasMode2 ? 2 : 0>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);   \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, false>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);   \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, 0>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);   \
     } while (0)
     switch (sh) {
     case 0: PRL_LAUNCH_FUSED(0); break;
@@ -1553,8 +1816,8 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
 template <int METHOD>
 int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
                  PageGlobals* g, RefItem* rl, WorkItem* wl, WorkItem* cand, CornerAcc* acc, unsigned* cnt,
-                 hipEvent_t ev_start, hipEvent_t ev_stop, bool with_fixup, hipEvent_t before_refine = nullptr,
-                 CornerAcc* cacc = nullptr, int n_pages = 0)
+                 hipEvent_t ev_start, hipEvent_t ev_stop, bool with_fixup, int n_pages, const GroupArrays& ga,
+                 hipEvent_t before_refine = nullptr, CornerAcc* cacc = nullptr)
 {
     if (ev_start) PRL_HIP_CHECK(hipEventRecord(ev_start, stream));
     int st = launch_sweep<METHOD>(sh, stream, src, dst, fp, g, rl, cand, cnt);
@@ -1567,8 +1830,18 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     const unsigned refine_blocks = fp.flt ? (fp.total_waves > 20000u ? 1024u : 256u) : 64u;
     hipLaunchKernelGGL((k_refine<METHOD>), dim3(refine_blocks), dim3(256), 0, stream, src, dst, fp, g, rl, wl, cnt, acc, done);
     PRL_HIP_CHECK(hipGetLastError());
+    // From kPageMajorMin queued pixels on the corner sums are built page by page (k_group_items + k_corner_rows, which return at
+    // once otherwise); calls of a few pages skip the two launches (a near-empty launch costs ~5 us, a single-page call 33).
+    const bool page_major = n_pages >= 8;
+    const size_t rows_lds = (size_t)std::min(fp.tp.width, kPageMajorMaxW) * 2 * sizeof(unsigned);
+    const dim3 rows_grid(kRowChunks, (unsigned)std::min(n_pages, 512));
     if (METHOD == PRL_WOLFJOLION) {
-        // the literal devianceMax of the pages whose pixels reached the fix-up list (none, as a rule: three immediate returns)
+        // the literal devianceMax of the pages whose pixels reached the fix-up list (none, as a rule: immediate returns)
+        if (page_major) {
+            hipLaunchKernelGGL(k_group_items, dim3(1), dim3(1024), 0, stream, cand, cnt, 2, g, n_pages, fp.tp.width, fp.wl_cap, ga);
+            hipLaunchKernelGGL(k_corner_rows<false>, rows_grid, dim3(256), rows_lds, stream, src, fp, cand, ga, cnt, cacc, dst, g,
+                               static_cast<unsigned*>(nullptr));
+        }
         hipLaunchKernelGGL(k_corner_partial<false>, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, cand, cnt, 2, cacc, dst, g,
                            static_cast<unsigned*>(nullptr));
         hipLaunchKernelGGL(k_wolf_final, dim3(16), dim3(256), 0, stream, fp, g, cand, cacc, cnt);
@@ -1579,6 +1852,10 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     // literal fix-up of what k_refine queued: the kernel reads the queue length on the device and does nothing when it is
     // empty (the usual case), so no host round trip decides whether it runs; k_refine zeroed the accumulators it uses; the
     // workgroup that delivers a pixel's last partial sum evaluates the pixel (no separate k_fixup_final launch)
+    if (page_major) {
+        hipLaunchKernelGGL(k_group_items, dim3(1), dim3(1024), 0, stream, wl, cnt, 1, g, n_pages, fp.tp.width, fp.wl_cap, ga);
+        hipLaunchKernelGGL(k_corner_rows<true>, rows_grid, dim3(256), rows_lds, stream, src, fp, wl, ga, cnt, acc, dst, g, done);
+    }
     hipLaunchKernelGGL(k_corner_partial<true>, dim3(kSplit, 16), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc, dst, g, done);  // (1024 workgroups: an empty queue is the rule, and its launch should cost little)
     PRL_HIP_CHECK(hipGetLastError());
     return PRL_OK;
@@ -1762,13 +2039,14 @@ extern "C" int prl_hip_internal_flt_q_error(int w, double* delta_qmin_cq)
     return flt_usable(tp, 1, &delta_qmin_cq[2], &delta_qmin_cq[0], &delta_qmin_cq[1]) ? 1 : 0;
 }
 
-size_t fused_small_bytes(int)
+size_t fused_small_bytes(int n_pages)
 {
     // [counters][refine list: kRefBuckets x kRefBucketCap][fix-up list][Wolf candidate list][corner sums][Wolf per-wavefront maxima][arrival counters]
     // [... arrival counters][corner sums of Wolf-Jolion's candidates]
+    // [... corner sums of Wolf-Jolion's candidates][k_group_items: item indices by page, page starts / cursors / list]
     return kFusedCounterBytes + sizeof(RefItem) * (size_t)kRefineCap + 2 * sizeof(WorkItem) * (size_t)kWorkCap +
            sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(float) * kSegmaxCap + sizeof(unsigned) * (size_t)kWorkCap +
-           sizeof(CornerAcc) * (size_t)kWorkCap;
+           sizeof(CornerAcc) * (size_t)kWorkCap + sizeof(unsigned) * ((size_t)kWorkCap + 3 * (size_t)std::max(n_pages, 1) + 4);
 }
 
 // Strips of a row: uo output columns each, fetched with w - 1 halo columns; uo = 512 - (w - 1) rounded down to a multiple of 8,
@@ -1964,6 +2242,31 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.rho = (float)(std::fmax(b1.rho, b.rho) * 1.01);  // sweep A runs the float32 pipeline on interior strips, sweep B the integer one
     fp.ev2 = (float)(2.0 * b1.Ev * 1.01 / (f * f));  // in K units
     {
+        // Threshold sweep with a wide window on the float32 loop (flt_w).  S is exact there, |Q~ - Q| <= dq (flt_a_usable), i.e. the
+        // variance f^2 K~ is off by at most dv = dq / w^2 beside the relative part every pipeline has; through s = sqrt(v) that is
+        // |ds| <= dv / (2 sqrt(v - dv)), bounded by a page-independent constant once v has a floor: vthr_f = 4 (a flat region of
+        // gray level p has v = p^2 r (1 - r), r = ((w-1)/w)^2: only flats darker than ~15 fall below it - the wavefront that
+        // meets one switches to the integer loop).  The term enters E1 with the factor of s in T: M |a| (Sauvola), |k| (Niblack);
+        // NICK's sqrt(q) has its own floor (1 + R) vthr_f on q; Feng's T does not depend on s.
+        double dqw = 0.0;
+        const bool wide_ok = !fp.flt && env_knobs().flt_wide && flt_a_usable(tp, src.step, &dqw);
+        fp.flt_w = 0;
+        if (wide_ok) {
+            const double vthr_f = 4.0, dv = dqw * 1.01 / (double)(tp.w * tp.w);
+            const double n1 = tp.w - 1.0, R = n1 * n1 / (2.0 * tp.w - 1.0), u24 = std::ldexp(1.0, -24);
+            double extra = 0.0;   // additional float32 evaluation error of T
+            if (tp.method == PRL_SAUVOLA) extra = 255.0 * std::fabs(tp.a) * dv / (2.0 * std::sqrt(vthr_f - 2.0 * dv));
+            else if (tp.method == PRL_NIBLACK) extra = std::fabs(tp.k) * dv / (2.0 * std::sqrt(vthr_f - 2.0 * dv));
+            else if (tp.method == PRL_NICK) extra = std::fabs(tp.k) * (dqw * 1.01 * f) / (2.0 * std::sqrt((1.0 + R) * vthr_f - 2.0 * dqw * f));
+            const double eps_w = 2.0 * (b1.E1 + 1.01 * extra + b1.Elit) + 1e-6;
+            fp.flt_w = 1;
+            fp.eps1_w = (float)(eps_w * 1.01 * Z);
+            fp.ds_w = (float)(1.01 * dv / (2.0 * std::sqrt(vthr_f - 2.0 * dv)));   // (Wolf-Jolion: times |k / devianceMax| 255, per page)
+            // the floor is tested on K~ (Q~ for NICK), which may exceed the exact value by its error: raise it by that much
+            if (tp.method == PRL_NICK) fp.vthr32_w = (float)(((1.0 + R) * vthr_f / f + dqw) * (1.0 + 4.0 * u24 + 1e-5));
+            else fp.vthr32_w = (float)((vthr_f / (f * f) + (double)(tp.w * tp.w) * dqw) * (1.0 + 2.0 * b1.rho + 1e-5));
+            fp.flt_dq = dqw;   // queued pixels carry Q~ (k_refine's interval test takes the bound as uncertainty of q)
+        }
         double dqa = 0.0;
         fp.flt_a = (tp.method == PRL_WOLFJOLION && !fp.flt && flt_a_usable(tp, src.step, &dqa)) ? 1 : 0;
         // |K~ - K| <= w^2 |Q~ - Q| (+ the relative part, rho: S^2 and the fma round as in the integer pipeline's conversion)
@@ -1984,6 +2287,11 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     auto* acc = reinterpret_cast<CornerAcc*>(cand + kWorkCap);
     fp.segmax = reinterpret_cast<float*>(acc + kWorkCap);
     auto* cacc = reinterpret_cast<CornerAcc*>(reinterpret_cast<unsigned*>(fp.segmax + kSegmaxCap) + kWorkCap);   // (behind the arrival counters)
+    GroupArrays ga;
+    ga.sidx = reinterpret_cast<unsigned*>(cacc + kWorkCap);
+    ga.pstart = ga.sidx + kWorkCap;
+    ga.pcur = ga.pstart + n_pages + 1;
+    ga.plist = ga.pcur + n_pages;
     if (phase == 2) {  // (kept for callers that split the pipeline; k_refine of phase 1 zeroed what this uses)
         unsigned* done = reinterpret_cast<unsigned*>(fp.segmax + kSegmaxCap);
         hipLaunchKernelGGL(k_corner_partial<true>, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc, dst, d_globals, done);
@@ -2062,14 +2370,14 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
             PRL_HIP_CHECK(hipStreamWaitEvent(stream, wolf_side->ev_min, 0));   // the threshold sweep needs the whole page minimum
             before_refine = wolf_side->ev_coeff;
         }
-        return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, before_refine,
-                                            cacc, n_pages);
+        return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, n_pages, ga,
+                                            before_refine, cacc);
     }
     switch (tp.method) {
-    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);
-    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);
-    case PRL_NICK: return launch_fused<PRL_NICK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);
-    case PRL_FENG: return launch_fused<PRL_FENG>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup);
+    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, n_pages, ga);
+    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, n_pages, ga);
+    case PRL_NICK: return launch_fused<PRL_NICK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, n_pages, ga);
+    case PRL_FENG: return launch_fused<PRL_FENG>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, n_pages, ga);
     default: return PRL_ERR_BAD_ARG;
     }
 }

@@ -289,10 +289,94 @@ def test_wolf_literal_maximum_is_computed_when_a_pixel_needs_it(prl, oracle, cud
     for morph in (0, 2):
         st = _check(prl, oracle, cuda_device, [others[0], page, others[1]], WOLFJOLION, w, k, morph)
         assert st.exact_pixels >= 24 * 24 // 2 and st.literal_pages == 0
-    # the same with so many such pixels that the fix-up list overflows: that page (only) goes through the literal pipeline
-    big, kb, _ = _wolf_boundary_page_and_k(oracle, w, c, flat=160, seed=63, shape=(420, 520))
+    # the same with so many such pixels that the fix-up list (2^17 entries) overflows: that page (only) goes through the literal pipeline
+    big, kb, _ = _wolf_boundary_page_and_k(oracle, w, c, flat=400, seed=63, shape=(520, 900))
     st = _check(prl, oracle, cuda_device, [big, _pages(big.shape, ["doc"], seed=64)[0]], WOLFJOLION, w, kb, 0)
     assert st.literal_pages == 1
+
+
+def test_many_undecidable_pixels_take_the_page_major_corner_sums(prl, oracle, cuda_device):
+    """From 64 queued pixels on (calls of 8 pages or more) the absolute corner sums are built page by page: k_group_items +
+    k_corner_rows instead of one pass over the page per pixel.  Flat regions on the tie (every pixel undecidable) that touch all
+    four page borders and corners - the replicate padding's multiplicities - among ordinary pages; a whole flat page."""
+    w, c = 15, 200
+    k = _flat_boundary_k(c, w, c)
+    docs = _pages((230, 310), ["doc"] * 9, seed=71)
+    docs[1][:70, :90] = c            # top-left corner
+    docs[1][-60:, -80:] = c          # bottom-right corner
+    docs[3][:50, -100:] = c          # top-right
+    docs[3][-55:, :75] = c           # bottom-left
+    docs[3][100:140, 120:200] = c    # interior
+    docs[6][:, :] = c                # everything (71 000 pixels, all of them through the literal evaluation)
+    for morph in (0, 2):
+        st = _check(prl, oracle, cuda_device, docs, SAUVOLA, w, k, morph)
+        assert st.exact_pixels > 60000 and st.literal_pages == 0
+    # the brute-force kernel on the same pixels (calls below 8 pages): same masks
+    st = _check(prl, oracle, cuda_device, [docs[1], docs[3]], SAUVOLA, w, k, 0)
+    assert st.exact_pixels > 5000 and st.literal_pages == 0
+
+
+@pytest.mark.parametrize("method,k", [(SAUVOLA, 0.01), (SAUVOLA, 0.34), (NIBLACK, 0.01), (NIBLACK, -0.2), (NICK, -0.01), (FENG, 0.0)])
+@pytest.mark.parametrize("win", [41, 63, 101, 129])
+def test_wide_window_float_loop_and_its_switch_on_dark_flats(prl, oracle, cuda_device, method, k, win):
+    """Windows of 33..129 columns run the threshold sweep on the float32 loop (doubling form of the lane sums) until a window's
+    variance falls below the floor where the absolute rounding bound of the wide Q sums would matter - dark flat regions, scanner
+    borders - and the integer loop from that row on.  Pages wide enough for interior strips with dark flats (gray 0, 1, 3, 9),
+    dark noise, a dark band across a strip boundary and a bright page; both loops must agree with the oracle bit for bit."""
+    rng = np.random.default_rng(win * 7 + method)
+    h, wd = 420, 1400
+    pages = _pages((h, wd), ["doc", "doc", "doc", "noise"], seed=90 + win)
+    pages[0][150:300, 200:900] = 0                                            # black block
+    pages[0][20:120, 950:1350] = 3                                            # dark flat
+    pages[1][:, 380:470] = rng.integers(1, 10, (h, 90), dtype=np.uint8)       # dark noise band over the first strip boundary
+    pages[1][300:, :] = 1                                                     # darkest non-black flat at the bottom
+    pages[2][:60, :] = 9
+    pages[2][200:260, 600:1000] = rng.integers(0, 3, (60, 400), dtype=np.uint8)
+    for morph in (0, 2):
+        st = _check(prl, oracle, cuda_device, pages, method, win, k, morph)
+        assert st.literal_pages == 0
+
+
+def test_feng_rational_ties_stay_on_the_fast_path(prl, oracle, cuda_device):
+    """Feng at the header defaults: (1 + (1 - alpha1)) m + c3 = 1.25 S / w^2 meets p - 0.5 EXACTLY for ~5 pixels in 10^6, which
+    only the literal evaluation decides.  256 x 4K pages have 21 000 of them: round 3's fix-up list (2^14) overflowed and every page
+    went through the literal pipeline (753 ms a step); now the list holds them and the page-major kernel builds their sums."""
+    import torch
+
+    from prlib_amd import synth
+
+    pages = synth.pages_torch(24, 1536, 1536, cuda_device, seed=4000)
+    p = prl.default_params(FENG)
+    got = prl.binarize(pages, p).cpu().numpy()
+    st = prl.last_stats()
+    assert st.literal_pages == 0 and st.exact_pixels >= 64
+    host = pages.cpu().numpy()
+    po = oracle.make_params(FENG)
+    for i in (0, 7, 23):
+        assert np.array_equal(got[i], oracle.binarize(host[i].copy(), po))
+
+
+def test_wolf_literal_maximum_with_many_candidates_page_major(prl, oracle, cuda_device):
+    """A page tiled from a small block attains its deviation maximum at every repetition: > 64 candidates, so the lazily computed
+    literal devianceMax takes the page-major kernel too (and the tie pixels of the flat patch the page-major fix-up)."""
+    w, c = 15, 120
+    rng = np.random.default_rng(81)
+    block = rng.integers(0, 256, (32, 32), dtype=np.uint8)
+    page = np.tile(block, (12, 16))[:380, :500].copy()
+    page[:20, :] = 127
+    page[-20:, :] = 127       # a bland frame: the windows on the replicated borders must not win
+    page[:, :20] = 127
+    page[:, -20:] = 127
+    page[40:40 + 40 + w, 260:260 + 40 + w] = c
+    page[0, 0] = 0
+    m, s = oracle.mean_dev(page, oracle.make_params(WOLFJOLION, w, 0.3, 0))
+    assert (s >= np.nanmax(s) * (1 - 1e-9)).sum() >= 100
+    yy, xx = 40 + w // 2 + 2, 260 + w // 2 + 2
+    k = (c - 0.5 - m[yy, xx]) / ((s[yy, xx] / np.nanmax(s) - 1.0) * m[yy, xx])
+    pages = _pages(page.shape, ["doc"] * 8, seed=82)
+    pages[5] = page
+    st = _check(prl, oracle, cuda_device, pages, WOLFJOLION, w, k, 0)
+    assert st.exact_pixels >= 800 and st.wolf_candidates >= 64 and st.literal_pages == 0
 
 
 def test_back_to_back_calls_reuse_the_self_cleaned_state(prl, oracle, cuda_device):
