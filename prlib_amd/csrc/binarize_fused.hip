@@ -72,7 +72,6 @@ struct PageK {  // per-page constants of the float32 test
     float imin;  // Wolf: Z * cv::minMaxLoc(imageInput) minimum
     float p0;    // P2 = fma(p, Z, p0) = Z (p - 0.5) [Feng: minus Z (k2*Imin - Imin)]
     float eps1;  // Z * decision margin (Wolf: page dependent through k / devianceMax)
-    float eps1w; // the same for the float32 loop of a wide window (k_fused MODE 2)
 };
 
 struct FusedParams {
@@ -107,11 +106,6 @@ struct FusedParams {
     // Epilogue of the call (small batches: a launch costs ~4 us, which is what the flag copy and the next call's
     // k_init_globals cost each): the last workgroup of the last kernel (k_corner_partial<true>) writes the per-page flags
     // straight into the caller's pinned slot and leaves globals and counters in their initial state.  ep_host == null: off.
-    int flt_w;         // threshold sweep with a wide window (30 < w - 1 <= 128) on the float32 loop (LO == 4 form), with the per-
-                       // wavefront switch to the integer loop where a window's variance falls below vthr32_w
-    float vthr32_w;    // ... its floor on K~ (on Q~ for NICK) and its margin (the absolute rounding bound of the wide Q sums
-    float eps1_w;      //     enters through 1 / sqrt(variance): a floor of 4 keeps that term small, darker flats switch)
-    float ds_w;        //     Wolf-Jolion: the bound on |ds| itself (its factor |k / devianceMax| 255 is per page)
     int flt_a;         // Wolf sweep A runs the float32 loop for this (wide) window too: no decision there, only K~ (flt_a_usable)
     float kabs;        // ... whose K~ then carries an ABSOLUTE error bound (w^2 times the rounding of the wide Q sums), in K units
     double flt_dq;     // float32 pipeline: |Q~ - Q| <= flt_dq (absolute, flt_usable's delta) for the sums queued pixels carry
@@ -388,11 +382,8 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                                            const FusedParams& fp, int page, int xs, int ys, int ye, int lane,
                                            const PageK& pk, unsigned wid, PageGlobals* __restrict__ g,
                                            RefItem* __restrict__ rl, WorkItem* __restrict__ cand,
-                                           unsigned* __restrict__ counters, bool last_ext = false,
-                                           bool resume = false, const float* vs0 = nullptr, const float* vq0 = nullptr)
+                                           unsigned* __restrict__ counters, bool last_ext = false)
 {
-    // resume: the float32 loop of a wide window handed this segment over at output row ys (strip_loop_f, SCAN): its column sums
-    // vs0 / vq0 (exact integers) replace the warm-up
     constexpr bool SWEEP = (METHOD == kWolfMax || METHOD == kWolfCollect);
     // WIDE: w - 1 > 181, S does not fit the mantissa trick (eval32)
     const ThrParams& tp = fp.tp;
@@ -439,23 +430,15 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     // warm-up: vertical sums over padded rows ys+1 .. ys+w-1
     // (8 rows in flight: a lone wavefront of a small batch waits for each fetch - 4 A4 pages, w=101: 0.090 -> 0.081 ms; 256
     // pages: -2..-3 %, profiles/r03/warm_unroll.txt)
-    if (resume) {
+#pragma unroll 8
+    for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
+        const uint2 v = load_win(pr);
+        track_min(v);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            VS[c] = (unsigned)vs0[c];
-            VQ[c] = (unsigned)vq0[c];
-        }
-    } else {
-#pragma unroll 8
-        for (int pr = ys + 1; pr <= ys + w - 1; ++pr) {
-            const uint2 v = load_win(pr);
-            track_min(v);
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const unsigned b = byte_of(v, c);
-                VS[c] += b;
-                VQ[c] += b * b;
-            }
+            const unsigned b = byte_of(v, c);
+            VS[c] += b;
+            VQ[c] += b * b;
         }
     }
 
@@ -749,14 +732,11 @@ __device__ __forceinline__ float bpermf(int addr, float v)
 // come as packed bytes from a clamped address, are put in place by strip_loop's two v_perm_b32 and converted when the
 // slide uses them (16 conversions a row more than an interior strip, still a quarter fewer vector instructions than the
 // integer loop: 2 of the 9 strips of a 4096-column page, 2 of the 6 of an A4 page); partial stores at the row end.
-// Returns the output row at which the segment was handed over to the integer loop (ye: it was not).  LO == 4 threshold sweeps
-// only: when a window of the row has a variance below fp.vthr32_w the wavefront stops BEFORE deciding that row and leaves its
-// column sums in vs_out / vq_out (float, exact integers) - strip_loop takes it from there.
 template <int METHOD, int SH, int LO, bool FAST, bool EDGE>
-__device__ __forceinline__ int strip_loop_f(gcptr img, gptr out, size_t istep, size_t ostep, const FusedParams& fp,
-                                            int page, int xs, int ys, int ye, int lane, const PageK& pk, unsigned wid,
-                                            PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
-                                            unsigned* __restrict__ counters, float* vs_out = nullptr, float* vq_out = nullptr)
+__device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, size_t ostep, const FusedParams& fp,
+                                             int page, int xs, int ys, int ye, int lane, const PageK& pk, unsigned wid,
+                                             PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
+                                             unsigned* __restrict__ counters)
 {
     constexpr bool SWEEP_A = METHOD == kWolfMax;  // Wolf-Jolion's variance-maximum sweep: sums and K~ only, no decision
     const ThrParams& tp = fp.tp;
@@ -952,19 +932,6 @@ __device__ __forceinline__ int strip_loop_f(gcptr img, gptr out, size_t istep, s
             vmin = fminf(vmin, v32);
         }
         unsigned lo = pack_signs(tn[0], tn[1], tn[2], tn[3]), hi = pack_signs(tn[4], tn[5], tn[6], tn[7]);
-        const float eps_row = SCAN ? pk.eps1w : pk.eps1, vth_row = SCAN ? fp.vthr32_w : fp.vthr32;
-        if constexpr (SCAN) {
-            // wide window: a variance this small makes the absolute rounding bound of Q~ matter (dark flats: scanner borders) -
-            // the rest of the segment runs the integer loop, this row first
-            if (__ballot(lane_has_out && !(vmin > vth_row)) != 0ull) {
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    vs_out[c] = VS[c];
-                    vq_out[c] = VQ[c];
-                }
-                return y;
-            }
-        }
 
         if (!FAST && fp.need_p0) {
             // p == 0 can never exceed T8: clear those bytes (only needed when T may be negative); on the packed bytes
@@ -976,7 +943,7 @@ __device__ __forceinline__ int strip_loop_f(gcptr img, gptr out, size_t istep, s
         const F8 pv_cur = pv;
 
         // rare: some pixel of this lane is not settled by the float32 test -> queue it (k_refine rebuilds its sums)
-        const bool unsure = lane_has_out && !((tmin > eps_row) && (vmin > vth_row));
+        const bool unsure = lane_has_out && !((tmin > pk.eps1) && (vmin > fp.vthr32));
         if (__ballot(unsure) != 0ull) {
             if (unsure) {
                 unsigned qm = 0u;   // this lane's pixels to queue, one bit each
@@ -986,7 +953,7 @@ __device__ __forceinline__ int strip_loop_f(gcptr img, gptr out, size_t istep, s
                     if (pv_cur.v[c] == 0.0f) continue;  // 0 > T8 is false whatever T is
                     float v32;
                     const float t = eval32f<METHOD>(fp, Ssum[c], Qsum[c], fmaf(pv_cur.v[c], kZ, pk.p0), pk, &v32);
-                    if (!((fabsf(t) > eps_row) && (v32 > vth_row))) qm |= 1u << c;
+                    if (!((fabsf(t) > pk.eps1) && (v32 > fp.vthr32))) qm |= 1u << c;
                 }
                 // the sums travel with the pixel: S is exact, Q within fp.flt_dq of the exact sum - k_refine's interval test
                 // takes that uncertainty first and only rebuilds the sums of what it leaves open.  (One push site, values
@@ -1071,18 +1038,13 @@ __device__ __forceinline__ int strip_loop_f(gcptr img, gptr out, size_t istep, s
             atomicMin(&g[page].imin, (int)pmin);
         }
     }
-    return ye;
 }
 
-// MODE 0: windows up to 181 columns; 1: wider ones (S no longer fits the mantissa trick, eval32 WIDE); 2: threshold sweep with
-// 30 < w - 1 <= 128 on the float32 loop with the switch to the integer loop (fp.flt_w) - its own instantiation, because a kernel
-// is allocated the registers of its hungriest path and this one would cost every narrow-window sweep a wavefront of occupancy.
-template <int METHOD, int SH, int MODE>
+template <int METHOD, int SH, bool WIDE>
 __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, FusedParams fp,
                                               PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
                                               WorkItem* __restrict__ cand, unsigned* __restrict__ counters)
 {
-    constexpr bool WIDE = MODE == 1;
     const ThrParams& tp = fp.tp;
     const int lane = threadIdx.x & (kWave - 1);
     const unsigned wpb = blockDim.x >> 6;  // wavefronts per block
@@ -1128,7 +1090,6 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     pk.imin = 0.0f;
     pk.p0 = -0.5f * kZ;
     pk.eps1 = fp.eps1;
-    pk.eps1w = fp.eps1_w;
     if (METHOD == PRL_FENG) {
         const double imin = (double)g[page].imin;
         const double c3 = (tp.k2 * imin + (-imin)) + 0.0;  // binarizeFeng.cpp:137 with r2 = c2 = 1
@@ -1151,10 +1112,9 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
             pk.c1 = c * fl;
             // (|T_literal - T*| grows with |coeff| through the sqrt noise: es_max)
             pk.eps1 = fp.eps1 + kZ * (2.02f * 255.0f * ac * fp.es_max + 1.02f * 255.0f * fabsf((float)tp.k) * delta);
-            pk.eps1w = pk.eps1 + kZ * 2.02f * 255.0f * ac * fp.ds_w;
         } else {  // (no deviation to speak of on this page: nothing is settled here, k_refine / the literal pipeline decide)
             pk.c1 = 0.0f;
-            pk.eps1 = pk.eps1w = __builtin_inff();
+            pk.eps1 = __builtin_inff();
         }
     } else if (METHOD == kWolfCollect) {
         // a pixel can only carry the literal maximum if K~ >= (1-rho) (Kmax/(1+rho) - 2 Ev / f^2)
@@ -1172,17 +1132,6 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
         // sweep A with a wide window: the float32 loop in its doubling form (the extended last strip stays on the integer loop)
         if (!interior) strip_loop_f<METHOD, SH, 4, false, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
         else strip_loop_f<METHOD, SH, 4, false, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
-    } else if (MODE == 2 && !(fp.ext && strip == fp.n_strips - 1)) {
-        // threshold sweep with a wide window: the float32 loop in its doubling form until a window's variance falls below its floor
-        // (dark flats, where the absolute rounding bound of the wide Q sums would matter), the integer loop from that row on
-        float vs_h[CPL], vq_h[CPL];
-        int yr;
-        if (!interior) yr = strip_loop_f<METHOD, SH, 4, false, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters, vs_h, vq_h);
-        else yr = strip_loop_f<METHOD, SH, 4, false, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters, vs_h, vq_h);
-        if (yr < ye) {
-            if (interior) strip_loop<METHOD, SH, false, false>(img, out, src.step, dst.step, fp, page, xs, yr, ye, lane, pk, wid, g, rl, cand, counters, false, true, vs_h, vq_h);
-            else strip_loop<METHOD, SH, true, false>(img, out, src.step, dst.step, fp, page, xs, yr, ye, lane, pk, wid, g, rl, cand, counters, false, true, vs_h, vq_h);
-        }
     } else if (kFloatOk && !WIDE && fp.flt) {
         // (wave-uniform dispatch, once per wavefront: the row loop itself is branch-free in the usual configuration)
         const bool fast = !fp.bit_out && fp.nt_store && !fp.need_p0 && !(fp.uo & 7);
@@ -1791,15 +1740,12 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     const unsigned blocks = 8u * ((fp.xcd_waves + wpb - 1) / wpb);   // each XCD: its share of every tier
     const dim3 grid(blocks), block(64 * wpb);
     const bool wide = fp.tp.w - 1 > 181;  // S no longer fits the mantissa of 2^23 (eval32)
-    constexpr bool kHasMode2 = METHOD >= 0 && METHOD <= PRL_FENG;
 #define PRL_LAUNCH_FUSED(SHV)                                                                                    \
     do {                                                                                                         \
         if (wide)                                                                                                \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, 1>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);    \
-        else if (kHasMode2 && fp.flt_w)                                                                          \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, kHasMode2 ? 2 : 0>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);   \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, true>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);    \
         else                                                                                                     \
-            hipLaunchKernelGGL((k_fused<METHOD, SHV, 0>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);   \
+            hipLaunchKernelGGL((k_fused<METHOD, SHV, false>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt);   \
     } while (0)
     switch (sh) {
     case 0: PRL_LAUNCH_FUSED(0); break;
@@ -2242,31 +2188,6 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.rho = (float)(std::fmax(b1.rho, b.rho) * 1.01);  // sweep A runs the float32 pipeline on interior strips, sweep B the integer one
     fp.ev2 = (float)(2.0 * b1.Ev * 1.01 / (f * f));  // in K units
     {
-        // Threshold sweep with a wide window on the float32 loop (flt_w).  S is exact there, |Q~ - Q| <= dq (flt_a_usable), i.e. the
-        // variance f^2 K~ is off by at most dv = dq / w^2 beside the relative part every pipeline has; through s = sqrt(v) that is
-        // |ds| <= dv / (2 sqrt(v - dv)), bounded by a page-independent constant once v has a floor: vthr_f = 4 (a flat region of
-        // gray level p has v = p^2 r (1 - r), r = ((w-1)/w)^2: only flats darker than ~15 fall below it - the wavefront that
-        // meets one switches to the integer loop).  The term enters E1 with the factor of s in T: M |a| (Sauvola), |k| (Niblack);
-        // NICK's sqrt(q) has its own floor (1 + R) vthr_f on q; Feng's T does not depend on s.
-        double dqw = 0.0;
-        const bool wide_ok = !fp.flt && env_knobs().flt_wide && flt_a_usable(tp, src.step, &dqw);
-        fp.flt_w = 0;
-        if (wide_ok) {
-            const double vthr_f = 4.0, dv = dqw * 1.01 / (double)(tp.w * tp.w);
-            const double n1 = tp.w - 1.0, R = n1 * n1 / (2.0 * tp.w - 1.0), u24 = std::ldexp(1.0, -24);
-            double extra = 0.0;   // additional float32 evaluation error of T
-            if (tp.method == PRL_SAUVOLA) extra = 255.0 * std::fabs(tp.a) * dv / (2.0 * std::sqrt(vthr_f - 2.0 * dv));
-            else if (tp.method == PRL_NIBLACK) extra = std::fabs(tp.k) * dv / (2.0 * std::sqrt(vthr_f - 2.0 * dv));
-            else if (tp.method == PRL_NICK) extra = std::fabs(tp.k) * (dqw * 1.01 * f) / (2.0 * std::sqrt((1.0 + R) * vthr_f - 2.0 * dqw * f));
-            const double eps_w = 2.0 * (b1.E1 + 1.01 * extra + b1.Elit) + 1e-6;
-            fp.flt_w = 1;
-            fp.eps1_w = (float)(eps_w * 1.01 * Z);
-            fp.ds_w = (float)(1.01 * dv / (2.0 * std::sqrt(vthr_f - 2.0 * dv)));   // (Wolf-Jolion: times |k / devianceMax| 255, per page)
-            // the floor is tested on K~ (Q~ for NICK), which may exceed the exact value by its error: raise it by that much
-            if (tp.method == PRL_NICK) fp.vthr32_w = (float)(((1.0 + R) * vthr_f / f + dqw) * (1.0 + 4.0 * u24 + 1e-5));
-            else fp.vthr32_w = (float)((vthr_f / (f * f) + (double)(tp.w * tp.w) * dqw) * (1.0 + 2.0 * b1.rho + 1e-5));
-            fp.flt_dq = dqw;   // queued pixels carry Q~ (k_refine's interval test takes the bound as uncertainty of q)
-        }
         double dqa = 0.0;
         fp.flt_a = (tp.method == PRL_WOLFJOLION && !fp.flt && flt_a_usable(tp, src.step, &dqa)) ? 1 : 0;
         // |K~ - K| <= w^2 |Q~ - Q| (+ the relative part, rho: S^2 and the fma round as in the integer pipeline's conversion)

@@ -65,7 +65,6 @@ const EnvKnobs& env_knobs()
         auto is0 = [](const char* name) { const char* e = std::getenv(name); return e && e[0] == '0'; };
         k.fused_wpb = (int)std::max(1ll, std::min(4ll, geti("PRL_HIP_WPB", 1)));
         k.flt = !is0("PRL_HIP_FLT");
-        k.flt_wide = !is0("PRL_HIP_FLT_WIDE");
         k.nt_store = !is0("PRL_HIP_NT");
         k.rows_per_seg = (int)geti("PRL_HIP_ROWS_PER_SEG", 0);
         if (k.rows_per_seg) k.rows_per_seg = std::max(4, k.rows_per_seg);

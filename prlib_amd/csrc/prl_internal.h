@@ -96,7 +96,6 @@ struct DeviceCtx {
 struct EnvKnobs {
     int fused_wpb = 1;            // PRL_HIP_WPB          wavefronts per workgroup of k_fused (1..4)
     bool flt = true;              // PRL_HIP_FLT=0        forces the integer sum pipeline everywhere
-    bool flt_wide = true;         // PRL_HIP_FLT_WIDE=0   threshold sweeps with windows above 31 stay on the integer pipeline
     bool nt_store = true;         // PRL_HIP_NT=0         plain instead of non-temporal mask stores
     int rows_per_seg = 0;         // PRL_HIP_ROWS_PER_SEG (0 = chosen from the batch size)
     bool tiers = true;            // PRL_HIP_TIERS=0      one segment length for the whole call (A/B of the tiered schedule)
