@@ -43,7 +43,7 @@ constexpr unsigned kRefBucketCap = 1u << 13;                      // entries per
 constexpr unsigned kRefineCap = kRefBuckets * kRefBucketCap;      // pixels the float32 test may leave undecided per call (2^21)
 constexpr unsigned kWorkCap = 1u << 17;    // pixels the float64 interval test may leave undecided (more: literal page); also Wolf-Jolion's candidates
 constexpr unsigned kPageMajorMin = 64;     // from this many queued pixels on, their corner sums are built page by page (k_corner_rows)
-constexpr int kPageMajorMaxW = 8160;       // ... for pages whose row prefixes fit 64 KB of LDS (two u32 per column)
+constexpr int kPageMajorMaxW = 7900;       // ... for pages whose row prefixes fit 64 KB of LDS (two u32 per column, padded)
 constexpr int kRowChunks = 64;             // workgroups per page of k_corner_rows
 constexpr size_t kSegmaxCap = 1u << 20;    // wavefronts per call whose sweep-A maxima can be kept (Wolf)
 
@@ -1573,14 +1573,17 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
                                                     const unsigned* __restrict__ counters, CornerAcc* __restrict__ acc, PageSetOut dst,
                                                     const PageGlobals* __restrict__ g, unsigned* __restrict__ done)
 {
-    extern __shared__ unsigned s_prefix[];   // [W] inclusive row prefix of P, [W] of P*P
+    extern __shared__ unsigned s_prefix[];   // inclusive row prefix of P and of P*P, one word of padding per 32 columns (PX)
     __shared__ unsigned s_ws[4], s_wq[4];
     const ThrParams& tp = fp.tp;
     const unsigned n_slots = counters[kCntPageMajor];
     if (n_slots == 0u) return;
     const int W = tp.width, H = tp.height, h = tp.half;
+    // (a thread writes the prefixes of its 32 consecutive columns: without the padding the lanes' stores would be 32 words apart -
+    // all in two banks, the kernel 3x slower)
+#define PX(c) ((c) + ((c) >> 5))
     unsigned* ps = s_prefix;
-    unsigned* pq = s_prefix + W;
+    unsigned* pq = s_prefix + PX(W) + 1;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     // this thread's columns of a row: 32 each (the whole-segment fast path) whenever 256 x 32 covers the row
     const int seg = W <= 8192 ? 32 : (W + 255) / 256, c0 = min(t * seg, W), c1 = min(c0 + seg, W);
@@ -1603,17 +1606,24 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
             const int r_m0 = pad_count(X0 + 1, X1, 0, W, h), r_mW = pad_count(X0 + 1, X1, W - 1, W, h);
             unsigned long long a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             // rows this workgroup has to walk for this group: none beyond the largest r_last (wave / block uniform via LDS-free max)
+            const bool whole = c1 - c0 == 32;
+            uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;   // the next row's 32 bytes, fetched while this row is worked on
+            if (whole && r_begin < r_stop) {
+                __builtin_memcpy(&n0, img + (size_t)r_begin * src.step + c0, 16);
+                __builtin_memcpy(&n1, img + (size_t)r_begin * src.step + c0 + 16, 16);
+            }
             for (int r = r_begin; r < r_stop; ++r) {
                 const uint8_t* row = img + (size_t)r * src.step;
                 // inclusive prefix of the row in LDS: every thread sums its columns (up to 32: two 16-byte loads when it has all
                 // of them - byte loads made this kernel 3x slower), block scan of the totals, second pass writes
                 unsigned s = 0, q = 0;
                 unsigned d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                const bool whole = c1 - c0 == 32;
                 if (whole) {
-                    uint4 v0, v1;
-                    __builtin_memcpy(&v0, row + c0, 16);
-                    __builtin_memcpy(&v1, row + c0 + 16, 16);
+                    const uint4 v0 = n0, v1 = n1;
+                    if (r + 1 < r_stop) {
+                        __builtin_memcpy(&n0, row + src.step + c0, 16);
+                        __builtin_memcpy(&n1, row + src.step + c0 + 16, 16);
+                    }
                     d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -1638,24 +1648,24 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
                         const unsigned b = (d[k >> 2] >> (8 * (k & 3))) & 0xffu;
                         so += b;
                         qo += b * b;
-                        ps[c0 + k] = so;
-                        pq[c0 + k] = qo;
+                        ps[PX(c0 + k)] = so;
+                        pq[PX(c0 + k)] = qo;
                     }
                 } else {
                     for (int c = c0; c < c1; ++c) {
                         const unsigned b = row[c];
                         so += b;
                         qo += b * b;
-                        ps[c] = so;
-                        pq[c] = qo;
+                        ps[PX(c)] = so;
+                        pq[PX(c)] = qo;
                     }
                 }
                 __syncthreads();
                 if (has && r <= r_last) {
-                    const unsigned e0 = ps[0], eW = ps[W - 1] - (W > 1 ? ps[W - 2] : 0u);
+                    const unsigned e0 = ps[0], eW = ps[PX(W - 1)] - (W > 1 ? ps[PX(W - 2)] : 0u);
                     const unsigned e0q = e0 * e0, eWq = eW * eW;
-                    unsigned sl = ps[lcb], ql = pq[lcb];                                             // columns 0 .. lcb
-                    unsigned sr = ps[rcb] - (rca > 0 ? ps[rca - 1] : 0u), qr = pq[rcb] - (rca > 0 ? pq[rca - 1] : 0u);
+                    unsigned sl = ps[PX(lcb)], ql = pq[PX(lcb)];                                     // columns 0 .. lcb
+                    unsigned sr = ps[PX(rcb)] - (rca > 0 ? ps[PX(rca - 1)] : 0u), qr = pq[PX(rcb)] - (rca > 0 ? pq[PX(rca - 1)] : 0u);
                     if (l_m0 > 0) { sl += (unsigned)(l_m0 - 1) * e0; ql += (unsigned)(l_m0 - 1) * e0q; }
                     if (l_mW > 0 && lcb == W - 1) { sl += (unsigned)(l_mW - 1) * eW; ql += (unsigned)(l_mW - 1) * eWq; }
                     if (r_m0 > 0 && rca == 0) { sr += (unsigned)(r_m0 - 1) * e0; qr += (unsigned)(r_m0 - 1) * e0q; }
@@ -1691,6 +1701,7 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
         }
     }
 }
+#undef PX
 
 // Page minimum of the part of the page no sweep-A wavefront fetches: the sweeps stop h rows above the bottom and may
 // stop short of the right border, so the last `band` rows and columns are reduced here (band = w is generous).
@@ -1779,7 +1790,8 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     // From kPageMajorMin queued pixels on the corner sums are built page by page (k_group_items + k_corner_rows, which return at
     // once otherwise); calls of a few pages skip the two launches (a near-empty launch costs ~5 us, a single-page call 33).
     const bool page_major = n_pages >= 8;
-    const size_t rows_lds = (size_t)std::min(fp.tp.width, kPageMajorMaxW) * 2 * sizeof(unsigned);
+    const int lds_w = std::min(fp.tp.width, kPageMajorMaxW);
+    const size_t rows_lds = ((size_t)(lds_w + (lds_w >> 5)) + 1) * 2 * sizeof(unsigned);   // (k_corner_rows' PX padding)
     const dim3 rows_grid(kRowChunks, (unsigned)std::min(n_pages, 512));
     if (METHOD == PRL_WOLFJOLION) {
         // the literal devianceMax of the pages whose pixels reached the fix-up list (none, as a rule: immediate returns)

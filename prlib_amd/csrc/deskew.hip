@@ -814,26 +814,31 @@ void fill_warp_page(int width, int height, double angle, bool copy, WarpPage* wp
 }
 
 // deskew.cpp:158-201 over the segments of one page
-double vote_angle(const int* lines, int nb_lines)
+// The angle vote of findAngle (deskew.cpp:158-201): every segment's atan2 joins the FIRST cluster whose representative (the angle
+// that opened it) lies within 0.01 rad, else opens a new one; a cluster's tally counts the joiners only (it starts at 0, as the
+// reference's does), the first cluster with the largest tally wins and its representative is returned in degrees.
+double vote_angle(const int* segments, int n_segments)
 {
-    if (!nb_lines) return 0.0;
-    std::vector<std::pair<double, int>> t_diff;
-    const double delta = 0.01;
-    for (int l = 0; l < nb_lines; ++l) {
-        const double ang = std::atan2((double)lines[4 * l + 3] - lines[4 * l + 1], (double)lines[4 * l + 2] - lines[4 * l]);
-        bool found = false;
-        for (auto& e : t_diff)
-            if (eq_d(ang, e.first, delta)) {
-                e.second++;
-                found = true;
-                break;
-            }
-        if (!found) t_diff.emplace_back(ang, 0);
+    if (n_segments <= 0) return 0.0;
+    constexpr double kClusterWidth = 0.01;
+    std::vector<double> representative;   // cluster -> the angle that opened it
+    std::vector<int> joiners;             // cluster -> segments that joined it afterwards
+    for (int i = 0; i < n_segments; ++i) {
+        const int* seg = segments + 4 * i;   // x0, y0, x1, y1
+        const double theta = std::atan2((double)seg[3] - seg[1], (double)seg[2] - seg[0]);
+        size_t c = 0;
+        while (c < representative.size() && !eq_d(theta, representative[c], kClusterWidth)) ++c;
+        if (c == representative.size()) {
+            representative.push_back(theta);
+            joiners.push_back(0);
+        } else {
+            ++joiners[c];
+        }
     }
-    size_t best = 0;
-    for (size_t e = 1; e < t_diff.size(); ++e)
-        if (t_diff[best].second < t_diff[e].second) best = e;
-    return t_diff[best].first * 180 / 3.14159265358979323846;
+    size_t winner = 0;   // (std::max_element keeps the first of equal maxima)
+    for (size_t c = 1; c < joiners.size(); ++c)
+        if (joiners[c] > joiners[winner]) winner = c;
+    return representative[winner] * 180 / 3.14159265358979323846;
 }
 
 int launch_warp(int channels, const PageSet& s, const PageSetOut& d, int width, int height, int n_pages, int max_ow, int max_oh,

@@ -7,7 +7,7 @@ TAG=${1:-r01}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --cpu-seconds 0 --check-pages 0 $*"
+ARGS="--steps 20 --warmup 3 --cpu-seconds 0 --check-pages 0 --worst-case 0 --end-to-end 0 $*"
 # 1. kernel trace + stats (no counters in this run)
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --traffic 0 --ceilings 0 $ARGS > "$OUT/trace.log" 2>&1
 # 2. PMC passes, each in its own run (TCC: FETCH_SIZE and WRITE_SIZE do not fit one pass)
