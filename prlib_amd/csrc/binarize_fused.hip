@@ -43,7 +43,7 @@ constexpr unsigned kRefBucketCap = 1u << 13;                      // entries per
 constexpr unsigned kRefineCap = kRefBuckets * kRefBucketCap;      // pixels the float32 test may leave undecided per call (2^21)
 constexpr unsigned kWorkCap = 1u << 17;    // pixels the float64 interval test may leave undecided (more: literal page); also Wolf-Jolion's candidates
 constexpr unsigned kPageMajorMin = 64;     // from this many queued pixels on, their corner sums are built page by page (k_corner_rows)
-constexpr int kPageMajorMaxW = 7900;       // ... for pages whose row prefixes fit 64 KB of LDS (two u32 per column, padded)
+constexpr int kPageMajorMaxW = 8192;       // ... for pages a workgroup of k_corner_rows covers with 32 columns per thread
 constexpr int kRowChunks = 64;             // workgroups per page of k_corner_rows
 constexpr size_t kSegmaxCap = 1u << 20;    // wavefronts per call whose sweep-A maxima can be kept (Wolf)
 
@@ -1183,7 +1183,7 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
         for (unsigned i = (wave_id / (unsigned)kRefBuckets) * kWave + lane; i - lane < n; i += per_bucket * kWave) {
             const bool valid = i < n;
             RefItem it = rl[(size_t)b * kRefBucketCap + (valid ? i : 0u)];
-            const bool approx = (it.p & kRefApprox) != 0u;
+            const bool approx = (it.p & kRefApprox) != 0u && fp.flt_dq > 0.0;   // (w <= 21: the float32 loop's sums are exact, nothing to rebuild)
             it.p &= 0xffu;
             unsigned r = 2;
             double imin = 0.0, coeff = 0.0, crel = 0.0;
@@ -1220,6 +1220,16 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
                 }
                 if (lane == owner) r = refine64<METHOD>(fp, S, Q, it.p, imin, coeff, 0.0, crel);
             }
+            // slots of the fix-up list: one atomic per wavefront (a same-address atomic with return costs ~20 ns under contention:
+            // Feng's 21 000 ties on 256 pages took k_refine 0.39 ms with one per pixel)
+            const bool to_fixup = valid && r == 2;
+            const unsigned long long fm = __ballot(to_fixup);
+            unsigned slot_base = 0;
+            if (fm) {
+                const int leader = __ffsll((long long)fm) - 1;
+                if (lane == leader) slot_base = atomicAdd(&counters[1], (unsigned)__popcll(fm));
+                slot_base = (unsigned)__shfl((int)slot_base, leader, kWave);
+            }
             if (!valid) continue;
             if (r != 2) {
                 store_decision(dst, fp.bit_out, it.page, it.y, it.x, r);
@@ -1227,7 +1237,7 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
             } else {
                 atomicAdd(&g[it.page].n_exact, 1u);
                 if (METHOD == PRL_WOLFJOLION) atomicOr(&g[it.page].need_literal, 1u);   // the fix-up evaluates with the LITERAL devianceMax (k_wolf_literal)
-                const unsigned idx = atomicAdd(&counters[1], 1u);
+                const unsigned idx = slot_base + (unsigned)__popcll(fm & ((1ull << lane) - 1ull));
                 if (idx < fp.wl_cap) {
                     WorkItem w;
                     w.page = it.page;
@@ -1573,22 +1583,33 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
                                                     const unsigned* __restrict__ counters, CornerAcc* __restrict__ acc, PageSetOut dst,
                                                     const PageGlobals* __restrict__ g, unsigned* __restrict__ done)
 {
-    extern __shared__ unsigned s_prefix[];   // inclusive row prefix of P and of P*P, one word of padding per 32 columns (PX)
+    // LDS, per row: the row's dwords, and the inclusive prefix sums of P and P*P through the END of each dword (one word of padding
+    // per 8: a thread writes 8 consecutive entries).  The prefix at a column = the entry of its dword minus the bytes behind the
+    // column, two v_dot4 on the masked dword.  (Round 4's first version kept a prefix per COLUMN: 160 of its 200 instructions a
+    // row went into the 32-step byte loop; 3.65 ms for Feng's 21 000 ties on 256 4K pages, see profiles/r04.)
+    extern __shared__ unsigned s_row[];
     __shared__ unsigned s_ws[4], s_wq[4];
     const ThrParams& tp = fp.tp;
     const unsigned n_slots = counters[kCntPageMajor];
     if (n_slots == 0u) return;
     const int W = tp.width, H = tp.height, h = tp.half;
-    // (a thread writes the prefixes of its 32 consecutive columns: without the padding the lanes' stores would be 32 words apart -
-    // all in two banks, the kernel 3x slower)
-#define PX(c) ((c) + ((c) >> 5))
-    unsigned* ps = s_prefix;
-    unsigned* pq = s_prefix + PX(W) + 1;
+#define PJ(j) ((j) + ((j) >> 3))
+    const int J = (W + 3) >> 2, JP = PJ(J) + 1;
+    unsigned* raw = s_row;
+    unsigned* ps4 = s_row + JP;
+    unsigned* pq4 = s_row + 2 * JP;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    // this thread's columns of a row: 32 each (the whole-segment fast path) whenever 256 x 32 covers the row
-    const int seg = W <= 8192 ? 32 : (W + 255) / 256, c0 = min(t * seg, W), c1 = min(c0 + seg, W);
+    const int c0 = 32 * t, j0 = 8 * t;               // this thread's 32 columns = 8 dwords of a row (W <= 8192)
+    const bool whole = c0 + 32 <= W;
     const int per = (H + kRowChunks - 1) / kRowChunks;
     const int r_begin = blockIdx.x * per, r_stop = min(r_begin + per, H);
+    auto prefix_at = [&](int c, unsigned* s_out, unsigned* q_out) {   // sums of P and P*P over columns 0 .. c of the row in LDS
+        const int j = c >> 2, rr = c & 3;
+        const unsigned x = raw[PJ(j)];
+        const unsigned xh = rr == 3 ? 0u : (x & (0xffffffffu << (8 * (rr + 1))));
+        *s_out = ps4[PJ(j)] - __builtin_amdgcn_udot4(xh, 0x01010101u, 0u, false);
+        *q_out = pq4[PJ(j)] - __builtin_amdgcn_udot4(xh, xh, 0u, false);
+    };
     for (unsigned slot = blockIdx.y; slot < n_slots; slot += gridDim.y) {
         const int page = (int)ga.plist[slot];
         const uint8_t* img = src.page(page);
@@ -1605,8 +1626,6 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
             const int l_m0 = pad_count(0, X0, 0, W, h), l_mW = pad_count(0, X0, W - 1, W, h);
             const int r_m0 = pad_count(X0 + 1, X1, 0, W, h), r_mW = pad_count(X0 + 1, X1, W - 1, W, h);
             unsigned long long a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            // rows this workgroup has to walk for this group: none beyond the largest r_last (wave / block uniform via LDS-free max)
-            const bool whole = c1 - c0 == 32;
             uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;   // the next row's 32 bytes, fetched while this row is worked on
             if (whole && r_begin < r_stop) {
                 __builtin_memcpy(&n0, img + (size_t)r_begin * src.step + c0, 16);
@@ -1614,9 +1633,6 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
             }
             for (int r = r_begin; r < r_stop; ++r) {
                 const uint8_t* row = img + (size_t)r * src.step;
-                // inclusive prefix of the row in LDS: every thread sums its columns (up to 32: two 16-byte loads when it has all
-                // of them - byte loads made this kernel 3x slower), block scan of the totals, second pass writes
-                unsigned s = 0, q = 0;
                 unsigned d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (whole) {
                     const uint4 v0 = n0, v1 = n1;
@@ -1625,47 +1641,45 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
                         __builtin_memcpy(&n1, row + src.step + c0 + 16, 16);
                     }
                     d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        s = __builtin_amdgcn_udot4(d[k], 0x01010101u, s, false);
-                        q = __builtin_amdgcn_udot4(d[k], d[k], q, false);
-                    }
                 } else {
-                    for (int c = c0; c < c1; ++c) {
-                        const unsigned b = row[c];
-                        s += b;
-                        q += b * b;
-                    }
+                    for (int c = c0; c < min(c0 + 32, W); ++c) d[(c - c0) >> 2] |= (unsigned)row[c] << (8 * ((c - c0) & 3));   // (the row's tail: zero-filled)
+                }
+                unsigned ds[8], dq[8], s = 0, q = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    ds[k] = __builtin_amdgcn_udot4(d[k], 0x01010101u, 0u, false);
+                    dq[k] = __builtin_amdgcn_udot4(d[k], d[k], 0u, false);
+                    s += ds[k];
+                    q += dq[k];
                 }
                 const unsigned si = wave_scan_incl(s), qi = wave_scan_incl(q);
                 if (lane == 63) { s_ws[wv] = si; s_wq[wv] = qi; }
                 __syncthreads();
                 unsigned so = si - s, qo = qi - q;
                 for (int k = 0; k < wv; ++k) { so += s_ws[k]; qo += s_wq[k]; }
-                if (whole) {
 #pragma unroll
-                    for (int k = 0; k < 32; ++k) {
-                        const unsigned b = (d[k >> 2] >> (8 * (k & 3))) & 0xffu;
-                        so += b;
-                        qo += b * b;
-                        ps[PX(c0 + k)] = so;
-                        pq[PX(c0 + k)] = qo;
-                    }
-                } else {
-                    for (int c = c0; c < c1; ++c) {
-                        const unsigned b = row[c];
-                        so += b;
-                        qo += b * b;
-                        ps[PX(c)] = so;
-                        pq[PX(c)] = qo;
+                for (int k = 0; k < 8; ++k) {
+                    so += ds[k];
+                    qo += dq[k];
+                    if (j0 + k < J) {
+                        raw[PJ(j0 + k)] = d[k];
+                        ps4[PJ(j0 + k)] = so;
+                        pq4[PJ(j0 + k)] = qo;
                     }
                 }
                 __syncthreads();
                 if (has && r <= r_last) {
-                    const unsigned e0 = ps[0], eW = ps[PX(W - 1)] - (W > 1 ? ps[PX(W - 2)] : 0u);
+                    const unsigned e0 = raw[0] & 0xffu, eW = (raw[PJ((W - 1) >> 2)] >> (8 * ((W - 1) & 3))) & 0xffu;
                     const unsigned e0q = e0 * e0, eWq = eW * eW;
-                    unsigned sl = ps[PX(lcb)], ql = pq[PX(lcb)];                                     // columns 0 .. lcb
-                    unsigned sr = ps[PX(rcb)] - (rca > 0 ? ps[PX(rca - 1)] : 0u), qr = pq[PX(rcb)] - (rca > 0 ? pq[PX(rca - 1)] : 0u);
+                    unsigned sl, ql, sr, qr;
+                    prefix_at(lcb, &sl, &ql);                                                        // columns 0 .. lcb
+                    prefix_at(rcb, &sr, &qr);                                                        // columns rca .. rcb
+                    if (rca > 0) {
+                        unsigned s0, q0;
+                        prefix_at(rca - 1, &s0, &q0);
+                        sr -= s0;
+                        qr -= q0;
+                    }
                     if (l_m0 > 0) { sl += (unsigned)(l_m0 - 1) * e0; ql += (unsigned)(l_m0 - 1) * e0q; }
                     if (l_mW > 0 && lcb == W - 1) { sl += (unsigned)(l_mW - 1) * eW; ql += (unsigned)(l_mW - 1) * eWq; }
                     if (r_m0 > 0 && rca == 0) { sr += (unsigned)(r_m0 - 1) * e0; qr += (unsigned)(r_m0 - 1) * e0q; }
@@ -1701,7 +1715,7 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
         }
     }
 }
-#undef PX
+#undef PJ
 
 // Page minimum of the part of the page no sweep-A wavefront fetches: the sweeps stop h rows above the bottom and may
 // stop short of the right border, so the last `band` rows and columns are reduced here (band = w is generous).
@@ -1790,8 +1804,8 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     // From kPageMajorMin queued pixels on the corner sums are built page by page (k_group_items + k_corner_rows, which return at
     // once otherwise); calls of a few pages skip the two launches (a near-empty launch costs ~5 us, a single-page call 33).
     const bool page_major = n_pages >= 8;
-    const int lds_w = std::min(fp.tp.width, kPageMajorMaxW);
-    const size_t rows_lds = ((size_t)(lds_w + (lds_w >> 5)) + 1) * 2 * sizeof(unsigned);   // (k_corner_rows' PX padding)
+    const int lds_j = (std::min(fp.tp.width, kPageMajorMaxW) + 3) / 4;
+    const size_t rows_lds = ((size_t)(lds_j + (lds_j >> 3)) + 1) * 3 * sizeof(unsigned);   // (k_corner_rows: row dwords + two dword-granular prefixes, PJ padding)
     const dim3 rows_grid(kRowChunks, (unsigned)std::min(n_pages, 512));
     if (METHOD == PRL_WOLFJOLION) {
         // the literal devianceMax of the pages whose pixels reached the fix-up list (none, as a rule: immediate returns)
