@@ -2001,6 +2001,15 @@ static bool flt_a_usable(const ThrParams& tp, size_t src_step, double* dq_out)
     return true;
 }
 
+extern "C" int prl_hip_internal_flt_a_q_error(int w, double* dq)
+{
+    // test hook (not in the public header): flt_a_usable()'s absolute bound on |Q~ - Q| for sweep A's doubling form; 0 when unused for w
+    ThrParams tp{};
+    tp.w = w;
+    tp.height = 1;
+    return flt_a_usable(tp, 1, dq) ? 1 : 0;
+}
+
 extern "C" int prl_hip_internal_flt_q_error(int w, double* delta_qmin_cq)
 {
     // test hook (not in the public header): the float32 pipeline's bound on |Q~ - Q| for window w -

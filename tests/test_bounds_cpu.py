@@ -153,6 +153,70 @@ def test_float32_pipeline_q_error_bound(prl, w):
     assert cq >= 1.0 and worst <= delta
 
 
+@pytest.mark.parametrize("w", [33, 41, 51, 63, 81, 101, 121, 129])
+def test_float32_sweep_a_wide_window_q_error_bound(prl, w):
+    """flt_a_usable()'s ABSOLUTE bound on the float32 window sum of squares of Wolf-Jolion's sweep A with wide windows
+    (strip_loop_f, LO == 4): the in-lane prefixes and the doubling form of the lane sums W (sums of 2, 4, 8, 16 consecutive lanes,
+    pieces picked by the binary digits of the lane offset) are emulated in numpy float32 on adversarial column sums and compared
+    with the exact integer window sums.  The S sums of the same shape must be exact."""
+    from prlib_amd import _capi
+
+    L = _capi.lib()
+    L.prl_hip_internal_flt_a_q_error.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    dq = C.c_double(0)
+    assert L.prl_hip_internal_flt_a_q_error(w, C.byref(dq)) == 1
+    n1, loff, sh = w - 1, (w - 1) // 8, (w - 1) % 8
+    assert 4 <= loff <= 16
+    rng = np.random.default_rng(w)
+    shl = lambda x, k: np.concatenate([x[k:], np.zeros(k, np.float32)])   # value of lane + k (garbage lanes are never valid outputs)
+    f32 = lambda x: x.astype(np.float32)
+    worst = 0.0
+    for colmax, exact_required in ((n1 * 65025, False), (n1 * 255, True)):   # column sums of P*P, and of P (must come out exact)
+        for trial in range(120):
+            kind = trial % 4
+            if kind == 0:
+                vq = np.full(512, colmax, np.int64)
+            elif kind == 1:
+                vq = rng.integers(0, colmax + 1, 512)
+            elif kind == 2:
+                vq = np.where((np.arange(512) // int(rng.integers(5, 60))) % 2 == 0, colmax, rng.integers(0, 2000, 512))
+            else:
+                vq = np.where(rng.random(512) < rng.random(), colmax, rng.integers(0, colmax // 50 + 1, 512))
+            f = f32(vq.reshape(64, 8))
+            eq = np.zeros((64, 8), np.float32)
+            acc = f[:, 0].copy()
+            for c in range(1, 8):
+                eq[:, c] = acc
+                acc = f32(acc + f[:, c])
+            tot = acc
+            s2 = f32(tot + shl(tot, 1))
+            s4 = f32(s2 + shl(s2, 2))
+            s8 = f32(s4 + shl(s4, 4))
+            w0, off = np.zeros(64, np.float32), 0
+            if loff & 16:
+                w0, off = f32(s8 + shl(s8, 8)), 16
+            for bit, piece in ((8, s8), (4, s4), (2, s2), (1, tot)):
+                if loff & bit:
+                    w0 = f32(w0 + (shl(piece, off) if off else piece))
+                    off += bit
+            w1 = f32(w0 + shl(tot, off))
+            exact_prefix = np.concatenate([[0], np.cumsum(vq)])
+            for lane in range(0, 64 - loff - 1):
+                for c in range(8):
+                    far1 = (c + sh) >= 8
+                    fl = lane + loff + (1 if far1 else 0)
+                    q32 = np.float32(np.float32(eq[fl, (c + sh) & 7] - eq[lane, c]) + (w1[lane] if far1 else w0[lane]))
+                    col = lane * 8 + c
+                    exact = int(exact_prefix[col + n1] - exact_prefix[col])
+                    err = abs(float(q32) - exact)
+                    if exact_required:
+                        assert err == 0.0, (w, trial, lane, c, err)
+                    else:
+                        assert err <= dq.value, (w, trial, lane, c, err, dq.value)
+                        worst = max(worst, err)
+    assert worst <= dq.value
+
+
 def test_strip_layout(prl):
     """Strips per row (binarize_fused.hip strip_layout).  The extended last strip saves the seventh strip of an A4 row and
     the eleventh of a 4096-column row at the default w = 101; a ragged uo saves the sixth strip of an A4 row at NICK's
