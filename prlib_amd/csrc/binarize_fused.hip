@@ -44,7 +44,7 @@ constexpr unsigned kRefineCap = kRefBuckets * kRefBucketCap;      // pixels the 
 constexpr unsigned kWorkCap = 1u << 17;    // pixels the float64 interval test may leave undecided (more: literal page); also Wolf-Jolion's candidates
 constexpr unsigned kPageMajorMin = 64;     // from this many queued pixels on, their corner sums are built page by page (k_corner_rows)
 constexpr int kPageMajorMaxW = 8192;       // ... for pages a workgroup of k_corner_rows covers with 32 columns per thread
-constexpr int kRowChunks = 64;             // workgroups per page of k_corner_rows
+constexpr int kRowChunks = 16;             // workgroups per page of k_corner_rows (each: 2 or 4 wavefronts taking rows in turn)
 constexpr size_t kSegmaxCap = 1u << 20;    // wavefronts per call whose sweep-A maxima can be kept (Wolf)
 
 struct RefItem {   // undecided after the float32 test: the window sums travel with the pixel
@@ -1577,30 +1577,34 @@ __global__ void __launch_bounds__(1024) k_group_items(const WorkItem* __restrict
     }
 }
 
-// grid (kRowChunks, page slots); 256 threads.  Thread t of a workgroup owns the t-th queued pixel of the page (256 at a time).
-template <bool FINAL>
+// grid (kRowChunks, page slots).  A workgroup walks one chunk of a page's rows; each of its NW wavefronts takes every NW-th row
+// of the chunk ON ITS OWN - the row's BPL bytes per lane in registers, dword sums, one DPP scan, the row's dwords and the
+// dword-granular prefixes of P and P*P in the wavefront's own piece of LDS - no workgroup barrier per row (the first version,
+// one row per workgroup and three barriers, spent 3.4 us a row waiting).  Lane L owns the L-th queued pixel of the page (64 at
+// a time) and adds the row's contribution to its eight sums (k_corner_partial's multiplicity arithmetic; a range sum is the
+// difference of two prefixes, a prefix at a column = its dword's entry minus the bytes behind the column, two v_dot4).  The
+// wavefronts' partial sums meet in LDS once per group of pixels, then one atomicAdd per sum.
+// BPL = 64 (rows up to 4096 bytes, NW = 4) or 128 (up to 8192, NW = 2): 55 KB of LDS either way.
+template <bool FINAL, int BPL>
 __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp, const WorkItem* __restrict__ items, GroupArrays ga,
                                                     const unsigned* __restrict__ counters, CornerAcc* __restrict__ acc, PageSetOut dst,
                                                     const PageGlobals* __restrict__ g, unsigned* __restrict__ done)
 {
-    // LDS, per row: the row's dwords, and the inclusive prefix sums of P and P*P through the END of each dword (one word of padding
-    // per 8: a thread writes 8 consecutive entries).  The prefix at a column = the entry of its dword minus the bytes behind the
-    // column, two v_dot4 on the masked dword.  (Round 4's first version kept a prefix per COLUMN: 160 of its 200 instructions a
-    // row went into the 32-step byte loop; 3.65 ms for Feng's 21 000 ties on 256 4K pages, see profiles/r04.)
-    extern __shared__ unsigned s_row[];
-    __shared__ unsigned s_ws[4], s_wq[4];
+    constexpr int DPL = BPL / 4;                 // dwords per lane
+    constexpr int JW = kWave * DPL;              // dwords of LDS row per wavefront (before padding)
+#define PJ(j) ((j) + ((j) >> 4))
+    constexpr int JP = JW + (JW >> 4) + 1;
+    extern __shared__ unsigned s_row[];          // per wavefront: raw[JP], ps4[JP], pq4[JP]; reused for the final reduction
     const ThrParams& tp = fp.tp;
     const unsigned n_slots = counters[kCntPageMajor];
     if (n_slots == 0u) return;
     const int W = tp.width, H = tp.height, h = tp.half;
-#define PJ(j) ((j) + ((j) >> 3))
-    const int J = (W + 3) >> 2, JP = PJ(J) + 1;
-    unsigned* raw = s_row;
-    unsigned* ps4 = s_row + JP;
-    unsigned* pq4 = s_row + 2 * JP;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int c0 = 32 * t, j0 = 8 * t;               // this thread's 32 columns = 8 dwords of a row (W <= 8192)
-    const bool whole = c0 + 32 <= W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, NW = blockDim.x >> 6;
+    unsigned* raw = s_row + (size_t)wv * 3 * JP;
+    unsigned* ps4 = raw + JP;
+    unsigned* pq4 = raw + 2 * JP;
+    const int c0 = BPL * lane, j0 = DPL * lane;
+    const bool whole = c0 + BPL <= W;
     const int per = (H + kRowChunks - 1) / kRowChunks;
     const int r_begin = blockIdx.x * per, r_stop = min(r_begin + per, H);
     auto prefix_at = [&](int c, unsigned* s_out, unsigned* q_out) {   // sums of P and P*P over columns 0 .. c of the row in LDS
@@ -1614,11 +1618,11 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
         const int page = (int)ga.plist[slot];
         const uint8_t* img = src.page(page);
         const unsigned i0 = ga.pstart[page], i1 = ga.pstart[page + 1];
-        for (unsigned g0 = i0; g0 < i1; g0 += 256u) {
-            const bool has = g0 + (unsigned)t < i1;
-            const unsigned idx = has ? ga.sidx[g0 + t] : 0u;
+        for (unsigned g0 = i0; g0 < i1; g0 += (unsigned)kWave) {
+            const bool has = g0 + (unsigned)lane < i1;
+            const unsigned idx = has ? ga.sidx[g0 + lane] : 0u;
             const WorkItem wi = items[idx];
-            // constants of this thread's pixel (k_corner_partial's arithmetic)
+            // constants of this lane's pixel (k_corner_partial's arithmetic)
             const int Y0 = wi.y, X0 = wi.x, Y1 = wi.y + tp.w - 1, X1 = wi.x + tp.w - 1;
             const int r_last = clampi(Y1 - h, 0, H - 1);
             const int lcb = clampi(X0 - h, 0, W - 1);
@@ -1626,48 +1630,55 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
             const int l_m0 = pad_count(0, X0, 0, W, h), l_mW = pad_count(0, X0, W - 1, W, h);
             const int r_m0 = pad_count(X0 + 1, X1, 0, W, h), r_mW = pad_count(X0 + 1, X1, W - 1, W, h);
             unsigned long long a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;   // the next row's 32 bytes, fetched while this row is worked on
-            if (whole && r_begin < r_stop) {
-                __builtin_memcpy(&n0, img + (size_t)r_begin * src.step + c0, 16);
-                __builtin_memcpy(&n1, img + (size_t)r_begin * src.step + c0 + 16, 16);
-            }
-            for (int r = r_begin; r < r_stop; ++r) {
+            unsigned nx[DPL];   // the next row of this wavefront, fetched while the current one is worked on
+            auto fetch = [&](int r) {
                 const uint8_t* row = img + (size_t)r * src.step;
-                unsigned d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (whole) {
-                    const uint4 v0 = n0, v1 = n1;
-                    if (r + 1 < r_stop) {
-                        __builtin_memcpy(&n0, row + src.step + c0, 16);
-                        __builtin_memcpy(&n1, row + src.step + c0 + 16, 16);
+#pragma unroll
+                    for (int k = 0; k < DPL; k += 4) {
+                        uint4 v;
+                        __builtin_memcpy(&v, row + c0 + 4 * k, 16);
+                        nx[k] = v.x; nx[k + 1] = v.y; nx[k + 2] = v.z; nx[k + 3] = v.w;
                     }
-                    d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
-                } else {
-                    for (int c = c0; c < min(c0 + 32, W); ++c) d[(c - c0) >> 2] |= (unsigned)row[c] << (8 * ((c - c0) & 3));   // (the row's tail: zero-filled)
-                }
-                unsigned ds[8], dq[8], s = 0, q = 0;
+                } else {   // the lane over the row's end (and the lanes beyond it): dwords while they fit, the last bytes one by one, zeros after
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    ds[k] = __builtin_amdgcn_udot4(d[k], 0x01010101u, 0u, false);
-                    dq[k] = __builtin_amdgcn_udot4(d[k], d[k], 0u, false);
-                    s += ds[k];
-                    q += dq[k];
-                }
-                const unsigned si = wave_scan_incl(s), qi = wave_scan_incl(q);
-                if (lane == 63) { s_ws[wv] = si; s_wq[wv] = qi; }
-                __syncthreads();
-                unsigned so = si - s, qo = qi - q;
-                for (int k = 0; k < wv; ++k) { so += s_ws[k]; qo += s_wq[k]; }
+                    for (int k = 0; k < DPL; ++k) {
+                        const int c = c0 + 4 * k;
+                        unsigned v = 0u;
+                        if (c + 4 <= W) {
+                            __builtin_memcpy(&v, row + c, 4);
+                        } else {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    so += ds[k];
-                    qo += dq[k];
-                    if (j0 + k < J) {
-                        raw[PJ(j0 + k)] = d[k];
-                        ps4[PJ(j0 + k)] = so;
-                        pq4[PJ(j0 + k)] = qo;
+                            for (int b = 0; b < 4; ++b)
+                                if (c + b < W) v |= (unsigned)row[c + b] << (8 * b);
+                        }
+                        nx[k] = v;
                     }
                 }
-                __syncthreads();
+            };
+            if (r_begin + wv < r_stop) fetch(r_begin + wv);
+            for (int r = r_begin + wv; r < r_stop; r += NW) {
+                unsigned d[DPL], dsum[DPL], dsq[DPL], s = 0, q = 0;
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) d[k] = nx[k];
+                if (r + NW < r_stop) fetch(r + NW);
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) {
+                    dsum[k] = __builtin_amdgcn_udot4(d[k], 0x01010101u, 0u, false);
+                    dsq[k] = __builtin_amdgcn_udot4(d[k], d[k], 0u, false);
+                    s += dsum[k];
+                    q += dsq[k];
+                }
+                unsigned so = wave_scan_incl(s) - s, qo = wave_scan_incl(q) - q;
+#pragma unroll
+                for (int k = 0; k < DPL; ++k) {
+                    so += dsum[k];
+                    qo += dsq[k];
+                    raw[PJ(j0 + k)] = d[k];
+                    ps4[PJ(j0 + k)] = so;
+                    pq4[PJ(j0 + k)] = qo;
+                }
+                __builtin_amdgcn_wave_barrier();   // (one wavefront: LDS operations complete in order; this only pins the schedule)
                 if (has && r <= r_last) {
                     const unsigned e0 = raw[0] & 0xffu, eW = (raw[PJ((W - 1) >> 2)] >> (8 * ((W - 1) & 3))) & 0xffu;
                     const unsigned e0q = e0 * e0, eWq = eW * eW;
@@ -1689,12 +1700,21 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
                     a[0] += ct * sl;  a[1] += ct * sr;  a[2] += cb2 * sl;  a[3] += cb2 * sr;
                     a[4] += ct * ql;  a[5] += ct * qr;  a[6] += cb2 * ql;  a[7] += cb2 * qr;
                 }
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
             }
-            if (has) {
+            // the wavefronts' partial sums meet in LDS (their row areas are free now), wavefront 0 adds them up
+            __syncthreads();
+            auto* red = reinterpret_cast<unsigned long long*>(s_row);   // [NW][8][64]
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (a[k] != 0ull) atomicAdd(&acc[idx].a[k], a[k]);
+            for (int k = 0; k < 8; ++k) red[((size_t)wv * 8 + k) * kWave + lane] = a[k];
+            __syncthreads();
+            if (wv == 0 && has) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    unsigned long long v = 0;
+                    for (int ww = 0; ww < NW; ++ww) v += red[((size_t)ww * 8 + k) * kWave + lane];
+                    if (v != 0ull) atomicAdd(&acc[idx].a[k], v);
+                }
                 if constexpr (FINAL) {
                     __threadfence();   // this workgroup's sums are visible before its arrival is
                     if (atomicAdd(&done[idx], 1u) == gridDim.x - 1) {   // the last of the page's row chunks: the literal evaluation
@@ -1712,6 +1732,7 @@ __global__ void __launch_bounds__(256) k_corner_rows(PageSet src, FusedParams fp
                     }
                 }
             }
+            __syncthreads();   // (the row areas are written again by the next group)
         }
     }
 }
@@ -1804,15 +1825,22 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     // From kPageMajorMin queued pixels on the corner sums are built page by page (k_group_items + k_corner_rows, which return at
     // once otherwise); calls of a few pages skip the two launches (a near-empty launch costs ~5 us, a single-page call 33).
     const bool page_major = n_pages >= 8;
-    const int lds_j = (std::min(fp.tp.width, kPageMajorMaxW) + 3) / 4;
-    const size_t rows_lds = ((size_t)(lds_j + (lds_j >> 3)) + 1) * 3 * sizeof(unsigned);   // (k_corner_rows: row dwords + two dword-granular prefixes, PJ padding)
-    const dim3 rows_grid(kRowChunks, (unsigned)std::min(n_pages, 512));
+    // k_corner_rows: 64 bytes of a row per lane and 4 wavefronts (rows up to 4096 bytes) or 128 and 2; per wavefront the row's dwords
+    // and two dword-granular prefixes with one word of padding per 16
+    const bool rows_wide = fp.tp.width > 4096;
+    const int rows_jw = 64 * (rows_wide ? 32 : 16), rows_nw = rows_wide ? 2 : 4;
+    const size_t rows_lds = (size_t)rows_nw * 3 * (size_t)(rows_jw + (rows_jw >> 4) + 1) * sizeof(unsigned);
+    const dim3 rows_grid(kRowChunks, (unsigned)std::min(n_pages, 512)), rows_block(64 * rows_nw);
     if (METHOD == PRL_WOLFJOLION) {
         // the literal devianceMax of the pages whose pixels reached the fix-up list (none, as a rule: immediate returns)
         if (page_major) {
             hipLaunchKernelGGL(k_group_items, dim3(1), dim3(1024), 0, stream, cand, cnt, 2, g, n_pages, fp.tp.width, fp.wl_cap, ga);
-            hipLaunchKernelGGL(k_corner_rows<false>, rows_grid, dim3(256), rows_lds, stream, src, fp, cand, ga, cnt, cacc, dst, g,
-                               static_cast<unsigned*>(nullptr));
+            if (rows_wide)
+                hipLaunchKernelGGL((k_corner_rows<false, 128>), rows_grid, rows_block, rows_lds, stream, src, fp, cand, ga, cnt, cacc, dst, g,
+                                   static_cast<unsigned*>(nullptr));
+            else
+                hipLaunchKernelGGL((k_corner_rows<false, 64>), rows_grid, rows_block, rows_lds, stream, src, fp, cand, ga, cnt, cacc, dst, g,
+                                   static_cast<unsigned*>(nullptr));
         }
         hipLaunchKernelGGL(k_corner_partial<false>, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, cand, cnt, 2, cacc, dst, g,
                            static_cast<unsigned*>(nullptr));
@@ -1826,7 +1854,8 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     // workgroup that delivers a pixel's last partial sum evaluates the pixel (no separate k_fixup_final launch)
     if (page_major) {
         hipLaunchKernelGGL(k_group_items, dim3(1), dim3(1024), 0, stream, wl, cnt, 1, g, n_pages, fp.tp.width, fp.wl_cap, ga);
-        hipLaunchKernelGGL(k_corner_rows<true>, rows_grid, dim3(256), rows_lds, stream, src, fp, wl, ga, cnt, acc, dst, g, done);
+        if (rows_wide) hipLaunchKernelGGL((k_corner_rows<true, 128>), rows_grid, rows_block, rows_lds, stream, src, fp, wl, ga, cnt, acc, dst, g, done);
+        else hipLaunchKernelGGL((k_corner_rows<true, 64>), rows_grid, rows_block, rows_lds, stream, src, fp, wl, ga, cnt, acc, dst, g, done);
     }
     hipLaunchKernelGGL(k_corner_partial<true>, dim3(kSplit, 16), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc, dst, g, done);  // (1024 workgroups: an empty queue is the rule, and its launch should cost little)
     PRL_HIP_CHECK(hipGetLastError());

@@ -337,6 +337,20 @@ def test_wide_windows_on_pages_with_dark_flats(prl, oracle, cuda_device, method,
         assert st.literal_pages == 0
 
 
+@pytest.mark.parametrize("width", [777, 2480, 4096, 4100, 6000, 8192, 8200])
+def test_page_major_corner_sums_row_widths(prl, oracle, cuda_device, width):
+    """k_corner_rows takes 64 bytes of a row per lane up to 4096 columns, 128 up to 8192 (the lane over the row's end fetches
+    dwords and single bytes); wider pages stay with the per-pixel kernel.  Tie regions at both ends of the row."""
+    w, c = 15, 200
+    k = _flat_boundary_k(c, w, c)
+    pages = _pages((70, width), ["doc"] * 8, seed=width)
+    pages[2][10:50, :60] = c
+    pages[2][5:45, -70:] = c
+    pages[7][20:60, width // 2 - 40:width // 2 + 40] = c
+    st = _check(prl, oracle, cuda_device, pages, SAUVOLA, w, k, 0)
+    assert st.exact_pixels > 1000 and st.literal_pages == 0
+
+
 def test_feng_rational_ties_stay_on_the_fast_path(prl, oracle, cuda_device):
     """Feng at the header defaults: (1 + (1 - alpha1)) m + c3 = 1.25 S / w^2 meets p - 0.5 EXACTLY for ~5 pixels in 10^6, which
     only the literal evaluation decides.  256 x 4K pages have 21 000 of them: round 3's fix-up list (2^14) overflowed and every page
