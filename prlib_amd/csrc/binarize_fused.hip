@@ -1198,7 +1198,14 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
             // what that leaves open and has an approximate Q: the wavefront rebuilds S and Q exactly from the page - padded rows
             // y+1 .. y+w-1, columns x+1 .. x+w-1 of the replicate-padded page, exact in u32 - one pixel at a
             // time, and the owner lane repeats the test with exact sums
-            unsigned long long todo = __ballot(valid && r == 2 && approx);
+            // (Feng's threshold depends on S only - exact in both loops - and on the variance through the s > 0 guard alone:
+            // when the guard held with the approximate Q, exact sums would repeat the same undecided answer - its ties)
+            bool rebuild = valid && r == 2 && approx;
+            if (METHOD == PRL_FENG && rebuild) {
+                const double mm = (double)it.S * tp.f, vv = (double)it.Q * tp.f - mm * mm;
+                rebuild = !(vv > 8.0 * (fp.Eq + eq_approx + 2.0 * mm * fp.Em + fp.Em * fp.Em) + 1e-9);
+            }
+            unsigned long long todo = __ballot(rebuild);
             while (todo) {
                 const int owner = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;

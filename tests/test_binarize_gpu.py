@@ -154,6 +154,40 @@ def test_pages_table_entry_point(prl, oracle, cuda_device):
         assert np.array_equal(outs[i][:, :g.out_w].cpu().numpy(), oracle.binarize(pg, p))
 
 
+@pytest.mark.parametrize("morph", [0, 2, -3, 9])
+def test_flagged_pages_are_redone_literally_as_one_batch(prl, oracle, cuda_device, morph):
+    """Several pages of a call overflow the fix-up list (flat pages on the tie, each with more undecidable pixels than the list
+    holds): the library redoes them through the literal pipeline in ONE batch - page-pointer tables on the device, chunks by the
+    scratch budget, the morphology pass behind it (radius 9: the chained large-radius path) - here through the page-table entry
+    point, so the flagged pages come from scattered allocations."""
+    import ctypes as C
+
+    import torch
+    from prlib_amd import _capi
+
+    w, c = 15, 200
+    k = _flat_boundary_k(c, w, c)
+    h, wd = 400, 360                    # 143 000 undecidable pixels a flat page: more than the 2^17 entries of the list
+    pages = _pages((h, wd), ["doc"] * 6, seed=97)
+    for i in (1, 2, 4):
+        pages[i][:, :] = c
+    dev = [torch.from_numpy(p).to(cuda_device) for p in pages]
+    params = prl.make_params(SAUVOLA, w, k, morph)
+    g = prl.geometry(params, wd, h)
+    outs = [torch.full((g.out_h, 384), 7, dtype=torch.uint8, device=cuda_device) for _ in pages]
+    src_tab = (C.c_void_p * 6)(*[t.data_ptr() for t in dev])
+    dst_tab = (C.c_void_p * 6)(*[t.data_ptr() for t in outs])
+    _capi.check(_capi.lib().prl_hip_binarize_pages_device(C.byref(params), 6, src_tab, wd, wd, h, dst_tab, 384,
+                                                          torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    st = prl.last_stats()
+    assert st.literal_pages == 3
+    p = oracle.make_params(SAUVOLA, w, k, morph)
+    for i, pg in enumerate(pages):
+        assert np.array_equal(outs[i][:, :g.out_w].cpu().numpy(), oracle.binarize(pg, p)), i
+        assert (outs[i][:, g.out_w:] == 7).all()
+
+
 def test_errors_match_reference(prl, cuda_device):
     import torch
 
