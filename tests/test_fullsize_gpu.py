@@ -143,3 +143,37 @@ def test_round2_stages_on_the_reference_test_images(prl, oracle, cuda_device):
         assert np.array_equal(prl.backgroundNormalization(t).cpu().numpy(), oracle.bgnorm(gray)), path
         n += 1
     assert n >= 6
+
+
+@pytest.mark.parametrize("method,win,k,morph", [(SAUVOLA, 31, 0.34, 0), (SAUVOLA, 101, 0.01, 2), (WOLFJOLION, 101, 0.01, 2), (FENG, 21, 0.0, 2)])
+def test_real_scans_tiled_to_4k_pages_fused_equals_literal(prl, oracle, cuda_device, method, win, k, morph):
+    """The reference's own scans (tests/golden/scans) tiled to 4096 x 4096 pages - tools/bench_real.py's batch, 12 pages of it:
+    real paper queues two orders of magnitude more near-threshold pixels than the synthetic pages, repeats its deviation maximum
+    at every repetition of a tile (hundreds of Wolf-Jolion candidates) and holds Feng's exact ties; fused == literal on every
+    page, the CPU oracle on one."""
+    import glob
+    import os
+
+    import torch
+
+    scans = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scans", "*.npz")))
+    assert len(scans) >= 24
+    pages_np = []
+    for i in range(12):
+        g = np.load(scans[(5 * i) % len(scans)])["gray"]
+        big = np.tile(g, (-(-4096 // g.shape[0]) + 1, -(-4096 // g.shape[1]) + 1))
+        oy, ox = (i * 97) % g.shape[0], (i * 211) % g.shape[1]
+        pages_np.append(np.ascontiguousarray(big[oy:oy + 4096, ox:ox + 4096]))
+    pages = torch.from_numpy(np.stack(pages_np)).to(cuda_device)
+    p = prl.make_params(method, win, k, morph)
+    fused = prl.binarize(pages, p).clone()
+    st = prl.last_stats()
+    assert st.literal_pages == 0
+    prl.set_exec_mode(1)
+    try:
+        lit = prl.binarize(pages, p).clone()
+    finally:
+        prl.set_exec_mode(0)
+    assert torch.equal(fused, lit)
+    want = oracle.binarize(pages_np[7], oracle.make_params(method, win, k, morph))
+    assert np.array_equal(fused[7].cpu().numpy(), want)
