@@ -2243,16 +2243,32 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.eps1 = (float)(b.eps1 * 1.01 * Z);
     fp.ref_cap = kRefineCap;
     fp.wl_cap = kWorkCap;
-    switch (tp.method) {  // need_p0 = 0 only where T >= 0 for every window, so p == 0 can never come out white
+    // need_p0 = 0 only where T > -0.5 for every window, so a black pixel can never come out white in the float32 sign test (the
+    // literal clamps T8 at 0).  Beyond T >= 0 two families qualify: a small negative k of Niblack / NICK - s <= sqrt(q) and
+    // q <= 255 m (Q = sum P^2 <= 255 sum P), so T >= m - |k| sqrt(255 m) >= -k^2 255 / 4, above -0.45 for |k| < 0.084 (NICK's header
+    // default -0.01) - and Feng when (1 + (1 - alpha1)) r + k2 >= 1 with r = ((w-1)/w)^2: m >= r Imin, so T = g m + (k2 - 1) Imin >= 0.
+    const bool small_neg_k = tp.k * tp.k * 63.75 < 0.45;
+    switch (tp.method) {
     case PRL_SAUVOLA:
         fp.c0 = (float)(Z * tp.a * f * f);
         fp.c1 = (float)(Z * tp.b * f);
         fp.need_p0 = !(tp.a >= 0.0 && tp.b >= 0.0);
         break;
-    case PRL_NIBLACK: fp.c0 = (float)(Z * tp.k * f); fp.c1 = (float)(Z * f); fp.need_p0 = !(tp.k >= 0.0); break;
-    case PRL_NICK: fp.c0 = (float)(Z * tp.k * std::sqrt(f)); fp.c1 = (float)(Z * f); fp.need_p0 = !(tp.k >= 0.0); break;
-    case PRL_FENG: fp.c0 = (float)(Z * (1.0 + tp.c1) * f); fp.need_p0 = 1; break;
-    case PRL_WOLFJOLION: fp.c0 = (float)tp.k; fp.c1 = (float)(Z * f); fp.need_p0 = 1; break;
+    case PRL_NIBLACK: fp.c0 = (float)(Z * tp.k * f); fp.c1 = (float)(Z * f); fp.need_p0 = !(tp.k >= 0.0 || small_neg_k); break;
+    case PRL_NICK: fp.c0 = (float)(Z * tp.k * std::sqrt(f)); fp.c1 = (float)(Z * f); fp.need_p0 = !(tp.k >= 0.0 || small_neg_k); break;
+    case PRL_FENG: {
+        const double g1 = 1.0 + tp.c1, r = (tp.w - 1.0) * (tp.w - 1.0) * f;
+        fp.c0 = (float)(Z * g1 * f);
+        fp.need_p0 = !(g1 >= 0.0 && (g1 * r + tp.k2 - 1.0 >= 1e-6 || tp.k2 >= 1.0));
+        break;
+    }
+    case PRL_WOLFJOLION:
+        fp.c0 = (float)tp.k;
+        fp.c1 = (float)(Z * f);
+        // T = m + (s c - k)(m - Imin) with s c in [0, k (1 + 1e-5)]: for 0 <= k <= 1 that is >= (1 - k) m + k Imin - 3e-3 > -0.5, so a
+        // black pixel can never come out white (m < Imin only by the (2w-1)/w^2 of the short window, where both factors are negative)
+        fp.need_p0 = !(tp.k >= 0.0 && tp.k <= 1.0);
+        break;
     default: return PRL_ERR_BAD_ARG;
     }
     fp.es_max = (float)(b.Es * 1.01);
