@@ -19,7 +19,10 @@ ap.add_argument("--seconds", type=float, default=120.0)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--methods", default="0,1,2,3,4", help="comma-separated method ids to draw from (2 = Wolf-Jolion)")
 ap.add_argument("--wide", type=float, default=0.0, help="probability of a window from {41..129} (the wide-window paths)")
+ap.add_argument("--hooks", type=int, default=0, help="1: load libprlib_hip_testhooks.so (reads the PRL_HIP_* knobs)")
 a = ap.parse_args()
+if a.hooks:
+    prlib_amd._capi.use_library(prlib_amd._capi.HOOKS_LIB_PATH)
 rng = np.random.default_rng(a.seed)
 dev = torch.device("cuda:0")
 METHODS = [int(m) for m in a.methods.split(",")]
