@@ -281,13 +281,18 @@ __device__ __forceinline__ void store_decision(const PageSetOut& dst, int bit_ou
 }
 
 // queue a pixel the float32 test left open: bucket = wavefront id mod kRefBuckets (see kRefBuckets in prl_internal.h)
-__device__ __forceinline__ void ref_push(RefItem* __restrict__ rl, unsigned* __restrict__ counters, PageGlobals* __restrict__ g,
+// -> true when the bucket is full: the page is flagged (the literal pipeline redoes it) and the caller stops queueing its pixels
+__device__ __forceinline__ bool ref_push(RefItem* __restrict__ rl, unsigned* __restrict__ counters, PageGlobals* __restrict__ g,
                                          unsigned wid, const RefItem& it)
 {
     const unsigned b = wid & (unsigned)(kRefBuckets - 1);
     const unsigned idx = atomicAdd(&counters[64 + kRefCounterStride * b], 1u);
-    if (idx < kRefBucketCap) rl[(size_t)b * kRefBucketCap + idx] = it;
-    else atomicOr(&g[it.page].worklist_overflow, 1u);
+    if (idx < kRefBucketCap) {
+        rl[(size_t)b * kRefBucketCap + idx] = it;
+        return false;
+    }
+    atomicOr(&g[it.page].worklist_overflow, 1u);
+    return true;
 }
 
 typedef const uint8_t __attribute__((address_space(1)))* gcptr;  // known-global pointers: global_load, not flat_load
@@ -443,6 +448,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     }
 
     float vmax_lane = 0.0f;  // Wolf sweep A
+    bool page_flagged = false;   // (wave-uniform) a push of this wavefront found its queue bucket full
     uint2 vnew_n = load_win(ys + w);  // entering row of the first iteration, fetched one iteration ahead
 #pragma unroll 1
     for (int y = ys; y < ye; ++y) {
@@ -608,7 +614,8 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
 
             // rare: some pixel of this lane is not settled by the float32 test -> queue it for k_refine
             const bool unsure = lane_has_out && !((tmin > pk.eps1) && (vmin > fp.vthr32));
-            if (__ballot(unsure) != 0ull) {
+            if (__ballot(unsure) != 0ull && !page_flagged) {   // (a flagged page is redone literally: no point in queueing more of it)
+                bool full = false;
                 if (unsure) {
     #pragma unroll 1
                     for (int c = 0; c < CPL; ++c) {
@@ -629,9 +636,10 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                         it.S = S - sbias;
                         it.Q = Q;
                         it.p = p;
-                        ref_push(rl, counters, g, wid, it);
+                        full |= ref_push(rl, counters, g, wid, it);
                     }
                 }
+                page_flagged = __ballot(full) != 0ull;
             }
 
             if (fp.bit_out) {
@@ -822,6 +830,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     // the loop-invariant column, the row travels in a scalar register - no 64-bit vector address arithmetic per row
     // (headline -0.7 %, 256 A4 pages NICK w=21 -4.9 %, tools/r3/bufpv_ab.sh)
     const int pv_col = EDGE ? ep.colc : x0;
+    bool page_flagged = false;   // (wave-uniform) a push of this wavefront found its queue bucket full
     int pv_off = ys * step;
     if (!SWEEP_A) pvb = bload8(pv_col, pv_off);
 #pragma unroll 1
@@ -944,7 +953,8 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
 
         // rare: some pixel of this lane is not settled by the float32 test -> queue it (k_refine rebuilds its sums)
         const bool unsure = lane_has_out && !((tmin > pk.eps1) && (vmin > fp.vthr32));
-        if (__ballot(unsure) != 0ull) {
+        if (__ballot(unsure) != 0ull && !page_flagged) {   // (a flagged page is redone literally: no point in queueing more of it)
+            bool full = false;
             if (unsure) {
                 unsigned qm = 0u;   // this lane's pixels to queue, one bit each
 #pragma unroll
@@ -973,9 +983,10 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
                     it.S = (unsigned)Sv;
                     it.Q = (unsigned)Qv;
                     it.p = byte_of(pvb, c) | kRefApprox;
-                    ref_push(rl, counters, g, wid, it);
+                    full |= ref_push(rl, counters, g, wid, it);
                 }
             }
+            page_flagged = __ballot(full) != 0ull;
         }
 
         if (lane_has_out) {
