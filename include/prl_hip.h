@@ -148,7 +148,7 @@ int prl_hip_binarize_geometry(const prl_binarize_params* p, int width, int heigh
  *   stream       hipStream_t or NULL
  * Everything is enqueued on `stream` (threshold sweep, interval refinement, literal fix-up - the last two find their
  * work lists on the device and do nothing when they are empty - and the morphology pass).  One thing needs the host:
- * a page with more than 2^14 pixels within ~1e-6 of their threshold (pathological input) is flagged and redone by the
+ * a page with more than 2^17 pixels within ~1e-6 of their threshold (pathological input) is flagged and redone by the
  * literal pipeline.  Default: the call waits for its own work once, looks at the flags and returns with the result
  * complete.  With prl_hip_set_deferred_completion(1) it returns right after enqueuing; the flags are looked at later
  * (a later call that needs the slot, prl_hip_last_stats, prl_hip_finish), so the caller must call

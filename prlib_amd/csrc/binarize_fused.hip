@@ -94,7 +94,7 @@ struct FusedParams {
     float vthr32;      // floor on K~ = w^2 Q - S^2 (= variance floor / f^2) below which the float32 test is not trusted
     double vthr;       // same floor for the float64 interval test
     double Em, Eq;     // |m_literal - f*S| <= Em, |q_literal - f*Q| <= Eq
-    unsigned ref_cap, wl_cap;
+    unsigned ref_cap, wl_cap;   // (ref_cap: total capacity of the refine queue, kRefBuckets x kRefBucketCap; wl_cap: fix-up / candidate lists)
     int need_p0;       // T may be negative: mask bytes of p == 0 pixels must be cleared explicitly
     float es_max;      // Wolf: bound on |s_literal - s*| for v* >= vthr (enters eps1 scaled by |k/devianceMax|)
     float rho;         // Wolf: relative error bound of the float32 variance v~
@@ -2292,7 +2292,8 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
         fp.kabs = fp.flt_a ? (float)((double)(tp.w * tp.w) * dqa * 1.01) : 0.0f;
     }
 
-    // [0] refine-list length, [1] fix-up-list length, [2] Wolf candidate-list length
+    // [1] fix-up-list length, [2] Wolf candidate-list length, [5] pages of the page-major corner kernel, [60] epilogue arrivals;
+    // words 64 ...: the refine queue's bucket counters (kRefCounterStride apart)
     auto* cnt = static_cast<unsigned*>(small);
     if (host_globals && phase == 0) {
         fp.ep_host = host_globals;

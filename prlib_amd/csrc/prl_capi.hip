@@ -613,12 +613,10 @@ SlotLayout slot_layout(int n_pages)
     return l;
 }
 
-// One overflowing page of a PRL_MODE_AUTO call, redone by the literal pipeline (and its morphology pass) from the
-// caller's own source page into the caller's destination page.  Pathological inputs only (more than 2^14 pixels of a
-// call within ~1e-6 of their threshold).
-// The flagged pages of a call (a queue overflowed) through the literal pipeline, as ONE batch: page-pointer tables on the device,
-// chunks sized by the literal scratch budget.  (Round 3 redid them one by one - a launch sequence and a workspace check per page:
-// 4 ms per 4K page against 0.4 ms in a batch.)
+// The flagged pages of a PRL_MODE_AUTO call (a queue overflowed: pathological inputs only - more than 2^21 pixels of a call inside
+// the float32 decision band, or 2^17 within ~1e-6 of their threshold), redone by the literal pipeline (and its morphology pass)
+// from the caller's own source pages into the caller's destination pages, as ONE batch: page-pointer tables on the device,
+// chunks sized by the literal scratch budget.  (Round 3 redid them one by one - a launch sequence and a workspace check per page.)
 int redo_pages_literal(StreamWs* ws, const PendingCall& pc, const std::vector<int>& idx)
 {
     const int n = (int)idx.size();
