@@ -378,6 +378,17 @@ int prl_hip_houghp_device(const uint8_t* d_image, size_t step, int width, int he
                           int line_gap, int32_t* lines, int cap, int* n_lines, void* stream);
 
 /*
+ * prl::findAngle (src/deskew/deskew.h:62, src/deskew/deskew.cpp:139-205) on 1-channel pages (the thresholded page prl::deskew
+ * hands it, :226; any 8-bit page is accepted, its points are the pixels != 255 as after the reference's bitwise_not):
+ * HoughLinesP(~page, 1, CV_PI/180, 100, width/8.f, 20), atan2 per segment, first-fit clusters of 0.01 rad, the most
+ * populated cluster's first angle in degrees; 0.0 when no segment was found.  angles (host, one per page) is required,
+ * n_segments (host, optional) receives the number of segments HoughLinesP found.  Synchronises.
+ */
+int prl_hip_find_angle_batch_device(int n_pages, const uint8_t* d_image, size_t page_stride, size_t step, int width, int height,
+                                    double* angles, int32_t* n_segments, void* stream);
+int prl_hip_find_angle_host(const uint8_t* src, size_t src_step, int width, int height, double* angle, int32_t* n_segments);
+
+/*
  * prl::deskew (src/deskew/deskew.cpp:208-251) on n_pages device pages of 1, 3 or 4 channels: gray -> Otsu -> findAngle
  * (HoughLinesP + angle vote) -> prl::rotate.  Page i's result is out_wh[2i] x out_wh[2i+1] pixels (host array):
  * max(width,height)^2 when an angle was found, width x height otherwise.  d_dst pages need room for max(width,height)

@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = [
     "prl_hip_default_chain_params", "prl_hip_chain_batch_device",
     "prl_hip_bgnorm_out_channels", "prl_hip_bgnorm_batch_device", "prl_hip_bgnorm_host",
     "prl_hip_rotate_out_size", "prl_hip_rotate_batch_device", "prl_hip_houghp_device", "prl_hip_deskew_batch_device",
-    "prl_hip_rotate_host", "prl_hip_deskew_host", "prl_hip_chain_max_out_size", "prl_hip_chain_pages_device",
+    "prl_hip_rotate_host", "prl_hip_deskew_host", "prl_hip_find_angle_batch_device", "prl_hip_find_angle_host", "prl_hip_chain_max_out_size", "prl_hip_chain_pages_device",
     "prl_hip_binarize_batch_host", "prl_hip_page_range", "prl_hip_binarize_lv_batch_device", "prl_hip_binarize_lv_host",
     "prl_hip_chain_batch_host", "prl_hip_alloc_host", "prl_hip_free_host", "prl_hip_host_register", "prl_hip_host_unregister",
 ]
@@ -160,6 +160,8 @@ def lib() -> C.CDLL:
         L.prl_hip_deskew_batch_device.argtypes = [i, i, vp, sz, sz, i, i, vp, sz, sz, vp, vp, vp]
         L.prl_hip_rotate_host.argtypes = [i, C.c_double, vp, sz, i, i, vp, sz]
         L.prl_hip_deskew_host.argtypes = [i, vp, sz, i, i, vp, sz, P(C.c_int), P(C.c_int), P(C.c_double)]
+        L.prl_hip_find_angle_batch_device.argtypes = [i, vp, sz, sz, i, i, vp, vp, vp]
+        L.prl_hip_find_angle_host.argtypes = [vp, sz, i, i, P(C.c_double), P(C.c_int32)]
         L.prl_hip_chain_max_out_size.argtypes = [P(ChainParams), i, i, P(C.c_int), P(C.c_int)]
         L.prl_hip_chain_pages_device.argtypes = [P(ChainParams), i, i, vp, sz, sz, i, i, vp, sz, sz, vp, vp, vp]
         L.prl_hip_binarize_batch_host.argtypes = [P(BinarizeParams), i, P(vp), sz, i, i, P(vp), sz, i]

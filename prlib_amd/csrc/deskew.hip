@@ -24,7 +24,7 @@
 //                        fixed-point coordinates from float64 (one rounding per operation), 5-bit bilinear weights,
 //                        (sum + 2^14) >> 15.  k_rot90<CH>: the transpose/flip branches (:38-58).
 // findOrientation (deskew.cpp:238, Leptonica pixOrientDetectDwa) is a no-op for the 1-channel page prl::deskew hands it
-// (oracle header); it is not built.
+// (oracle header); prl::findOrientation of the host layer returns that 0 (prl_host.cpp), no kernel is built for it.
 #include <algorithm>
 #include <cfloat>
 #include <climits>
@@ -1210,6 +1210,68 @@ int prl_hip_houghp_device(const uint8_t* d_image, size_t step, int width, int he
     *n_lines = (int)(out[0].size() / 4);
     for (int i = 0; i < std::min(cap, *n_lines) * 4; ++i) lines[i] = out[0][(size_t)i];
     return PRL_OK;
+}
+
+/*
+ * prl::findAngle (src/deskew/deskew.cpp:139-205) on n_pages 1-channel device pages: bitwise_not (:146), cv::HoughLinesP(input,
+ * lines, 1, CV_PI/180, 100, width/8.f, 20) (:148), atan2 per segment and the first-fit vote (:158-201).  HoughLinesP's points
+ * are the non-zero pixels of the complement, i.e. the pixels p != 255: the point stage runs on the page as it is with the
+ * fixed threshold 254 (no inverted copy).  angles / n_segments: host arrays, one entry per page.  Synchronises.
+ */
+int prl_hip_find_angle_batch_device(int n_pages, const uint8_t* d_image, size_t page_stride, size_t step, int width, int height,
+                                    double* angles, int32_t* n_segments, void* stream)
+{
+    if (width <= 0 || height <= 0) return PRL_ERR_EMPTY;
+    if (n_pages < 0 || !d_image || !angles || step < (size_t)width || std::max(width, height) > 32767) return PRL_ERR_BAD_ARG;
+    if (n_pages == 0) return PRL_OK;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    const int chunk = deskew_pages_per_pass(n_pages, width, height);
+    for (int first = 0; first < n_pages; first += chunk) {
+        const int cnt = std::min(chunk, n_pages - first);
+        PageSet g{};
+        g.base = d_image + (size_t)first * page_stride; g.page_stride = page_stride; g.step = step;
+        std::vector<std::vector<int>> lines;
+        {
+            std::lock_guard<std::mutex> lk(ctx->ppht_mu);
+            st = ppht_pages(ctx, cnt, g, width, height, 100, (int)std::lrint((double)(width / 8.f)), (int)std::lrint(20.0), false, 254,
+                            &lines, nullptr, hs);
+        }
+        if (st != PRL_OK) return st;
+        for (int i = 0; i < cnt; ++i) {
+            const int n = (int)(lines[(size_t)i].size() / 4);
+            angles[first + i] = vote_angle(lines[(size_t)i].data(), n);
+            if (n_segments) n_segments[first + i] = n;
+        }
+    }
+    return PRL_OK;
+}
+
+/* prl::findAngle on one host image (what the cv::Mat wrapper calls). */
+int prl_hip_find_angle_host(const uint8_t* src, size_t src_step, int width, int height, double* angle, int32_t* n_segments)
+{
+    if (width <= 0 || height <= 0 || !src) return PRL_ERR_EMPTY;
+    if (!angle || src_step < (size_t)width || std::max(width, height) > 32767) return PRL_ERR_BAD_ARG;
+    int dev;
+    int st = current_device(&dev);
+    if (st != PRL_OK) return st;
+    DeviceCtx* ctx = device_ctx(dev);
+    const size_t bytes = r256((size_t)width * height);
+    uint8_t* d_in = nullptr;
+    PRL_HIP_CHECK(hipMalloc(&d_in, bytes));
+    struct Free { uint8_t* p; ~Free() { (void)hipFree(p); } } free_d_in{d_in};
+    hipStream_t stream = nullptr;
+    {
+        std::lock_guard<std::mutex> slk(ctx->stage_mu);
+        st = ensure_stage_pinned(ctx, bytes);
+        if (st == PRL_OK) st = stage_upload(ctx, 0, src, src_step, (size_t)width, height, d_in, stream);
+        if (st == PRL_OK) st = hipStreamSynchronize(stream) == hipSuccess ? PRL_OK : PRL_ERR_HIP;
+    }
+    if (st != PRL_OK) return st;
+    return prl_hip_find_angle_batch_device(1, d_in, bytes, (size_t)width, width, height, angle, n_segments, stream);
 }
 
 /*

@@ -4,13 +4,19 @@
 // container nor the GPU box has OpenCV).  Only what prl::binarize*/prl::denoise and their callers
 // (samples/binarizations/binarizeSauvola_sample.cpp:48-53) use is provided: a ref-counted 8-bit
 // matrix header with rows/cols/step/data, create/clone/copyTo, ROI views, and the CV_8UCn type codes.
+//
+// The shim is a STRICT SUBSET of OpenCV's API: every name it offers exists in <opencv2/core/core.hpp> with the same
+// signature (cv::Exception's five-argument constructor, cv::Error codes, a global `uchar`, Mat's constructors and members),
+// so code that compiles against it compiles against OpenCV.  tests/test_cpp_host.py holds it to that by compiling the
+// host layer and its callers against tests/cpp/opencv_api/ (declaration-only headers with OpenCV's signatures).
 #pragma once
 
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <memory>
-#include <stdexcept>
+#include <exception>
+#include <string>
 
 #define CV_8U 0
 #define CV_CN_SHIFT 3
@@ -21,9 +27,24 @@
 #define CV_8UC4 CV_MAKETYPE(CV_8U, 4)
 #define PRL_CVMAT_SHIM 1
 
+typedef unsigned char uchar;   // global, as in opencv2/core/hal/interface.h
+
 namespace cv {
 
-typedef unsigned char uchar;
+typedef std::string String;   // opencv2/core/cvstd.hpp (4.x)
+
+namespace Error {
+enum Code {   // opencv2/core/base.hpp
+    StsOk = 0,
+    StsError = -2,
+    StsNoMem = -4,
+    StsBadArg = -5,
+    StsUnsupportedFormat = -210,
+    StsOutOfRange = -211,
+    StsAssert = -215,
+    GpuApiCallError = -217,
+};
+}  // namespace Error
 
 struct Size {
     int width = 0, height = 0;
@@ -37,9 +58,27 @@ struct Rect {
     Rect(int x_, int y_, int w, int h) : x(x_), y(y_), width(w), height(h) {}
 };
 
-class Exception : public std::runtime_error {
+// opencv2/core.hpp: class Exception : public std::exception, with exactly this constructor and these members
+class Exception : public std::exception {
 public:
-    explicit Exception(const std::string& m) : std::runtime_error(m) {}
+    Exception() : code(0), line(0) {}
+    Exception(int _code, const String& _err, const String& _func, const String& _file, int _line)
+        : code(_code), err(_err), func(_func), file(_file), line(_line)
+    {
+        formatMessage();
+    }
+    virtual ~Exception() throw() {}
+    virtual const char* what() const throw() { return msg.c_str(); }
+    void formatMessage()   // the text cv::Exception::formatMessage builds (the version prefix left out)
+    {
+        msg = file + ":" + std::to_string(line) + ": error: (" + std::to_string(code) + ") " + err;
+        if (!func.empty()) msg += " in function '" + func + "'";
+        msg += "\n";
+    }
+    String msg;
+    int code;
+    String err, func, file;
+    int line;
 };
 
 class Mat {
@@ -60,7 +99,7 @@ public:
 
     void create(int r, int c, int type)
     {
-        if (r == rows && c == cols && type == type_ && data && owner_ && step == (size_t)c * cn(type)) return;
+        if (r == rows && c == cols && type == type_ && data) return;   // as cv::Mat::create: a matching header (a ROI view too) is kept
         rows = r;
         cols = c;
         type_ = type;
@@ -98,7 +137,8 @@ public:
     Mat operator()(const Rect& r) const
     {
         if (r.x < 0 || r.y < 0 || r.width < 0 || r.height < 0 || r.x + r.width > cols || r.y + r.height > rows)
-            throw Exception("Mat ROI out of range");
+            throw Exception(Error::StsAssert, "0 <= roi.x && 0 <= roi.width && roi.x + roi.width <= m.cols && 0 <= roi.y && 0 <= roi.height && roi.y + roi.height <= m.rows",
+                            "Mat", __FILE__, __LINE__);
         Mat m(*this);
         m.data = data + (size_t)r.y * step + (size_t)r.x * channels();
         m.rows = r.height;

@@ -24,6 +24,9 @@
 #define PRL_HAVE_OPENCV 1
 #endif
 #endif
+#if defined(PRL_REQUIRE_OPENCV) && !defined(PRL_HAVE_OPENCV)
+#error "PRL_REQUIRE_OPENCV: <opencv2/core/core.hpp> was not found on the include path"
+#endif
 #ifndef PRL_HAVE_OPENCV
 #include "cvmat_shim.h"
 #endif
@@ -74,6 +77,11 @@ CV_EXPORTS void backgroundNormalization(const cv::Mat& inputImage, cv::Mat& outp
 // rotate; the result is max(cols, rows) square when an angle was found (src/rotate.cpp:64-68), a clone otherwise.
 // The orientation step (src/deskew/deskew.cpp:238) is a no-op for the page the reference hands it.
 CV_EXPORTS bool deskew(const cv::Mat& inputImage, cv::Mat& outputImage);
+// src/deskew/deskew.h:62 - the angle prl::deskew rotates by: HoughLinesP on the complement of a 1-channel (thresholded)
+// page, first-fit vote over the segments' atan2, in degrees; 0.0 when no segment is found (deskew.cpp:139-205).
+CV_EXPORTS double findAngle(const cv::Mat& inputImage);
+// src/deskew/deskew.h:52 - 0.0 (see prl_host.cpp: a no-op for the page prl::deskew hands it, deskew.cpp:70-84, :238).
+CV_EXPORTS double findOrientation(const cv::Mat& inputImage);
 CV_EXPORTS void rotate(const cv::Mat& inputImage, cv::Mat& outputImage, double angle);
 
 // BASELINE config 1 (plumbing, host only): global Otsu, the one global threshold the reference uses

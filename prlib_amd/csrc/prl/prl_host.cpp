@@ -1,27 +1,59 @@
 // prl_host.cpp — thin C++ shims: validate like the reference, hand (data, step, rows, cols) to the C ABI.
+//
+// Builds against real OpenCV (PRL_HAVE_OPENCV, set by prl.h when <opencv2/core/core.hpp> exists) and against cvmat_shim.h.
+// Only names both have are used; tests/test_cpp_host.py compiles this file against OpenCV's declared signatures
+// (tests/cpp/opencv_api/).  With OpenCV present the colour conversion is OpenCV's own cv::cvtColor, as in the reference.
 #include "prl.h"
 
 #include <stdexcept>
 #include <string>
 #include <vector>
 
+#ifdef PRL_HAVE_OPENCV
+#include <opencv2/imgproc/imgproc.hpp>   // cv::cvtColor — the header the reference includes (binarizeSauvola.cpp:29)
+#endif
+
 #include "../../../include/prl_hip.h"
 
 namespace {
 
-[[noreturn]] void raise(int status)
+// Every cv::Exception of this layer is thrown here, through the constructor OpenCV has:
+// Exception(int code, const String& err, const String& func, const String& file, int line).
+[[noreturn]] void fail_cv(int code, const std::string& err, const char* func, int line)
+{
+    throw cv::Exception(code, err, func, __FILE__, line);
+}
+#define PRL_FAIL_CV(code, err) fail_cv((code), (err), __func__, __LINE__)
+
+// A C-ABI status as the exception the reference would raise at that point.
+[[noreturn]] void raise_at(int status, const char* func, int line)
 {
     const std::string msg = prl_hip_strerror(status);
     if (status == PRL_ERR_EMPTY || status == PRL_ERR_BAD_WINDOW)
         throw std::invalid_argument(msg);  // binarizeSauvola.cpp:38-47
-    std::string detail = prl_hip_last_error_detail();
-    throw cv::Exception(detail.empty() ? msg : msg + " [" + detail + "]");
+    const std::string detail = prl_hip_last_error_detail();
+    int code = cv::Error::StsError;
+    switch (status) {
+    case PRL_ERR_BAD_CHANNELS: code = cv::Error::StsUnsupportedFormat; break;   // cvtColor / NLM reject the type
+    case PRL_ERR_EMPTY_RECT: code = cv::Error::StsAssert; break;                // the ROI assertion of cv::Mat::operator()
+    case PRL_ERR_BAD_ARG: code = cv::Error::StsBadArg; break;
+    case PRL_ERR_NO_DEVICE:
+    case PRL_ERR_HIP: code = cv::Error::GpuApiCallError; break;
+    case PRL_ERR_NOMEM: code = cv::Error::StsNoMem; break;
+    default: break;
+    }
+    fail_cv(code, detail.empty() ? msg : msg + " [" + detail + "]", func, line);
 }
+#define raise(status) raise_at((status), __func__, __LINE__)
 
 // cv::cvtColor(in, in, cv::COLOR_BGR2GRAY) on 8-bit BGR/BGRA — binarizeSauvola.cpp:51.
-// [upstream] 14-bit fixed point luma; pure per-pixel data conversion on the host.
+// With OpenCV: the installed cv::cvtColor itself (its luma coefficients differ between versions, SURVEY.md Appendix B, and
+// the reference gets whatever the machine has).  Without: the 14-bit fixed-point luma, a per-pixel conversion on the host.
 void bgr2gray_inplace(cv::Mat& m)
 {
+#ifdef PRL_HAVE_OPENCV
+    cv::cvtColor(m, m, cv::COLOR_BGR2GRAY);
+#else
     const int cn = m.channels();
     cv::Mat g(m.rows, m.cols, CV_8UC1);
     for (int y = 0; y < m.rows; ++y) {
@@ -31,6 +63,7 @@ void bgr2gray_inplace(cv::Mat& m)
             d[x] = (unsigned char)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + (1 << 13)) >> 14);
     }
     m = g;
+#endif
 }
 
 void run(int method, cv::Mat& in, cv::Mat& out, int windowSize, double k, int morph, double a1 = 0.75,
@@ -39,7 +72,7 @@ void run(int method, cv::Mat& in, cv::Mat& out, int windowSize, double k, int mo
     if (in.empty()) throw std::invalid_argument("Input image for binarization is empty");
     if (!((windowSize > 1) && ((windowSize % 2) == 1)))
         throw std::invalid_argument(prl_hip_strerror(PRL_ERR_BAD_WINDOW));
-    if (in.depth() != CV_8U) throw cv::Exception("prl: 8-bit images only");
+    if (in.depth() != CV_8U) PRL_FAIL_CV(cv::Error::StsUnsupportedFormat, "prl: 8-bit images only");
     if (in.channels() != 1) {
         if (in.channels() != 3 && in.channels() != 4) raise(PRL_ERR_BAD_CHANNELS);
         bgr2gray_inplace(in);
@@ -109,7 +142,7 @@ void prl::denoise(const cv::Mat& inputImage, cv::Mat& outputImage, double streng
 {
     // [upstream] an empty Mat has type CV_8UC1: "Type of input image should be CV_8UC3 or CV_8UC4!"
     if (inputImage.empty()) raise(PRL_ERR_BAD_CHANNELS);
-    if (inputImage.depth() != CV_8U) throw cv::Exception("prl::denoise: 8-bit images only");
+    if (inputImage.depth() != CV_8U) PRL_FAIL_CV(cv::Error::StsUnsupportedFormat, "prl::denoise: 8-bit images only");
     cv::Mat result(inputImage.rows, inputImage.cols, inputImage.type());
     const int st = prl_hip_denoise_host(inputImage.channels(), (float)strength, inputImage.data, inputImage.step,
                                         inputImage.cols, inputImage.rows, result.data, result.step);
@@ -148,9 +181,9 @@ void prl::binarizeByLocalVariancesWithoutFilters(cv::Mat& inputImage, cv::Mat& o
 void prl::backgroundNormalization(const cv::Mat& inputImage, cv::Mat& outputImage)
 {
     if (inputImage.empty()) throw std::invalid_argument("Input image for flipping is empty");  // backgroundNormalization.cpp:40-43
-    if (inputImage.depth() != CV_8U) throw cv::Exception("Cannot convert RAW image to Pix\n");   // formatConvert.cpp:103-104
+    if (inputImage.depth() != CV_8U) PRL_FAIL_CV(cv::Error::StsUnsupportedFormat, "Cannot convert RAW image to Pix\n");   // formatConvert.cpp:103-104
     const int cn = inputImage.channels();
-    if (cn != 1 && cn != 3 && cn != 4) throw cv::Exception("Cannot convert RAW image to Pix\n");
+    if (cn != 1 && cn != 3 && cn != 4) PRL_FAIL_CV(cv::Error::StsUnsupportedFormat, "Cannot convert RAW image to Pix\n");
     cv::Mat result(inputImage.rows, inputImage.cols, cn == 1 ? CV_8UC1 : CV_8UC3);
     const int st = prl_hip_bgnorm_host(cn, inputImage.data, inputImage.step, inputImage.cols, inputImage.rows, result.data,
                                        result.step);
@@ -161,7 +194,7 @@ void prl::backgroundNormalization(const cv::Mat& inputImage, cv::Mat& outputImag
 void prl::rotate(const cv::Mat& inputImage, cv::Mat& outputImage, double angle)
 {
     if (inputImage.empty()) raise(PRL_ERR_EMPTY);  // [upstream] cv::transpose / cv::warpAffine assert on an empty source
-    if (inputImage.depth() != CV_8U) throw cv::Exception("prl::rotate: 8-bit images only");
+    if (inputImage.depth() != CV_8U) PRL_FAIL_CV(cv::Error::StsUnsupportedFormat, "prl::rotate: 8-bit images only");
     int ow = 0, oh = 0;
     int st = prl_hip_rotate_out_size(inputImage.cols, inputImage.rows, angle, &ow, &oh);
     if (st != PRL_OK) raise(st);
@@ -174,8 +207,8 @@ void prl::rotate(const cv::Mat& inputImage, cv::Mat& outputImage, double angle)
 
 bool prl::deskew(const cv::Mat& inputImage, cv::Mat& outputImage)
 {
-    if (inputImage.empty()) throw cv::Exception("!inputImage.empty()");  // CV_Assert, deskew.cpp:210
-    if (inputImage.depth() != CV_8U) throw cv::Exception("prl::deskew: 8-bit images only");
+    if (inputImage.empty()) PRL_FAIL_CV(cv::Error::StsAssert, "!inputImage.empty()");  // CV_Assert, deskew.cpp:210
+    if (inputImage.depth() != CV_8U) PRL_FAIL_CV(cv::Error::StsUnsupportedFormat, "prl::deskew: 8-bit images only");
     const int len = inputImage.cols > inputImage.rows ? inputImage.cols : inputImage.rows;
     cv::Mat big(len, len, inputImage.type());
     int ow = 0, oh = 0;
@@ -184,6 +217,31 @@ bool prl::deskew(const cv::Mat& inputImage, cv::Mat& outputImage)
     if (st != PRL_OK) raise(st);
     outputImage = (ow == len && oh == len) ? big : big(cv::Rect(0, 0, ow, oh)).clone();
     return !outputImage.empty();  // deskew.cpp:245-250
+}
+
+// deskew.h:62, deskew.cpp:139-205.  The reference hands cv::HoughLinesP the complement of the page; HoughLinesP takes
+// CV_8UC1 only ([upstream] CV_Assert(image.type() == CV_8UC1)) and finds no line on an empty image, so 0.0 (:154-157).
+double prl::findAngle(const cv::Mat& inputImage)
+{
+    if (inputImage.empty()) return 0.0;
+    if (inputImage.type() != CV_8UC1) PRL_FAIL_CV(cv::Error::StsAssert, "image.type() == CV_8UC1");
+    double angle = 0.0;
+    const int st = prl_hip_find_angle_host(inputImage.data, inputImage.step, inputImage.cols, inputImage.rows, &angle, nullptr);
+    if (st != PRL_OK) raise(st);
+    return angle;
+}
+
+// deskew.h:52, deskew.cpp:70-136.  The reference fills its gray page only for 3-channel input (:73-76), thresholds it
+// (cv::adaptiveThreshold, :78) and asks Leptonica's pixOrientDetectDwa / makeOrientDecision for one of four orientations
+// (:91, :101).  prl::deskew - its only caller (:238) - always hands it the 1-channel thresholded page, for which the gray page
+// is EMPTY: the function leaves through its NULL-pix exit with 0 (:80-84) or throws inside adaptiveThreshold, depending on the
+// OpenCV version.  This layer returns that 0.0 for every input: the orientation step of the hot path is a no-op
+// (SURVEY.md Appendix D), and Leptonica's DWA text-orientation detector is outside the
+// path's scope.  A 3-channel caller therefore always gets "up" (L_TEXT_ORIENT_UNKNOWN -> 0.0, :125-128).
+double prl::findOrientation(const cv::Mat& inputImage)
+{
+    (void)inputImage;
+    return 0.0;
 }
 
 namespace {

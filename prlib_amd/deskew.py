@@ -1,6 +1,8 @@
 """Host-side mirror of prl::deskew / prl::rotate (src/deskew/deskew.cpp:208-251, src/rotate.cpp:35-72) over the C ABI.
 
     bool prl::deskew(const cv::Mat& inputImage, cv::Mat& outputImage)
+    double prl::findAngle(const cv::Mat& inputImage)                       (src/deskew/deskew.h:62, deskew.cpp:139-205)
+    double prl::findOrientation(const cv::Mat& inputImage)                 (src/deskew/deskew.h:52, deskew.cpp:70-136)
     void prl::rotate(const cv::Mat& inputImage, cv::Mat& outputImage, double angle)
 
 Pages are torch CUDA uint8 tensors N x H x W x C (C in 1, 3, 4; a 3-d tensor is N x H x W gray).  Every deskewed page
@@ -66,6 +68,35 @@ def deskew(pages):
                                               buf.stride(0), buf.stride(1), wh.ctypes.data, ang.ctypes.data, stream))
     outs = [buf[i, : wh[i, 1], : wh[i, 0]] for i in range(n)]
     return (outs if pages.dim() == 4 else [o[:, :, 0] for o in outs]), ang
+
+
+def find_angle(pages, return_segments: bool = False):
+    """prl::findAngle per 1-channel page (N x H x W, or one H x W page) -> angles in degrees (float64 numpy; a float for a
+    single page).  The points of the Hough transform are the pixels != 255, as after the reference's bitwise_not."""
+    import torch
+
+    single = pages.dim() == 2
+    t = pages[None] if single else pages
+    if t.dtype != torch.uint8 or not t.is_cuda or t.dim() != 3 or t.stride(2) != 1:
+        raise TypeError("expected an [N x] H x W uint8 CUDA tensor (cv::HoughLinesP takes CV_8UC1)")
+    n, h, w = t.shape
+    ang = np.zeros(n, dtype=np.float64)
+    nseg = np.zeros(n, dtype=np.int32)
+    L = _capi.lib()
+    _capi.check(L.prl_hip_set_device(t.device.index or 0))
+    stream = torch.cuda.current_stream(t.device).cuda_stream
+    _capi.check(L.prl_hip_find_angle_batch_device(n, t.data_ptr(), t.stride(0), t.stride(1), w, h, ang.ctypes.data,
+                                                  nseg.ctypes.data, stream))
+    a = float(ang[0]) if single else ang
+    return (a, (int(nseg[0]) if single else nseg)) if return_segments else a
+
+
+def find_orientation(pages):
+    """prl::findOrientation.  The reference builds its gray page only for 3-channel input (deskew.cpp:73-76) and then needs
+    Leptonica's pixOrientDetectDwa (:91); for the 1-channel page prl::deskew hands it (:238) the gray page is empty and the
+    function returns 0 through its NULL-pix exit (:81-84) or throws, depending on the OpenCV version.  Canonical result: 0.0
+    (SURVEY.md Appendix D)."""
+    return 0.0 if pages.dim() == 2 else np.zeros(pages.shape[0], dtype=np.float64)
 
 
 def houghp(image, threshold: int, line_length: int, line_gap: int) -> np.ndarray:

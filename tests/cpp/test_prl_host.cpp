@@ -67,6 +67,11 @@ static void test_validation()
     bool threw_cv = false;
     try { prl::deskew(empty, out); } catch (const cv::Exception&) { threw_cv = true; } catch (...) {}
     CHECK(threw_cv);  // CV_Assert(!inputImage.empty()), deskew.cpp:210
+    CHECK(prl::findAngle(empty) == 0.0 && prl::findOrientation(empty) == 0.0);   // no lines on an empty page, deskew.cpp:154-157
+    threw_cv = false;
+    cv::Mat bgr(16, 16, CV_8UC3);
+    try { prl::findAngle(bgr); } catch (const cv::Exception& e) { threw_cv = e.code == cv::Error::StsAssert; } catch (...) {}
+    CHECK(threw_cv);  // [upstream] cv::HoughLinesP: CV_Assert(image.type() == CV_8UC1)
     // global Otsu plumbing (host only): bimodal page splits between the modes
     cv::Mat bi(64, 64, CV_8UC1), bo;
     for (int y = 0; y < 64; ++y)
@@ -275,6 +280,28 @@ static void test_gpu_round2()
         size_t bad = 0;
         for (int y = 0; y < out.rows && out.cols == ow; ++y) bad += std::memcmp(out.ptr(y), &want[(size_t)y * ow * ch], (size_t)ow * ch) != 0;
         CHECK(bad == 0);
+    }
+    // prl::findAngle (deskew.h:62) on the thresholded page prl::deskew would hand it (deskew.cpp:224-226): the oracle's angle,
+    // through a continuous Mat and through a ROI view (step > cols); prl::findOrientation (deskew.h:52) is 0.0
+    {
+        cv::Mat gray = text_page(300, 420, 0.04, 1), bin(300, 420, CV_8UC1);
+        prl_oracle_otsu(gray.data, gray.step, 420, 300, bin.data, bin.step);
+        int nl = 0;
+        const double want = prl_oracle_find_angle(bin.data, bin.step, 420, 300, &nl);
+        CHECK(nl > 5 && want != 0.0);
+        const cv::Mat keep = bin.clone();
+        CHECK(prl::findAngle(bin) == want);
+        CHECK(std::memcmp(bin.data, keep.data, (size_t)300 * 420) == 0);   // const input: untouched (the reference clones, :144)
+        cv::Mat wide(300, 500, CV_8UC1);
+        std::memset(wide.data, 255, (size_t)300 * 500);
+        cv::Mat view = wide(cv::Rect(37, 0, 420, 300));
+        bin.copyTo(view);
+        CHECK(view.data == wide.data + 37 && !view.isContinuous());
+        CHECK(prl::findAngle(view) == want);
+        cv::Mat white(200, 300, CV_8UC1);
+        std::memset(white.data, 255, (size_t)200 * 300);
+        CHECK(prl::findAngle(white) == 0.0);   // no points, no segment: 0.0 (:154-157)
+        CHECK(prl::findOrientation(bin) == 0.0);
     }
     // prl::binarizeByLocalVariancesWithoutFilters (integer-exact) and binarizeByLocalVariances (float32 log / exp: tolerance)
     {

@@ -70,3 +70,20 @@ def test_work_pool_many_callers():
     subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s", "test_work_pool"], check=True)
     r = subprocess.run([os.path.join(os.path.join(ROOT, "tests", "cpp"), "test_work_pool")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "work_pool: OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_boundary_compiles_against_opencv_signatures():
+    """The OpenCV-present branch of the C++ boundary (prl.h: PRL_HAVE_OPENCV).  No box of this pool has OpenCV, so that
+    branch is compiled - syntax only - against tests/cpp/opencv_api/: declaration-only headers carrying OpenCV's real
+    signatures for the members the host layer and its callers use (cv::Exception(int, const String&, const String&, const
+    String&, int), MatStep / MatSize, _InputArray / _OutputArray, cv::cvtColor).  A use of anything only cvmat_shim.h offers
+    fails here.  Also the converse: the shim's own Exception has no other public constructor."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    r = subprocess.run(["make", "-C", cpp, "-s", "conformance"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # the check discriminates: the one-string constructor the old shim offered is rejected by the same compile
+    probe = ('#include "%s"\nvoid f() { throw cv::Exception("one string"); }\n'
+             % os.path.join(ROOT, "prlib_amd", "csrc", "prl", "prl.h"))
+    for inc in (["-I" + os.path.join(cpp, "opencv_api"), "-DPRL_REQUIRE_OPENCV"], []):   # OpenCV's API, then the shim
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", "-"] + inc, input=probe, capture_output=True, text=True)
+        assert r.returncode != 0 and "Exception" in r.stderr, r.stderr

@@ -30,6 +30,43 @@ def test_houghp_segments_equal_oracle(prl, oracle, cuda_device):
     assert len(prl.houghp(torch.zeros((40, 50), dtype=torch.uint8, device=cuda_device), 10, 10, 2)) == 0
 
 
+def test_find_angle_equals_oracle(prl, oracle, cuda_device):
+    """prl::findAngle (deskew.h:62, deskew.cpp:139-205) as an entry point of its own: the thresholded page prl::deskew hands
+    it (:224-226), a batch with per-page angles, a strided view, a page without points, and the cv::Mat wrapper's host form."""
+    import ctypes as C
+
+    import torch
+    from prlib_amd import _capi
+
+    pages, want, nseg = [], [], []
+    for i, skew in enumerate((2.0, -3.5, 0.0, 7.0)):
+        p = synth.text_page_numpy(300, 420, 20 + i, skew_deg=skew)
+        _, binary = oracle.otsu(p)
+        a, n = oracle.find_angle(binary)
+        pages.append(binary); want.append(a); nseg.append(n)
+    assert sum(a != 0.0 for a in want) >= 2 and min(nseg) > 5
+    t = torch.from_numpy(np.stack(pages)).to(cuda_device)
+    got, got_n = prl.findAngle(t, return_segments=True)
+    assert got.tolist() == want and got_n.tolist() == nseg          # exact: same segments, same host atan2 / vote
+    assert prl.findAngle(t[1]) == want[1]
+    # rows 500 bytes apart (a cv::Mat ROI)
+    wide = torch.full((4, 300, 500), 255, dtype=torch.uint8, device=cuda_device)
+    wide[:, :, 37:457] = t
+    assert prl.findAngle(wide[:, :, 37:457]).tolist() == want
+    # no point at all (every pixel 255) -> no segment -> 0.0 (deskew.cpp:154-157); a gray page: points are the pixels != 255
+    assert prl.findAngle(torch.full((120, 200), 255, dtype=torch.uint8, device=cuda_device)) == 0.0
+    g = synth.text_page_numpy(200, 260, 3, skew_deg=1.0)
+    assert prl.findAngle(torch.from_numpy(g).to(cuda_device)) == oracle.find_angle(g)[0]
+    assert np.array_equal(prl.findOrientation(t), np.zeros(4))
+    # host form
+    ang, n = C.c_double(-1.0), C.c_int32(-1)
+    b = np.ascontiguousarray(pages[0])
+    _capi.check(_capi.lib().prl_hip_find_angle_host(b.ctypes.data, b.strides[0], 420, 300, C.byref(ang), C.byref(n)))
+    assert ang.value == want[0] and n.value == nseg[0]
+    assert _capi.lib().prl_hip_find_angle_host(b.ctypes.data, 100, 420, 300, C.byref(ang), None) == _capi.PRL_ERR_BAD_ARG
+    assert _capi.lib().prl_hip_find_angle_host(None, 420, 420, 300, C.byref(ang), None) == _capi.PRL_ERR_EMPTY
+
+
 @pytest.mark.parametrize("c", [1, 3, 4])
 @pytest.mark.parametrize("angle", [0.0, 3.0, -7.25, 45.0, 90.0, 180.0, 270.0, 450.0, 359.999, 1e-9, 123.456])
 def test_rotate_matches_oracle(prl, oracle, cuda_device, c, angle):
