@@ -308,9 +308,10 @@ def main():
         pdist.barrier()
         slowest = pdist.max_over_ranks(float(rank + 1))
         total = pdist.sum_over_ranks(float(len(mine)))
+        blocks = pdist.gather_lists([[mine.start, mine.stop]])   # every rank's block, in rank order
         if rank == 0:
             print(json.dumps({"dryrun": True, "n_gpus": world, "pages_total": int(total), "max_rank_plus_1": slowest,
-                              "first_block": [mine.start, mine.stop],
+                              "first_block": [mine.start, mine.stop], "blocks": blocks,
                               "scaling": "weak" if args.scaling == "both" else args.scaling,
                               "strong_ride_along": args.scaling == "both"}), flush=True)
         pdist.finish()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PRL_HIP_ABI_VERSION 3   /* 2: prl_chain_params grew deskew / background_normalization; 3: prl_hip_last_call_ms, prl_binarize_stats.wolf_candidates */
+#define PRL_HIP_ABI_VERSION 4   /* 2: prl_chain_params grew deskew / background_normalization; 3: prl_hip_last_call_ms, prl_binarize_stats.wolf_candidates; 4: prl_hip_find_angle_*, prl_deskew_stats */
 
 typedef enum prl_status {
     PRL_OK = 0,
@@ -376,6 +376,25 @@ int prl_hip_rotate_batch_device(int n_pages, int channels, const double* angles,
  * *n_lines = number found (may exceed cap).  Synchronises. */
 int prl_hip_houghp_device(const uint8_t* d_image, size_t step, int width, int height, int threshold, int line_length,
                           int line_gap, int32_t* lines, int cap, int* n_lines, void* stream);
+
+/* Diagnostics of the HoughLinesP searches (prl::deskew, prl::findAngle, the chain's deskew stage, prl_hip_houghp_device)
+ * accumulated process-wide since the last reset - the chain searches on a helper thread, so these are not per thread.
+ * The point and segment lists are sized per page from the page's ink before the search: `segment_capacity` is the room the
+ * segment lists had, `min_page_headroom` the smallest (capacity - segments found) of any page.  A page that needed more
+ * room than it had makes its call fail with PRL_ERR_NOMEM ("HoughLinesP: segment list overflow"): nothing is clipped
+ * silently, and a negative headroom is only ever seen together with that error. */
+typedef struct prl_deskew_stats {
+    uint64_t pages;              /* pages searched */
+    uint64_t points;             /* non-zero pixels handed to HoughLinesP */
+    uint64_t segments;           /* segments found */
+    uint64_t segment_capacity;   /* room of the segment lists */
+    uint64_t max_page_points;
+    uint64_t max_page_segments;
+    int64_t  min_page_headroom;  /* min over pages of capacity - segments */
+    uint64_t reserved;
+} prl_deskew_stats;
+int prl_hip_last_deskew_stats(prl_deskew_stats* out);
+int prl_hip_reset_deskew_stats(void);
 
 /*
  * prl::findAngle (src/deskew/deskew.h:62, src/deskew/deskew.cpp:139-205) on 1-channel pages (the thresholded page prl::deskew

@@ -8,7 +8,7 @@ from . import _capi, binarizations  # noqa: F401
 from .denoise import denoise, nlm_planes  # noqa: F401
 from .thinning import thinGuoHall, thinZhangSuen  # noqa: F401
 from .background import backgroundNormalization  # noqa: F401
-from .deskew import deskew, find_angle as findAngle, find_orientation as findOrientation, houghp, rotate  # noqa: F401
+from .deskew import deskew, deskew_stats, find_angle as findAngle, find_orientation as findOrientation, houghp, rotate  # noqa: F401
 from .chain import bitwise_not, cvtColorBGR2GRAY, cvtColorGRAY2BGR, process_pages, process_pages_host  # noqa: F401
 from .binarizations import (  # noqa: F401
     FENG, NICK, NIBLACK, SAUVOLA, WOLFJOLION, binarize, binarizeFeng, binarizeNICK, binarizeNiblack,
@@ -18,6 +18,6 @@ from .binarizations import (  # noqa: F401
 
 __all__ = [
     "binarize", "binarizeSauvola", "binarizeNiblack", "binarizeWolfJolion", "binarizeNICK", "binarizeFeng", "binarizeByLocalVariances", "binarizeByLocalVariancesWithoutFilters",
-    "denoise", "nlm_planes", "backgroundNormalization", "deskew", "rotate", "houghp", "findAngle", "findOrientation", "thinZhangSuen", "thinGuoHall", "cvtColorBGR2GRAY", "cvtColorGRAY2BGR", "bitwise_not", "process_pages", "process_pages_host", "make_params", "default_params", "geometry", "last_stats", "morph", "set_exec_mode", "set_deferred_completion", "finish", "binarize_pages_host", "PinnedPages",
+    "denoise", "nlm_planes", "backgroundNormalization", "deskew", "rotate", "houghp", "findAngle", "findOrientation", "deskew_stats", "thinZhangSuen", "thinGuoHall", "cvtColorBGR2GRAY", "cvtColorGRAY2BGR", "bitwise_not", "process_pages", "process_pages_host", "make_params", "default_params", "geometry", "last_stats", "morph", "set_exec_mode", "set_deferred_completion", "finish", "binarize_pages_host", "PinnedPages",
     "SAUVOLA", "NIBLACK", "WOLFJOLION", "NICK", "FENG",
 ]

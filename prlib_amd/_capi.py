@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = [
     "prl_hip_default_chain_params", "prl_hip_chain_batch_device",
     "prl_hip_bgnorm_out_channels", "prl_hip_bgnorm_batch_device", "prl_hip_bgnorm_host",
     "prl_hip_rotate_out_size", "prl_hip_rotate_batch_device", "prl_hip_houghp_device", "prl_hip_deskew_batch_device",
-    "prl_hip_rotate_host", "prl_hip_deskew_host", "prl_hip_find_angle_batch_device", "prl_hip_find_angle_host", "prl_hip_chain_max_out_size", "prl_hip_chain_pages_device",
+    "prl_hip_rotate_host", "prl_hip_deskew_host", "prl_hip_find_angle_batch_device", "prl_hip_find_angle_host", "prl_hip_last_deskew_stats", "prl_hip_reset_deskew_stats", "prl_hip_chain_max_out_size", "prl_hip_chain_pages_device",
     "prl_hip_binarize_batch_host", "prl_hip_page_range", "prl_hip_binarize_lv_batch_device", "prl_hip_binarize_lv_host",
     "prl_hip_chain_batch_host", "prl_hip_alloc_host", "prl_hip_free_host", "prl_hip_host_register", "prl_hip_host_unregister",
 ]

@@ -14,6 +14,7 @@ the owner of the device memory and the stream).  Compute always happens in libpr
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -71,33 +72,39 @@ def last_stats() -> BinarizeStats:
     return s
 
 
+def _free_pinned(address: int) -> None:
+    try:
+        _capi.lib().prl_hip_free_host(C.c_void_p(address))
+    except Exception:   # interpreter shutdown
+        pass
+
+
 class PinnedPages:
-    """N x H x W uint8 pages in pinned host memory (prl_hip_alloc_host): `array` is a numpy view; the memory is freed by
-    close() / the context manager.  Pages in such memory are moved by DMA directly (no bounce copies)."""
+    """N x H x W uint8 pages in pinned host memory (prl_hip_alloc_host): `array` is a numpy view.  Pages in such memory are
+    moved by DMA directly (no bounce copies).
+
+    Lifetime: the block belongs to the BUFFER the views are made of, not to this wrapper - it is freed when the last numpy view
+    of it (`array`, slices, `list(pin.array)`) is gone, so `PinnedPages(n, h, w).array` or pages that outlive the wrapper stay
+    valid (and valid DMA targets).  close() / the context manager free it at once; the caller then must not touch views it
+    still holds."""
 
     def __init__(self, n: int, h: int, w: int):
-        self._ptr = C.c_void_p()
-        _capi.check(_capi.lib().prl_hip_alloc_host(max(1, n * h * w), C.byref(self._ptr)))
-        buf = (C.c_uint8 * (n * h * w)).from_address(self._ptr.value)
+        ptr = C.c_void_p()
+        _capi.check(_capi.lib().prl_hip_alloc_host(max(1, n * h * w), C.byref(ptr)))
+        buf = (C.c_uint8 * (n * h * w)).from_address(ptr.value)
+        # every view keeps `buf` alive through its .base chain; the finalizer runs when the last one dies (or at close())
+        self._finalizer = weakref.finalize(buf, _free_pinned, ptr.value)
         self.array = np.frombuffer(buf, dtype=np.uint8).reshape(n, h, w)
 
     def close(self):
-        if self._ptr is not None and self._ptr.value:
-            self.array = None
-            _capi.check(_capi.lib().prl_hip_free_host(self._ptr))
-            self._ptr = None
+        self.array = None
+        self._finalizer()   # idempotent
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
         self.close()
-
-    def __del__(self):   # a forgotten close() must not leak pinned memory
-        try:
-            self.close()
-        except Exception:
-            pass
 
 
 def binarize_pages_host(pages, params: BinarizeParams, n_devices: int = 0, out=None):

@@ -21,9 +21,12 @@
 //
 // Memory: 1 B/px read + 1 B/px written to HBM (the algorithmic 2 B/px); window halos, the "leaving" row of
 // the sliding window and the compared-pixel row are re-read through L2 / Infinity Cache (measured 20 GB of
-// fabric traffic per 8.6 GB algorithmic).  Roofline by the metric: HBM; the measured limiter is VALU issue
-// (~630-680 SIMD cycles per 512-column wavefront-row, instruction costs in profiles/r01/valu_issue_costs.txt),
-// see DESIGN.md 4.1.
+// fabric traffic per 8.6 GB algorithmic).  Roofline by the metric: HBM (0.335 of 8 TB/s on the driver's run).  The row
+// loop is balanced against four pipes, none saturated: per 512-column wavefront-row of an interior strip 149 vector
+// instructions (117 two-cycle, 24 four-cycle, 8 v_sqrt_f32: ~450 SIMD cycles of issue; edge strips 199, ~650), 42 scalar
+// ones, 14 ds_bpermute, 6 vector-memory instructions, against ~710 measured cycles: vector issue ~0.7, vector memory
+// 0.5-0.8, LDS ~0.5 of the time (tools/isa_budget.py reads this from the compiler's output; instruction costs in
+// profiles/r01/valu_issue_costs.txt).  Perfect overlap would end at ~0.48 of the HBM roofline; see DESIGN.md 4.1.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -95,6 +98,7 @@ struct FusedParams {
     double vthr;       // same floor for the float64 interval test
     double Em, Eq;     // |m_literal - f*S| <= Em, |q_literal - f*Q| <= Eq
     unsigned ref_cap, wl_cap;   // (ref_cap: total capacity of the refine queue, kRefBuckets x kRefBucketCap; wl_cap: fix-up / candidate lists)
+    unsigned cand_page_cap;     // Wolf-Jolion sweep B: candidates one page may queue before it is marked cand_overflow
     int need_p0;       // T may be negative: mask bytes of p == 0 pixels must be cleared explicitly
     float es_max;      // Wolf: bound on |s_literal - s*| for v* >= vthr (enters eps1 scaled by |k/devianceMax|)
     float rho;         // Wolf: relative error bound of the float32 variance v~
@@ -560,23 +564,55 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                 // parts in 10^9 (k_wolf_interval) - all the sweeps and k_refine need; the candidates themselves are only
                 // evaluated literally when a pixel of the page reaches the literal fix-up (k_wolf_literal)
                 unsigned long long kbest = 0ull;
+                unsigned mine = 0u;   // bit c: pixel c of this lane is a candidate
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
                     if (lane_has_out && (x0 + c < tp.ow) && vv[c] >= pk.c1) {
                         const unsigned long long s64 = (unsigned long long)(Ssum[c] - sbias);
                         const unsigned long long k64 = (unsigned long long)(unsigned)(w * w) * (unsigned long long)Qsum[c] - s64 * s64;
                         kbest = k64 > kbest ? k64 : kbest;
-                        atomicAdd(&g[page].n_cand, 1u);
-                        const unsigned idx = atomicAdd(&counters[2], 1u);
-                        if (idx < fp.wl_cap) {
-                            WorkItem it;
-                            it.page = page;
-                            it.y = y;
-                            it.x = x0 + c;
-                            it.pad = 0;
-                            cand[idx] = it;
-                        } else {
-                            atomicOr(&g[page].cand_overflow, 1u);
+                        mine |= 1u << c;
+                    }
+                }
+                // The list slots of a wavefront-row are taken with ONE atomic on the page's counter and one on the list's (a
+                // flat page makes every pixel a candidate: two same-address atomics per pixel serialised 8.7 million times
+                // per A4 page).  A page may queue fp.cand_page_cap candidates; past that it is marked cand_overflow - the
+                // literal pipeline redoes it if it ever needs its literal maximum - and this wavefront stops queueing
+                // (page_flagged), so that one blank page neither stalls the side stream nor eats the other pages' room.
+                if (!page_flagged) {
+                    const unsigned cnt = (unsigned)__popc(mine);
+                    unsigned incl = cnt;
+#pragma unroll
+                    for (int d = 1; d < kWave; d <<= 1) {
+                        const unsigned t = (unsigned)__shfl_up((int)incl, d, kWave);
+                        if (lane >= d) incl += t;
+                    }
+                    const unsigned total = (unsigned)__shfl((int)incl, kWave - 1, kWave);
+                    unsigned base = 0xffffffffu;
+                    if (lane == 0) {
+                        const unsigned before = atomicAdd(&g[page].n_cand, total);
+                        if (before + total <= fp.cand_page_cap) base = atomicAdd(&counters[2], total);
+                    }
+                    base = (unsigned)__shfl((int)base, 0, kWave);
+                    if (base == 0xffffffffu || base + total > fp.wl_cap) {
+                        if (lane == 0) atomicOr(&g[page].cand_overflow, 1u);
+                        page_flagged = true;
+                    }
+                    if (base != 0xffffffffu) {   // (slots below the list's end are always written: the counter has moved past them)
+                        unsigned idx = base + incl - cnt;
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c) {
+                            if ((mine >> c) & 1u) {
+                                if (idx < fp.wl_cap) {
+                                    WorkItem it;
+                                    it.page = page;
+                                    it.y = y;
+                                    it.x = x0 + c;
+                                    it.pad = 0;
+                                    cand[idx] = it;
+                                }
+                                ++idx;
+                            }
                         }
                     }
                 }
@@ -1826,7 +1862,7 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
 template <int METHOD>
 int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
                  PageGlobals* g, RefItem* rl, WorkItem* wl, WorkItem* cand, CornerAcc* acc, unsigned* cnt,
-                 hipEvent_t ev_start, hipEvent_t ev_stop, bool with_fixup, int n_pages, const GroupArrays& ga,
+                 hipEvent_t ev_start, hipEvent_t ev_stop, int n_pages, const GroupArrays& ga,
                  hipEvent_t before_refine = nullptr, CornerAcc* cacc = nullptr)
 {
     if (ev_start) PRL_HIP_CHECK(hipEventRecord(ev_start, stream));
@@ -1866,7 +1902,6 @@ int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
         hipLaunchKernelGGL(k_wolf_literal_coeff, dim3((n_pages + 63) / 64), dim3(64), 0, stream, fp, g, n_pages, cnt);
         PRL_HIP_CHECK(hipGetLastError());
     }
-    if (!with_fixup) return PRL_OK;
     // literal fix-up of what k_refine queued: the kernel reads the queue length on the device and does nothing when it is
     // empty (the usual case), so no host round trip decides whether it runs; k_refine zeroed the accumulators it uses; the
     // workgroup that delivers a pixel's last partial sum evaluates the pixel (no separate k_fixup_final launch)
@@ -2139,11 +2174,9 @@ int fused_max_pages(const ThrParams& tp)
     return (int)std::max<long long>(1, (long long)env_knobs().segmax_cap / (n_strips * n_segs));
 }
 
-// phase 0: the whole pipeline; 1: everything up to and including k_refine; 2: only the literal fix-up of the pixels
-// k_refine queued in an earlier phase-1 call with the same arguments (the caller reads PageGlobals::n_exact in between
-// and skips phase 2 - two launches and a 1 MB memset - when nothing was queued, the usual case)
+// The whole pipeline of one call: threshold sweep, k_refine, literal fix-up (the last two find their queues on the device).
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst, void* small,
-              PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool bit_out, int phase,
+              PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool bit_out,
               bool counters_zeroed, PageGlobals* host_globals, const WolfSide* wolf_side)
 {
     FusedParams fp{};
@@ -2254,6 +2287,9 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.eps1 = (float)(b.eps1 * 1.01 * Z);
     fp.ref_cap = kRefineCap;
     fp.wl_cap = kWorkCap;
+    // a page's share of the candidate list: the whole list for a single page, never less than a quarter of it in a batch
+    // (real scans queue ~400 candidates a page, profiles/r04/real_scans.jsonl; a flat page would queue every pixel)
+    fp.cand_page_cap = n_pages <= 1 ? kWorkCap : kWorkCap / 4;
     // need_p0 = 0 only where T > -0.5 for every window, so a black pixel can never come out white in the float32 sign test (the
     // literal clamps T8 at 0).  Beyond T >= 0 two families qualify: a small negative k of Niblack / NICK - s <= sqrt(q) and
     // q <= 255 m (Q = sum P^2 <= 255 sum P), so T >= m - |k| sqrt(255 m) >= -k^2 255 / 4, above -0.45 for |k| < 0.084 (NICK's header
@@ -2295,7 +2331,7 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     // [1] fix-up-list length, [2] Wolf candidate-list length, [5] pages of the page-major corner kernel, [60] epilogue arrivals;
     // words 64 ...: the refine queue's bucket counters (kRefCounterStride apart)
     auto* cnt = static_cast<unsigned*>(small);
-    if (host_globals && phase == 0) {
+    if (host_globals) {
         fp.ep_host = host_globals;
         fp.ep_dev = d_globals;
         fp.ep_counters = cnt;
@@ -2312,13 +2348,6 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     ga.pstart = ga.sidx + kWorkCap;
     ga.pcur = ga.pstart + n_pages + 1;
     ga.plist = ga.pcur + n_pages;
-    if (phase == 2) {  // (kept for callers that split the pipeline; k_refine of phase 1 zeroed what this uses)
-        unsigned* done = reinterpret_cast<unsigned*>(fp.segmax + kSegmaxCap);
-        hipLaunchKernelGGL(k_corner_partial<true>, dim3(kSplit, 128), dim3(256), 0, stream, src, fp, wl, cnt, 1, acc, dst, d_globals, done);
-        PRL_HIP_CHECK(hipGetLastError());
-        return PRL_OK;
-    }
-    const bool with_fixup = phase == 0;
     if (!counters_zeroed) PRL_HIP_CHECK(hipMemsetAsync(cnt, 0, kFusedCounterBytes, stream));
 
     if (tp.method == PRL_FENG) {
@@ -2359,45 +2388,52 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
             PRL_HIP_CHECK(hipGetLastError());
             return PRL_OK;
         };
-        int st;
-        if (wolf_side) {
-            PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_fork, stream));          // (globals and counters are initialised)
-            PRL_HIP_CHECK(hipStreamWaitEvent(ss, wolf_side->ev_fork, 0));
-        }
-        PRL_HIP_CHECK(hipMemsetAsync(cacc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, ss));   // (only the lazy literal path uses it)
-        st = border_min(ss);
-        if (st != PRL_OK) return st;
-        if (wolf_side) PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_min, ss));
-        st = launch_sweep<kWolfMax>(sh, stream, src, dst, fp, d_globals, rl, cand, cnt);
-        if (st != PRL_OK) return st;
-        if (wolf_side) {
-            PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_a, stream));
-            PRL_HIP_CHECK(hipStreamWaitEvent(ss, wolf_side->ev_a, 0));
-        }
-        st = launch_sweep<kWolfCollect>(sh, ss, src, dst, fp, d_globals, rl, cand, cnt);
-        if (st != PRL_OK) return st;
-        hipLaunchKernelGGL(k_wolf_interval, dim3((n_pages + 63) / 64), dim3(64), 0, ss, fp, d_globals, n_pages);
-        PRL_HIP_CHECK(hipGetLastError());
-        if (env_knobs().debug) {
-            unsigned hc[4] = {0, 0, 0, 0};
-            (void)hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, ss);
-            (void)hipStreamSynchronize(ss);
-            std::fprintf(stderr, "[prl_hip] Wolf-Jolion: %u maximum-deviation candidates on %d pages (cap %u)\n", hc[2], n_pages, fp.wl_cap);
-        }
-        hipEvent_t before_refine = nullptr;
-        if (wolf_side) {
-            PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_coeff, ss));
-            PRL_HIP_CHECK(hipStreamWaitEvent(stream, wolf_side->ev_min, 0));   // the threshold sweep needs the whole page minimum
-            before_refine = wolf_side->ev_coeff;
-        }
-        return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, n_pages, ga,
-                                            before_refine, cacc);
+        // Between the fork and the join the side stream reads the caller's pages: an error return in that span first waits
+        // for it (the API must not hand an error back while its kernels still run on the caller's memory).
+        auto forked = [&]() -> int {
+            int st;
+            if (wolf_side) {
+                PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_fork, stream));          // (globals and counters are initialised)
+                PRL_HIP_CHECK(hipStreamWaitEvent(ss, wolf_side->ev_fork, 0));
+            }
+            PRL_HIP_CHECK(hipMemsetAsync(cacc, 0, sizeof(CornerAcc) * (size_t)kWorkCap, ss));   // (only the lazy literal path uses it)
+            st = border_min(ss);
+            if (st != PRL_OK) return st;
+            if (wolf_side) PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_min, ss));
+            st = launch_sweep<kWolfMax>(sh, stream, src, dst, fp, d_globals, rl, cand, cnt);
+            if (st != PRL_OK) return st;
+            if (wolf_side) {
+                PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_a, stream));
+                PRL_HIP_CHECK(hipStreamWaitEvent(ss, wolf_side->ev_a, 0));
+            }
+            st = launch_sweep<kWolfCollect>(sh, ss, src, dst, fp, d_globals, rl, cand, cnt);
+            if (st != PRL_OK) return st;
+            hipLaunchKernelGGL(k_wolf_interval, dim3((n_pages + 63) / 64), dim3(64), 0, ss, fp, d_globals, n_pages);
+            PRL_HIP_CHECK(hipGetLastError());
+            if (env_knobs().debug) {
+                unsigned hc[4] = {0, 0, 0, 0};
+                (void)hipMemcpyAsync(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost, ss);
+                (void)hipStreamSynchronize(ss);
+                std::fprintf(stderr, "[prl_hip] Wolf-Jolion: %u maximum-deviation candidates on %d pages (cap %u)\n", hc[2], n_pages, fp.wl_cap);
+            }
+            hipEvent_t before_refine = nullptr;
+            if (wolf_side) {
+                PRL_HIP_CHECK(hipEventRecord(wolf_side->ev_coeff, ss));
+                PRL_HIP_CHECK(hipStreamWaitEvent(stream, wolf_side->ev_min, 0));   // the threshold sweep needs the whole page minimum
+                before_refine = wolf_side->ev_coeff;
+            }
+            return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga,
+                                                before_refine, cacc);
+        };
+        const int st = forked();
+        if (st != PRL_OK && wolf_side) (void)hipStreamSynchronize(wolf_side->stream);
+        return st;
     }
     switch (tp.method) {
-    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, n_pages, ga);
-    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, n_pages, ga);
-    case PRL_NICK: return launch_fused<PRL_NICK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, n_pages, ga);
-    case PRL_FENG: return launch_fused<PRL_FENG>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, with_fixup, n_pages, ga);
+    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga);
+    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga);
+    case PRL_NICK: return launch_fused<PRL_NICK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga);
+    case PRL_FENG: return launch_fused<PRL_FENG>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga);
     default: return PRL_ERR_BAD_ARG;
     }
 }

@@ -869,6 +869,10 @@ size_t r256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
 
+// Totals of the Hough searches since the last prl_hip_reset_deskew_stats (process-wide: the chain searches on a helper thread).
+static std::mutex g_deskew_stats_mu;
+static prl_deskew_stats g_deskew_stats{};
+
 // Segments of cv::HoughLinesP(~binarized, 1, CV_PI/180, threshold, line_length, line_gap) for `n_pages` 1-channel pages
 // whose dark mask (p <= thr[page]) is the non-zero image.  `gray` pages are device resident.  Returns the segments
 // per page in `lines_out` (host).  Synchronises the stream.  The caller holds ctx->ppht_mu (the workspace is ctx->ppht_buf).
@@ -974,6 +978,20 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     PRL_HIP_CHECK(hipMemcpyAsync(h_nl.data(), d_nlines, (size_t)n_pages * 4, hipMemcpyDeviceToHost, stream));
     PRL_HIP_CHECK(hipMemcpyAsync(h_lines.data(), d_lines, (size_t)ln_total * 16, hipMemcpyDeviceToHost, stream));
     PRL_HIP_CHECK(hipStreamSynchronize(stream));
+    {   // diagnostics of the search (prl_hip_last_deskew_stats): what the lists held against what they had room for
+        std::lock_guard<std::mutex> lk(g_deskew_stats_mu);
+        prl_deskew_stats& ds = g_deskew_stats;
+        for (int i = 0; i < n_pages; ++i) {
+            const long long room = (long long)h_cap[(size_t)i] - (long long)h_nl[(size_t)i];
+            if (ds.pages == 0 || room < ds.min_page_headroom) ds.min_page_headroom = room;
+            ds.pages += 1;
+            ds.points += h_count[(size_t)i];
+            ds.segments += h_nl[(size_t)i];
+            ds.segment_capacity += h_cap[(size_t)i];
+            ds.max_page_segments = std::max<uint64_t>(ds.max_page_segments, h_nl[(size_t)i]);
+            ds.max_page_points = std::max<uint64_t>(ds.max_page_points, h_count[(size_t)i]);
+        }
+    }
     lines_out->assign((size_t)n_pages, {});
     for (int i = 0; i < n_pages; ++i) {
         if (h_nl[(size_t)i] > h_cap[(size_t)i]) {
@@ -1209,6 +1227,21 @@ int prl_hip_houghp_device(const uint8_t* d_image, size_t step, int width, int he
     if (st != PRL_OK) return st;
     *n_lines = (int)(out[0].size() / 4);
     for (int i = 0; i < std::min(cap, *n_lines) * 4; ++i) lines[i] = out[0][(size_t)i];
+    return PRL_OK;
+}
+
+int prl_hip_last_deskew_stats(prl_deskew_stats* out)
+{
+    if (!out) return PRL_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_deskew_stats_mu);
+    *out = g_deskew_stats;
+    return PRL_OK;
+}
+
+int prl_hip_reset_deskew_stats(void)
+{
+    std::lock_guard<std::mutex> lk(g_deskew_stats_mu);
+    g_deskew_stats = prl_deskew_stats{};
     return PRL_OK;
 }
 

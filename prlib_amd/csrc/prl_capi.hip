@@ -878,13 +878,22 @@ int binarize_common(const prl_binarize_params* p, int n_pages, PageSet src, int 
         const WolfSide* wolf_side = nullptr;
         if (tp.method == PRL_WOLFJOLION && env_knobs().wolf_side) {
             if (!ws->wolf.stream) {
-                PRL_HIP_CHECK(hipStreamCreateWithFlags(&ws->wolf.stream, hipStreamNonBlocking));
-                for (hipEvent_t* e : {&ws->wolf.ev_fork, &ws->wolf.ev_min, &ws->wolf.ev_a, &ws->wolf.ev_coeff})
-                    PRL_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+                // built in a local and published only when the stream and all four events exist: a half-made side would be
+                // taken for a whole one by the next call (stream set, events null)
+                WolfSide side{};
+                hipError_t e = hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking);
+                for (hipEvent_t* ev : {&side.ev_fork, &side.ev_min, &side.ev_a, &side.ev_coeff})
+                    if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+                if (e != hipSuccess) {
+                    for (hipEvent_t ev : {side.ev_fork, side.ev_min, side.ev_a, side.ev_coeff}) if (ev) (void)hipEventDestroy(ev);
+                    if (side.stream) (void)hipStreamDestroy(side.stream);
+                    PRL_HIP_CHECK(e);
+                }
+                ws->wolf = side;
             }
             wolf_side = &ws->wolf;
         }
-        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask, 0, true, epilogue ? h_globals : nullptr, wolf_side);
+        st = fused_run(tp, src, n_pages, thr_dst, d_fused, d_globals, stream, ev0, ev1, bit_mask, true, epilogue ? h_globals : nullptr, wolf_side);
         if (st != PRL_OK) return st;
         if (epilogue) ws->clean_pages = n_pages;
         else PRL_HIP_CHECK(hipMemcpyAsync(h_globals, d_globals, sizeof(PageGlobals) * (size_t)n_pages, hipMemcpyDeviceToHost, stream));

@@ -241,7 +241,7 @@ size_t fused_small_bytes(int n_pages);
 // bit_out: dst is a bit plane (rows of dst.step bytes, 1 bit per output pixel) instead of a 0/255 byte mask
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst,
               void* small, PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start,
-              hipEvent_t ev_stop, bool bit_out = false, int phase = 0, bool counters_zeroed = false,
+              hipEvent_t ev_stop, bool bit_out = false, bool counters_zeroed = false,
               PageGlobals* host_globals = nullptr, const WolfSide* wolf_side = nullptr);  // host_globals (pinned, n_pages entries): see FusedParams::ep_host
 bool fused_supports(const ThrParams& tp);
 int fused_max_pages(const ThrParams& tp);  // pages one fused_run call can take (Wolf-Jolion: per-wavefront maxima storage)

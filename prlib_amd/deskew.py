@@ -99,6 +99,24 @@ def find_orientation(pages):
     return 0.0 if pages.dim() == 2 else np.zeros(pages.shape[0], dtype=np.float64)
 
 
+class DeskewStats(C.Structure):
+    """prl_deskew_stats (include/prl_hip.h): totals of the HoughLinesP searches since the last reset."""
+    _fields_ = [("pages", C.c_uint64), ("points", C.c_uint64), ("segments", C.c_uint64), ("segment_capacity", C.c_uint64),
+                ("max_page_points", C.c_uint64), ("max_page_segments", C.c_uint64), ("min_page_headroom", C.c_int64),
+                ("reserved", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
+def deskew_stats(reset: bool = False) -> DeskewStats:
+    st = DeskewStats()
+    _capi.check(_capi.lib().prl_hip_last_deskew_stats(C.byref(st)))
+    if reset:
+        _capi.check(_capi.lib().prl_hip_reset_deskew_stats())
+    return st
+
+
 def houghp(image, threshold: int, line_length: int, line_gap: int) -> np.ndarray:
     """cv::HoughLinesP(image, lines, 1, CV_PI/180, threshold, line_length, line_gap) on one H x W CUDA page."""
     import torch

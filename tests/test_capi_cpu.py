@@ -20,7 +20,7 @@ def test_header_symbols_are_exported(prl):
     L = _capi.lib()
     for name in declared:
         assert hasattr(L, name), f"{name} is declared in the header but not exported"
-    assert L.prl_hip_abi_version() == 3
+    assert L.prl_hip_abi_version() == 4
 
 
 def test_struct_layout_matches_header(prl):

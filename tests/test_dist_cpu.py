@@ -114,7 +114,7 @@ def test_bench_launcher_path_two_ranks_dryrun():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d == {"dryrun": True, "n_gpus": 2, "pages_total": 10, "max_rank_plus_1": 2.0, "first_block": [0, 5],
+    assert d == {"dryrun": True, "n_gpus": 2, "pages_total": 10, "max_rank_plus_1": 2.0, "first_block": [0, 5], "blocks": [[0, 5], [5, 10]],
                  "scaling": "weak", "strong_ride_along": True}   # N > 1: the weak line also carries the strong-scaling measurement
 
 
@@ -139,8 +139,28 @@ def test_bench_gpus_flag_spawns_its_own_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d == {"dryrun": True, "n_gpus": 2, "pages_total": 7, "max_rank_plus_1": 2.0, "first_block": [0, 4],
+    assert d == {"dryrun": True, "n_gpus": 2, "pages_total": 7, "max_rank_plus_1": 2.0, "first_block": [0, 4], "blocks": [[0, 4], [4, 7]],
                  "scaling": "strong", "strong_ride_along": False}
+
+
+@pytest.mark.parametrize("scaling,pages,total", [("weak", 3, 24), ("strong", 61, 61)])
+def test_bench_gpus_8_dryrun_partitions_the_page_list(scaling, pages, total):
+    """The shape of the driver's first 8-GPU command, `python bench.py --gpus 8`, as eight gloo ranks on the CPU: rendezvous,
+    barrier, max / sum over the ranks, one JSON line from rank 0 - and the eight contiguous page blocks partition the list
+    (weak: 8 x pages-per-GPU; strong: a 61-page list that does not divide by 8, block sizes differ by at most one)."""
+    import json
+
+    r = _run_bench(["--gpus", "8", "--pages", str(pages), "--scaling", scaling, "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["pages_total"] == total and d["max_rank_plus_1"] == 8.0
+    blocks = d["blocks"]
+    assert len(blocks) == 8 and blocks[0][0] == 0 and blocks[-1][1] == total
+    assert all(blocks[i][1] == blocks[i + 1][0] for i in range(7))             # contiguous, in rank order, no gap, no overlap
+    sizes = [b - a for a, b in blocks]
+    assert sum(sizes) == total and max(sizes) - min(sizes) <= 1
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
