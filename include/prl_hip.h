@@ -47,7 +47,9 @@ typedef enum prl_status {
     PRL_ERR_BAD_ARG = 5,     /* null pointer, step < row bytes, negative count, unknown method ... */
     PRL_ERR_NO_DEVICE = 6,   /* no gfx950 device / HIP runtime unusable */
     PRL_ERR_HIP = 7,         /* a HIP call failed; see prl_hip_last_error_detail() */
-    PRL_ERR_NOMEM = 8        /* device or host allocation failed */
+    PRL_ERR_NOMEM = 8,       /* device or host allocation failed */
+    PRL_ERR_LITERAL_BUDGET = 9 /* more pages of the call need the literal redo than prl_hip_set_literal_page_budget() allows:
+                                  the masks of those pages are UNFINISHED (every other page is complete); see INTEGRATION.md §3 */
 } prl_status;
 
 /* The five local-adaptive binarizers of src/binarizations named by the north star. */
@@ -117,6 +119,14 @@ int         prl_hip_set_device(int device);
 int         prl_hip_set_exec_mode(int mode);           /* prl_exec_mode */
 int         prl_hip_get_exec_mode(void);
 int         prl_hip_last_stats(prl_binarize_stats* out);
+/* Cost bound for hostile input (process-wide; INTEGRATION.md §3 "What a hostile input costs").  A page whose queues of
+ * undecided pixels overflow is redone by the literal pipeline (~50 x the fast path's time per pixel); an exact two-level
+ * periodic pattern makes every page of a call do that.  With a budget >= 0 a call that would redo more than `max_pages`
+ * pages does not: it returns PRL_ERR_LITERAL_BUDGET (prl_hip_last_stats().literal_pages says how many needed it) and the
+ * caller decides where that request runs.  -1 (default; env PRL_HIP_LITERAL_PAGE_BUDGET): no limit.  Results are never
+ * approximated: a page is either bit-exact or reported unfinished. */
+int         prl_hip_set_literal_page_budget(int max_pages);
+int         prl_hip_get_literal_page_budget(void);
 int         prl_hip_release_workspace(void);           /* free cached device scratch of the current device */
 /* Measurement aid: when enabled, HIP events bracket the dominant kernel of each binarize call
  * (k_fused in PRL_MODE_AUTO, the whole integral+threshold chain in PRL_MODE_LITERAL) on the stream it

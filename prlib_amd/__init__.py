@@ -13,11 +13,11 @@ from .chain import bitwise_not, cvtColorBGR2GRAY, cvtColorGRAY2BGR, process_page
 from .binarizations import (  # noqa: F401
     FENG, NICK, NIBLACK, SAUVOLA, WOLFJOLION, binarize, binarizeFeng, binarizeNICK, binarizeNiblack,
     binarizeSauvola, binarizeWolfJolion, default_params, geometry, last_stats, make_params, morph,
-    set_exec_mode, set_deferred_completion, finish, binarize_pages_host, PinnedPages, binarizeByLocalVariances, binarizeByLocalVariancesWithoutFilters,
+    set_exec_mode, set_literal_page_budget, set_deferred_completion, finish, binarize_pages_host, PinnedPages, binarizeByLocalVariances, binarizeByLocalVariancesWithoutFilters,
 )
 
 __all__ = [
     "binarize", "binarizeSauvola", "binarizeNiblack", "binarizeWolfJolion", "binarizeNICK", "binarizeFeng", "binarizeByLocalVariances", "binarizeByLocalVariancesWithoutFilters",
-    "denoise", "nlm_planes", "backgroundNormalization", "deskew", "rotate", "houghp", "findAngle", "findOrientation", "deskew_stats", "thinZhangSuen", "thinGuoHall", "cvtColorBGR2GRAY", "cvtColorGRAY2BGR", "bitwise_not", "process_pages", "process_pages_host", "make_params", "default_params", "geometry", "last_stats", "morph", "set_exec_mode", "set_deferred_completion", "finish", "binarize_pages_host", "PinnedPages",
+    "denoise", "nlm_planes", "backgroundNormalization", "deskew", "rotate", "houghp", "findAngle", "findOrientation", "deskew_stats", "thinZhangSuen", "thinGuoHall", "cvtColorBGR2GRAY", "cvtColorGRAY2BGR", "bitwise_not", "process_pages", "process_pages_host", "make_params", "default_params", "geometry", "last_stats", "morph", "set_exec_mode", "set_literal_page_budget", "set_deferred_completion", "finish", "binarize_pages_host", "PinnedPages",
     "SAUVOLA", "NIBLACK", "WOLFJOLION", "NICK", "FENG",
 ]

@@ -32,6 +32,7 @@ PRL_ERR_BAD_ARG = 5
 PRL_ERR_NO_DEVICE = 6
 PRL_ERR_HIP = 7
 PRL_ERR_NOMEM = 8
+PRL_ERR_LITERAL_BUDGET = 9
 
 SAUVOLA, NIBLACK, WOLFJOLION, NICK, FENG = range(5)
 MODE_AUTO, MODE_LITERAL = 0, 1
@@ -48,7 +49,7 @@ EXPORTED_SYMBOLS = [
     "prl_hip_default_chain_params", "prl_hip_chain_batch_device",
     "prl_hip_bgnorm_out_channels", "prl_hip_bgnorm_batch_device", "prl_hip_bgnorm_host",
     "prl_hip_rotate_out_size", "prl_hip_rotate_batch_device", "prl_hip_houghp_device", "prl_hip_deskew_batch_device",
-    "prl_hip_rotate_host", "prl_hip_deskew_host", "prl_hip_find_angle_batch_device", "prl_hip_find_angle_host", "prl_hip_last_deskew_stats", "prl_hip_reset_deskew_stats", "prl_hip_chain_max_out_size", "prl_hip_chain_pages_device",
+    "prl_hip_rotate_host", "prl_hip_deskew_host", "prl_hip_find_angle_batch_device", "prl_hip_find_angle_host", "prl_hip_last_deskew_stats", "prl_hip_reset_deskew_stats", "prl_hip_set_literal_page_budget", "prl_hip_get_literal_page_budget", "prl_hip_chain_max_out_size", "prl_hip_chain_pages_device",
     "prl_hip_binarize_batch_host", "prl_hip_page_range", "prl_hip_binarize_lv_batch_device", "prl_hip_binarize_lv_host",
     "prl_hip_chain_batch_host", "prl_hip_alloc_host", "prl_hip_free_host", "prl_hip_host_register", "prl_hip_host_unregister",
 ]
@@ -178,4 +179,4 @@ def check(status: int) -> None:
         L = lib()
         msg = L.prl_hip_strerror(status).decode()
         detail = L.prl_hip_last_error_detail().decode()
-        raise PrlError(status, f"{msg}" + (f" [{detail}]" if detail and status in (PRL_ERR_HIP, PRL_ERR_NO_DEVICE, PRL_ERR_NOMEM, PRL_ERR_BAD_ARG) else ""))
+        raise PrlError(status, f"{msg}" + (f" [{detail}]" if detail and status in (PRL_ERR_HIP, PRL_ERR_NO_DEVICE, PRL_ERR_NOMEM, PRL_ERR_BAD_ARG, PRL_ERR_LITERAL_BUDGET) else ""))

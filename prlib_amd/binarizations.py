@@ -146,6 +146,12 @@ def finish(device=None) -> None:
     _capi.check(L.prl_hip_finish(torch.cuda.current_stream(dev).cuda_stream))
 
 
+def set_literal_page_budget(max_pages: int) -> None:
+    """prl_hip_set_literal_page_budget: a call that would redo more than `max_pages` pages literally fails with
+    PRL_ERR_LITERAL_BUDGET instead (-1: no limit).  The cost bound a service puts on hostile input."""
+    _capi.check(_capi.lib().prl_hip_set_literal_page_budget(int(max_pages)))
+
+
 def set_exec_mode(mode: int) -> None:
     _capi.check(_capi.lib().prl_hip_set_exec_mode(mode))
 

@@ -864,7 +864,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     uint2 pvb = make_uint2(0u, 0u);
     // the compared pixels and the mask bytes go through raw buffer resources as well: the per-lane part of the address is
     // the loop-invariant column, the row travels in a scalar register - no 64-bit vector address arithmetic per row
-    // (headline -0.7 %, 256 A4 pages NICK w=21 -4.9 %, tools/r3/bufpv_ab.sh)
+    // (headline -0.7 %, 256 A4 pages NICK w=21 -4.9 %, profiles/r03/buffer_path_ab.txt)
     const int pv_col = EDGE ? ep.colc : x0;
     bool page_flagged = false;   // (wave-uniform) a push of this wavefront found its queue bucket full
     int pv_off = ys * step;
@@ -2439,29 +2439,3 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
 }
 
 }  // namespace prl_hip
-
-// ---- counter calibration hook (not in the public header) -------------------------------------------
-// Streams `bytes` with the access shape k_fused uses (8 B per lane, wave-contiguous) so that
-// rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on a known byte count (MI355X_MICROARCH.md:
-// FETCH_SIZE is only calibrated for 16 B/lane streams on gfx950).
-namespace prl_hip {
-namespace {
-__global__ void __launch_bounds__(256) k_calib_stream8(const uint2* __restrict__ src, uint2* __restrict__ dst, size_t n)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        uint2 v = src[i];
-        v.x ^= 0x01010101u;
-        dst[i] = v;
-    }
-}
-}  // namespace
-}  // namespace prl_hip
-
-extern "C" int prl_hip_internal_calib_stream8(const void* d_src, void* d_dst, size_t bytes, void* stream)
-{
-    using namespace prl_hip;
-    hipLaunchKernelGGL(k_calib_stream8, dim3(256 * 16), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const uint2*>(d_src), static_cast<uint2*>(d_dst), bytes / 8);
-    PRL_HIP_CHECK(hipGetLastError());
-    return PRL_OK;
-}

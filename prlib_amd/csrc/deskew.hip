@@ -165,7 +165,28 @@ struct PphtArgs {
     const float* ttab;          // kNumAngle x {cos, sin}
     int* lines; const unsigned long long* lines_off; const unsigned* lines_cap; unsigned* n_lines;
     int prio;                   // raise the wavefront priority (PRL_HIP_PPHT_PRIO)
+    unsigned long long* prof;   // hooks build, PRL_HIP_PPHT_PROF=1: 16 counters per page (cycles per phase, event counts); else null
 };
+
+// Phase accounting of k_ppht_mw (hooks build only: the product kernel carries none of it).  Wavefront 0 / lane 0 adds the
+// shader-clock cycles since the previous mark to the phase that just ended.
+#ifdef PRL_TEST_HOOKS
+#define PPHT_MARK(slot)                                                                  \
+    do {                                                                                 \
+        if (a.prof && wv == 0) {                                                         \
+            const unsigned long long now_ = __builtin_readcyclecounter();                \
+            if (lane == 0) a.prof[(size_t)page * 16 + (slot)] += now_ - prof_t;          \
+            prof_t = now_;                                                               \
+        }                                                                                \
+    } while (0)
+#define PPHT_COUNT(slot, n)                                                              \
+    do {                                                                                 \
+        if (a.prof && wv == 0 && lane == 0) a.prof[(size_t)page * 16 + (slot)] += (n);   \
+    } while (0)
+#else
+#define PPHT_MARK(slot) do { } while (0)
+#define PPHT_COUNT(slot, n) do { } while (0)
+#endif
 
 __device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }
 
@@ -450,6 +471,9 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
     unsigned n_lines = 0;
     const unsigned N = a.count[page];
     int kbuf = 0;
+#ifdef PRL_TEST_HOOKS
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
 
     auto process_line = [&](int j, int i, int max_n) {
         const float fa = -a.ttab[2 * max_n + 1], fb = a.ttab[2 * max_n];
@@ -500,6 +524,8 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
         step_pixel(xflag, x0, y0, dx0, dy0, end_step[0], &ex[0], &ey[0]);
         step_pixel(xflag, x0, y0, -dx0, -dy0, end_step[1], &ex[1], &ey[1]);
         const bool good_line = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
+        PPHT_MARK(3);   // read-only walk
+        PPHT_COUNT(9, (end_step[0] + end_step[1]) / 64 + 2);
         __syncthreads();  // nobody clears a pixel before everybody has finished the read-only walk
         // second walk: wavefront 0 clears the set pixels and publishes which ones they were
         if (wv == 0) {
@@ -521,12 +547,14 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
             }
         }
         __syncthreads();
+        PPHT_MARK(4);   // clearing walk
         if (good_line) {  // a good line takes the votes of its pixels back: every wavefront its own angles
             int gidx = 0;
             for (int k = 0; k < 2; ++k) {
                 const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
                 for (unsigned base = (unsigned)k; base <= end_step[k]; base += 64, ++gidx) {
                     unsigned long long nzb = s_ballot[gidx];
+                    PPHT_COUNT(10, __popcll(nzb));
                     while (nzb) {
                         const int q = __ffsll((long long)nzb) - 1;
                         nzb &= nzb - 1;
@@ -545,6 +573,8 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
             ++n_lines;
         }
         __syncthreads();  // s_ballot is free again; the cleared pixels are visible to everybody's next mask reads
+        PPHT_MARK(5);   // un-votes (+ the segment store)
+        PPHT_COUNT(8, good_line ? 1 : 0);
     };
 
     for (unsigned t0 = 0; t0 < N; t0 += kBlkMw) {
@@ -577,13 +607,16 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
         // no further barrier)
         if (act && !((skip >> lane) & 1ull)) nz[idx] = rl;
         const unsigned pt = rp;
+        PPHT_MARK(0);   // block prologue: RNG, list fetch, swaps
+        PPHT_COUNT(6, 1);
 
         unsigned start = 0;
         while (start < nb) {
             unsigned m = 0;
             if (act && (unsigned)lane >= start) m = mask[(size_t)(pt >> 16) * W + (pt & 0xffffu)];
             const unsigned long long vm = __ballot(m != 0);
-            if (!vm) break;
+            if (!vm) { PPHT_MARK(1); break; }
+            PPHT_COUNT(11, __popcll(vm));
             int v[kBlkMw];
 #pragma unroll
             for (int p = 0; p < kBlkMw; ++p) {
@@ -611,7 +644,9 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
             }
             kbuf ^= 1;
             const unsigned long long tb = __ballot(lane < kBlkMw && ((vm >> lane) & 1ull) && (kk >> 8) >= a.threshold);
+            PPHT_MARK(1);   // mask bytes, votes issued and retired
             if (!tb) break;  // every vote of the block stands
+            PPHT_COUNT(7, 1);
             const int trig = __ffsll((long long)tb) - 1;
             const int trig_n = 255 - (__builtin_amdgcn_readlane(kk, trig) & 255);
             for (unsigned p = (unsigned)trig + 1; p < nb; ++p) {
@@ -622,6 +657,7 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
                 }
             }
             const unsigned tq = (unsigned)__builtin_amdgcn_readlane((int)pt, trig);
+            PPHT_MARK(2);   // roll-back of the younger points' votes
             process_line((int)(tq & 0xffffu), (int)(tq >> 16), trig_n);
             start = (unsigned)trig + 1;
         }
@@ -965,6 +1001,15 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     a.mask = d_mask; a.mask_page = mask_page; a.nz = d_nz; a.nz_off = d_nzoff; a.count = d_count; a.accum = d_accum; a.ttab = d_ttab;
     a.lines = d_lines; a.lines_off = d_lnoff; a.lines_cap = d_cap; a.n_lines = d_nlines;
     a.prio = env_knobs().ppht_prio;
+    a.prof = nullptr;
+#ifdef PRL_TEST_HOOKS
+    unsigned long long* d_prof = nullptr;
+    if (std::getenv("PRL_HIP_PPHT_PROF")) {
+        PRL_HIP_CHECK(hipMalloc(&d_prof, (size_t)n_pages * 16 * 8));
+        PRL_HIP_CHECK(hipMemsetAsync(d_prof, 0, (size_t)n_pages * 16 * 8, stream));
+        a.prof = d_prof;
+    }
+#endif
     // three wavefronts per page (shorter critical path per page; equal to one per page once the memory system is the limit)
     const int mw_env = env_knobs().ppht_mw;
     if (start && start->ev) PRL_HIP_CHECK(hipEventRecord(start->ev, stream));   // the streaming prelude ends here
@@ -978,6 +1023,27 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     PRL_HIP_CHECK(hipMemcpyAsync(h_nl.data(), d_nlines, (size_t)n_pages * 4, hipMemcpyDeviceToHost, stream));
     PRL_HIP_CHECK(hipMemcpyAsync(h_lines.data(), d_lines, (size_t)ln_total * 16, hipMemcpyDeviceToHost, stream));
     PRL_HIP_CHECK(hipStreamSynchronize(stream));
+#ifdef PRL_TEST_HOOKS
+    if (d_prof) {   // one JSON line per call on stderr: the three heaviest pages and the sum, cycles per phase and event counts
+        std::vector<unsigned long long> hp((size_t)n_pages * 16);
+        (void)hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_prof);
+        std::vector<int> order((size_t)n_pages);
+        for (int i = 0; i < n_pages; ++i) order[(size_t)i] = i;
+        auto total = [&](int i) { unsigned long long t = 0; for (int k = 0; k < 6; ++k) t += hp[(size_t)i * 16 + k]; return t; };
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return total(x) > total(y); });
+        static const char* names[12] = {"prologue_cyc", "vote_cyc", "rollback_cyc", "walk1_cyc", "walk2_cyc", "unvote_cyc", "blocks", "triggers",
+                                        "good_lines", "walk_chunks", "unvoted_px", "voted_points"};
+        std::fprintf(stderr, "{\"ppht_prof\": {\"pages\": %d, \"width\": %d, \"height\": %d, \"heaviest\": [", n_pages, width, height);
+        for (int r = 0; r < std::min(3, n_pages); ++r) {
+            const int i = order[(size_t)r];
+            std::fprintf(stderr, "%s{\"page\": %d, \"points\": %u, \"segments\": %u", r ? ", " : "", i, h_count[(size_t)i], h_nl[(size_t)i]);
+            for (int k = 0; k < 12; ++k) std::fprintf(stderr, ", \"%s\": %llu", names[k], hp[(size_t)i * 16 + k]);
+            std::fprintf(stderr, "}");
+        }
+        std::fprintf(stderr, "]}}\n");
+    }
+#endif
     {   // diagnostics of the search (prl_hip_last_deskew_stats): what the lists held against what they had room for
         std::lock_guard<std::mutex> lk(g_deskew_stats_mu);
         prl_deskew_stats& ds = g_deskew_stats;

@@ -39,6 +39,18 @@ std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
 std::atomic<int> g_exec_mode{-1};  // -1: take PRL_HIP_MODE
 std::atomic<bool> g_profiling{false};
 std::atomic<bool> g_deferred{false};  // prl_hip_set_deferred_completion
+std::atomic<int> g_literal_budget{-2};  // prl_hip_set_literal_page_budget; -2: take PRL_HIP_LITERAL_PAGE_BUDGET (default -1 = no limit)
+
+int literal_budget()
+{
+    int b = g_literal_budget.load(std::memory_order_relaxed);
+    if (b == -2) {
+        const char* e = std::getenv("PRL_HIP_LITERAL_PAGE_BUDGET");
+        b = e && *e ? std::max(-1, std::atoi(e)) : -1;
+        g_literal_budget.store(b, std::memory_order_relaxed);
+    }
+    return b;
+}
 thread_local bool t_force_deferred = false;  // library-internal callers that call prl_hip_finish themselves (host batch)
 
 }  // namespace
@@ -710,9 +722,14 @@ int resolve_front(StreamWs* ws)
             flagged.push_back(i);
         }
     }
-    const int st = redo_pages_literal(ws, pc, flagged);
     ws->last = cs;
-    return st;
+    const int budget = literal_budget();
+    if (budget >= 0 && (int)flagged.size() > budget) {   // the caller's cost bound: report, do not redo
+        set_error_detail(std::to_string(flagged.size()) + " of " + std::to_string(pc.n_pages) + " pages need the literal pipeline, the budget is " +
+                         std::to_string(budget) + " (first: page " + std::to_string(flagged.front()) + ")");
+        return PRL_ERR_LITERAL_BUDGET;
+    }
+    return redo_pages_literal(ws, pc, flagged);
 }
 
 int resolve_all(StreamWs* ws)
@@ -982,11 +999,20 @@ const char* prl_hip_strerror(int status)
     case PRL_ERR_NO_DEVICE: return "no usable HIP device (gfx950 required); there is no CPU fallback";
     case PRL_ERR_HIP: return "HIP runtime error";
     case PRL_ERR_NOMEM: return "out of memory";
+    case PRL_ERR_LITERAL_BUDGET: return "literal-page budget exceeded: the flagged pages are unfinished";
     default: return "unknown status";
     }
 }
 
 const char* prl_hip_last_error_detail(void) { return t_error_detail.c_str(); }
+
+int prl_hip_set_literal_page_budget(int max_pages)
+{
+    g_literal_budget.store(max_pages < 0 ? -1 : max_pages, std::memory_order_relaxed);
+    return PRL_OK;
+}
+
+int prl_hip_get_literal_page_budget(void) { return literal_budget(); }
 
 int prl_hip_device_count(int* count)
 {

@@ -655,6 +655,39 @@ def test_deferred_completion_and_two_streams(prl, oracle, cuda_device):
         prl.set_deferred_completion(False)
 
 
+def test_literal_page_budget_bounds_the_cost_of_hostile_pages(prl, oracle, cuda_device):
+    """prl_hip_set_literal_page_budget: a flat page tuned to sit on its own threshold overflows the fix-up
+    list and is redone literally.  With a budget of 0 the call reports that instead of paying for it (PRL_ERR_LITERAL_BUDGET,
+    the statistics say how many pages needed the redo); the ordinary pages of the same call are complete; with the budget
+    lifted (or large enough) the same call is bit-exact again.  Never an approximate mask."""
+    import torch
+    from prlib_amd import _capi
+
+    w, c = 15, 200
+    k = _flat_boundary_k(c, w, c)
+    pages = [np.full((640, 700), c, np.uint8), _pages((640, 700), ["doc"], seed=29)[0], _pages((640, 700), ["doc"], seed=30)[0]]
+    t = torch.from_numpy(np.stack(pages)).to(cuda_device)
+    p = prl.make_params(SAUVOLA, w, k, 0)
+    want = _oracle_batch(oracle, pages, SAUVOLA, w, k, 0)
+    L = _capi.lib()
+    assert L.prl_hip_get_literal_page_budget() == -1
+    try:
+        prl.set_literal_page_budget(0)
+        with pytest.raises(_capi.PrlError) as e:
+            prl.binarize(t, p)
+        assert e.value.status == _capi.PRL_ERR_LITERAL_BUDGET and "1 of 3 pages" in str(e.value)
+        assert prl.last_stats().literal_pages == 1
+        got = prl.binarize(t[1:], p).cpu().numpy()            # ordinary pages: no redo needed, the budget does not bite
+        assert np.array_equal(got[0], want[1]) and np.array_equal(got[1], want[2])
+        prl.set_literal_page_budget(1)
+        got = prl.binarize(t, p).cpu().numpy()
+        assert all(np.array_equal(got[i], want[i]) for i in range(3)) and prl.last_stats().literal_pages == 1
+    finally:
+        prl.set_literal_page_budget(-1)
+    got = prl.binarize(t, p).cpu().numpy()
+    assert all(np.array_equal(got[i], want[i]) for i in range(3))
+
+
 def test_host_batch_entry_shards_and_double_buffers(prl, oracle, cuda_device):
     """prl_hip_binarize_batch_host on one device: 40 pages of 2048^2 are three chunks alternating between two streams;
     results come back in the caller's order, from pages with a row stride larger than the width."""

@@ -67,3 +67,23 @@ extern "C" int prl_probe_stream(int mode, const void* src, void* dst, size_t byt
     *ms_out = t[t.size() / 2];
     return 0;
 }
+
+// ---- counter calibration (moved here from the product library in round 5) -------------------------------------------------
+// Streams `bytes` with the access shape k_fused uses (8 B per lane, wave-contiguous) so that rocprofv3's FETCH_SIZE / WRITE_SIZE
+// can be calibrated on a known byte count (MI355X_MICROARCH.md: FETCH_SIZE is only calibrated for 16 B/lane streams on gfx950).
+// tools/calib_counters.py / tools/calib.sh.
+__global__ void __launch_bounds__(256) k_calib_stream8(const uint2* __restrict__ src, uint2* __restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint2 v = src[i];
+        v.x ^= 0x01010101u;
+        dst[i] = v;
+    }
+}
+
+extern "C" int prl_probe_calib_stream8(const void* d_src, void* d_dst, size_t bytes, void* stream)
+{
+    hipLaunchKernelGGL(k_calib_stream8, dim3(256 * 16), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint2*>(d_src), static_cast<uint2*>(d_dst), bytes / 8);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
