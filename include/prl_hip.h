@@ -23,6 +23,14 @@
  *     result is in the caller's buffer.
  *   - All functions return PRL_OK (0) or a prl_status error; prl_hip_strerror() explains it and
  *     prl_hip_last_error_detail() carries the HIP runtime message for PRL_ERR_HIP.
+ *   - Threading: every entry point may be called from any thread.  Calls that name different (device, stream) pairs share
+ *     no workspace and overlap; calls on one stream - from one thread or several - are serialised by that stream's
+ *     workspace lock and ordered by the stream.  The *_host entries and the stages that use the per-device staging area
+ *     (denoise, deskew, backgroundNormalization, the chain) take a per-device lock for their duration.  Process-wide
+ *     switches (exec mode, deferred completion, profiling, literal-page budget) are atomics; prl_hip_set_device, the error
+ *     detail and prl_hip_last_stats are per thread.  Held by tests/test_concurrency_gpu.py (four threads on their own
+ *     streams, two threads on one, 2 000 mixed calls with the device's free memory back at its baseline after
+ *     prl_hip_release_workspace).
  *   - The library never falls back to a CPU implementation.  Without a usable gfx950 device every
  *     compute entry point fails with PRL_ERR_NO_DEVICE.
  */

@@ -21,12 +21,13 @@
 //
 // Memory: 1 B/px read + 1 B/px written to HBM (the algorithmic 2 B/px); window halos, the "leaving" row of
 // the sliding window and the compared-pixel row are re-read through L2 / Infinity Cache (measured 20 GB of
-// fabric traffic per 8.6 GB algorithmic).  Roofline by the metric: HBM (0.335 of 8 TB/s on the driver's run).  The row
-// loop is balanced against four pipes, none saturated: per 512-column wavefront-row of an interior strip 149 vector
-// instructions (117 two-cycle, 24 four-cycle, 8 v_sqrt_f32: ~450 SIMD cycles of issue; edge strips 199, ~650), 42 scalar
-// ones, 14 ds_bpermute, 6 vector-memory instructions, against ~710 measured cycles: vector issue ~0.7, vector memory
-// 0.5-0.8, LDS ~0.5 of the time (tools/isa_budget.py reads this from the compiler's output; instruction costs in
-// profiles/r01/valu_issue_costs.txt).  Perfect overlap would end at ~0.48 of the HBM roofline; see DESIGN.md 4.1.
+// fabric traffic per 8.6 GB algorithmic).  Roofline by the metric: HBM (0.335 of 8 TB/s on the driver's run, 0.365 on the
+// fastest box).  The row loop is balanced against four pipes, none saturated: per 512-column wavefront-row of an interior
+// strip 149 vector instructions (117 two-cycle, 24 four-cycle, 8 v_sqrt_f32: ~450 SIMD cycles of issue; edge strips 199,
+// ~650), 42 scalar ones, 14 ds_bpermute, 6 vector-memory instructions, against 588 measured cycles (GRBM_GUI_ACTIVE: the
+// chip runs this kernel at ~1.8 GHz under its power cap): vector issue ~0.84, vector memory 0.65-0.98, LDS 0.57 of the time
+// (tools/isa_budget.py reads the instruction mix from the compiler's output; costs in profiles/r01/valu_issue_costs.txt).
+// Perfect overlap would end at ~0.43 of the HBM roofline; see DESIGN.md 4.1.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

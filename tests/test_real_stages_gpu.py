@@ -195,3 +195,37 @@ def test_real_colour_scans_through_deskew_bgnorm_and_the_chain(prl, oracle, cuda
     assert st["pages"] == len(group) and st["min_page_headroom"] >= 0
     records.append({"batch_of": len(group), "shape": list(shape), "hough": st, "result_sizes": sorted({tuple(o.shape) for o in outs})})
     _emit(records, "real_stages.jsonl")
+
+
+@pytest.mark.gpu
+def test_real_colour_scans_through_the_remaining_entry_points(prl, oracle, cuda_device):
+    """The rest of the built surface on the same ten colour scans, against the oracle run beside it: the two local-variance
+    binarizers (the one without filters is integer-exact; the filtered one carries its stated 1e-3 tolerance), Guo-Hall
+    thinning of the Sauvola mask, the (2n+1)^2 closing / opening on its own, the BGRA form of the page through
+    backgroundNormalization (the fourth channel is dropped, src/formatConvert.cpp:193-206), and prl::rotate by the page's own
+    deskew angle."""
+    import torch
+
+    for path in CHAIN:
+        z = np.load(path)
+        bgr = z["bgr"]
+        name = _name(path)
+        t = torch.from_numpy(bgr).to(cuda_device)
+        got = prl.binarizeByLocalVariancesWithoutFilters(t[None])[0].cpu().numpy()
+        assert np.array_equal(got, oracle.binarize_lv_nofilters(bgr)), f"{name}: binarizeByLocalVariancesWithoutFilters"
+        got = prl.binarizeByLocalVariances(t[None])[0].cpu().numpy()
+        want = oracle.binarize_lv(bgr)
+        assert (got != want).mean() <= 1e-3, f"{name}: binarizeByLocalVariances differs on {(got != want).mean():.2e} of the page"
+        gray = oracle.bgr2gray(bgr)
+        mask = prl.binarizeSauvola(torch.from_numpy(gray).to(cuda_device), 31, 0.34, 0)
+        m_host = mask.cpu().numpy()
+        assert np.array_equal(m_host, oracle.binarize(gray, oracle.make_params(oracle.SAUVOLA, 31, 0.34, 0))), name
+        gh = prl.thinGuoHall(prl.bitwise_not(mask)).cpu().numpy()
+        assert np.array_equal(gh, oracle.thin(255 - m_host, 1)), f"{name}: thinGuoHall"
+        for it in (3, -2):
+            assert np.array_equal(prl.morph(mask, it).cpu().numpy(), oracle.morph(m_host, it)), f"{name}: morphology {it}"
+        bgra = np.concatenate([bgr, np.full(bgr.shape[:2] + (1,), 200, np.uint8)], axis=2)
+        assert np.array_equal(prl.backgroundNormalization(torch.from_numpy(bgra).to(cuda_device)).cpu().numpy(), oracle.bgnorm(bgra)), name
+        ang = float(z["deskew_angle"][0]) or 7.5
+        r = prl.rotate(t[None], [ang])[0].cpu().numpy()
+        assert np.array_equal(r, oracle.rotate(bgr, ang)), f"{name}: rotate({ang})"

@@ -35,7 +35,9 @@ def pmc_pass(argv):
             return None, f"{cset[0]}: {e!r}"
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}, "rocprofv3 --pmc, two passes, this run"
+    # the child runs the batch twice (the warm-up call and one timed step) and a batch may be several launches (chunks of pages):
+    # per batch = the sum over every launch / 2
+    return {k: {c: sum(v) / 2.0 for c, v in cs.items()} for k, cs in acc.items()}, "rocprofv3 --pmc, two passes, this run; per batch = sum over the launches / 2 batches"
 
 
 _pmc = None

@@ -169,7 +169,9 @@ def main():
     ap.add_argument("--pages", type=int, default=256)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--window", type=int, default=31)
-    ap.add_argument("--ghz", type=float, default=2.4)
+    ap.add_argument("--ghz", type=float, default=2.4, help="shader clock to turn --ms into cycles (rocm-smi under sustained load: 2.04-2.08)")
+    ap.add_argument("--gui-active", type=float, default=0.0, help="GRBM_GUI_ACTIVE per launch from a rocprofv3 --pmc pass (summed over the 8 XCDs): "
+                    "the launch's duration in shader cycles without assuming a clock; overrides --ghz")
     ap.add_argument("--only", default="", help="substring of `kind` (e.g. 'interior') to keep")
     a = ap.parse_args()
     asm = a.asm
@@ -216,7 +218,7 @@ def main():
             n_strips = -(-(a.size - 1) // uo)
             rows = a.pages * (a.size - 1) * n_strips
             simds = 256 * 4
-            cyc = a.ms * 1e-3 * a.ghz * 1e9 * simds / rows
+            cyc = (a.gui_active / 8.0 if a.gui_active else a.ms * 1e-3 * a.ghz * 1e9) * simds / rows
             rec["measured"] = {"launch_ms": a.ms, "wavefront_rows": rows, "strips_per_row": n_strips, "simd_cycles_per_row": round(cyc, 1),
                                "valu_pipe_fill": round(valu_cycles / cyc, 3),
                                "lds_pipe_fill": round(counts.get("lds", 0) * 6 * 4 / cyc, 3),
@@ -237,7 +239,9 @@ def main():
         valu = wavg("valu_issue_cycles_per_row")
         out["headline_summary"] = {
             "window": a.window, "lane_offset": lo_idx, "interior_loop": fast["label"], "edge_loop": edge["label"], "strips_per_row": ns,
-            "assumed_clock_GHz": a.ghz, "measured_simd_cycles_per_wavefront_row": cyc_meas,
+            "cycles_from": (f"GRBM_GUI_ACTIVE {a.gui_active:.5g} / 8 XCDs = {a.gui_active / 8:.4g} cycles per launch (= {a.gui_active / 8 / (a.ms * 1e-3) / 1e9:.3f} GHz over {a.ms} ms)"
+                            if a.gui_active else f"{a.ms} ms at an assumed {a.ghz} GHz"),
+            "measured_simd_cycles_per_wavefront_row": cyc_meas,
             "per_wavefront_row_weighted": {
                 "valu_instructions": round(wavg("valu_total"), 1), "valu_issue_cycles": round(valu, 1),
                 "salu_and_waitcnt_instructions": round(wavg("salu") + wavg("waitcnt"), 1),
