@@ -224,6 +224,40 @@ constexpr int kBlk = PRL_PPHT_BLK;
 // L2s, profiles/r02/pmc_ppht.txt).
 __device__ __forceinline__ int vote(int* cell, int d) { return __hip_atomic_fetch_add(cell, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Cells hold count + 2^31 (the accumulator is filled with 0x80000000): a vote's returned value gives the count by flipping the top
+// bit, and the un-votes of a good line can be taken from TWO adjacent cells with one 64-bit subtraction - the low half never
+// borrows from the high one, because a biased cell is never smaller than what is subtracted from it.
+constexpr unsigned kAccBias = 0x80000000u;
+__device__ __forceinline__ int count_of(int stored) { return (int)((unsigned)stored ^ kAccBias); }
+
+// The un-votes of one lane's angle along a line walk.  For a fixed angle the cell index r = round(x cos + y sin) is monotone
+// along the walk and moves by at most sqrt(2) per step, so consecutive erased pixels hit the same cell or its neighbour: the
+// decrements are collected per aligned PAIR of cells and leave as one global_atomic_sub_x2 when the walk moves on - about a
+// third of the atomics of one decrement per pixel and angle (the transform is bound by the rate of memory-side atomics:
+// 2.1e10 per second for the whole chip), with identical cell values at every later vote.
+struct Unvotes {
+    int pair = -1;
+    unsigned lo = 0, hi = 0;
+    __device__ __forceinline__ void flush(unsigned long long* acc64)
+    {
+        if (pair >= 0)
+            (void)__hip_atomic_fetch_sub(acc64 + pair, (unsigned long long)lo | ((unsigned long long)hi << 32), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+        pair = -1;
+        lo = hi = 0;
+    }
+    __device__ __forceinline__ void add(unsigned long long* acc64, int idx)   // idx: cell index from the page's accumulator base
+    {
+        const int p = idx >> 1;
+        if (p != pair) {
+            flush(acc64);
+            pair = p;
+        }
+        if (idx & 1) ++hi;
+        else ++lo;
+    }
+};
+
 // HoughLinesP stage 2, one wavefront per page, BLOCKS OF kBlk POINTS (round 2, second version).  The first version walked the
 // points one by one: list fetch -> mask byte -> 180 voting atomics -> decision, three dependent memory round trips per
 // point (1.9 us).  Two facts allow overlapping them without changing a single result:
@@ -251,13 +285,16 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
     const unsigned cap = a.lines_cap[page];
     float tc[3], ts[3];
     int* arow[3];
+    int row0[3];   // index of cell r = 0 of the lane's three angle rows
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int n = min(lane + 64 * q, kNumAngle - 1);
         tc[q] = a.ttab[2 * n];
         ts[q] = a.ttab[2 * n + 1];
         arow[q] = accum + (size_t)n * numrho + (numrho - 1) / 2;
+        row0[q] = n * numrho + (numrho - 1) / 2;
     }
+    unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(accum);
     const bool has2 = lane + 128 < kNumAngle;
     unsigned long long rng = ~0ull;
     unsigned n_lines = 0;
@@ -314,6 +351,7 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
         step_pixel(xflag, x0, y0, -dx0, -dy0, end_step[1], &ex[1], &ey[1]);
         const bool good_line = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
         // second walk: clear the set pixels up to the line ends; a good line takes their votes back
+        Unvotes uv[3];
         for (int k = 0; k < 2; ++k) {
             const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
             for (unsigned base = (unsigned)k; base <= end_step[k]; base += 64) {  // (step 0 was cleared by k = 0)
@@ -334,11 +372,13 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
                         step_pixel(xflag, x0, y0, dx, dy, base + (unsigned)q, &jq, &iq);
 #pragma unroll
                         for (int qq = 0; qq < 3; ++qq)
-                            if (qq < 2 || has2) vote(arow[qq] + cv_round_f((float)jq * tc[qq] + (float)iq * ts[qq]), -1);
+                            if (qq < 2 || has2) uv[qq].add(acc64, row0[qq] + cv_round_f((float)jq * tc[qq] + (float)iq * ts[qq]));
                     }
                 }
             }
         }
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) uv[qq].flush(acc64);   // before any later vote reads these cells
         if (good_line) {
             if (lane == 0 && n_lines < cap) {
                 lines[4 * n_lines] = ex[0];
@@ -408,7 +448,7 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
                     int key = INT_MIN;
 #pragma unroll
                     for (int qq = 0; qq < 3; ++qq)
-                        if (qq < 2 || has2) key = max(key, (v[p][qq] + 1) * 256 + (255 - (lane + 64 * qq)));
+                        if (qq < 2 || has2) key = max(key, (count_of(v[p][qq]) + 1) * 256 + (255 - (lane + 64 * qq)));
                     key = wave_max_i32(key);
                     if ((key >> 8) >= a.threshold) {
                         trig = p;
@@ -467,6 +507,8 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
     const int angc = min(ang, kNumAngle - 1);
     const float tc = a.ttab[2 * angc], ts = a.ttab[2 * angc + 1];
     int* arow = accum + (size_t)angc * numrho + (numrho - 1) / 2;
+    const int row0 = angc * numrho + (numrho - 1) / 2;   // index of this lane's cell r = 0
+    unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(accum);
     unsigned long long rng = ~0ull;
     unsigned n_lines = 0;
     const unsigned N = a.count[page];
@@ -549,6 +591,7 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
         __syncthreads();
         PPHT_MARK(4);   // clearing walk
         if (good_line) {  // a good line takes the votes of its pixels back: every wavefront its own angles
+            Unvotes uv;
             int gidx = 0;
             for (int k = 0; k < 2; ++k) {
                 const int dx = k ? -dx0 : dx0, dy = k ? -dy0 : dy0;
@@ -560,10 +603,11 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
                         nzb &= nzb - 1;
                         int jq, iq;
                         step_pixel(xflag, x0, y0, dx, dy, base + (unsigned)q, &jq, &iq);
-                        if (has) vote(arow + cv_round_f((float)jq * tc + (float)iq * ts), -1);
+                        if (has) uv.add(acc64, row0 + cv_round_f((float)jq * tc + (float)iq * ts));
                     }
                 }
             }
+            uv.flush(acc64);   // before any later vote reads these cells
             if (wv == 0 && lane == 0 && n_lines < cap) {
                 lines[4 * n_lines] = ex[0];
                 lines[4 * n_lines + 1] = ey[0];
@@ -631,7 +675,7 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
 #pragma unroll
             for (int p = 0; p < kBlkMw; ++p) {
                 if ((vm >> p) & 1ull) {
-                    const int key = wave_max_i32(has ? (v[p] + 1) * 256 + (255 - ang) : INT_MIN);
+                    const int key = wave_max_i32(has ? (count_of(v[p]) + 1) * 256 + (255 - ang) : INT_MIN);
                     if (lane == p) mine = key;
                 }
             }
@@ -993,7 +1037,7 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
         h_ttab[2 * n + 1] = (float)(std::sin((double)n * theta) * irho);
     }
     PRL_HIP_CHECK(hipMemcpyAsync(d_ttab, h_ttab, sizeof(h_ttab), hipMemcpyHostToDevice, stream));
-    PRL_HIP_CHECK(hipMemsetAsync(d_accum, 0, (size_t)n_pages * kNumAngle * numrho * 4, stream));
+    PRL_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_accum), (int)kAccBias, (size_t)n_pages * kNumAngle * numrho, stream));   // count 0 = bias
     hipLaunchKernelGGL(k_collect, dim3((unsigned)height, (unsigned)n_pages), dim3(64), 0, stream, width, height, d_mask, mask_page,
                        d_rowoff, d_nzoff, d_nz);
     PphtArgs a{};
