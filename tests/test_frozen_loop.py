@@ -1,0 +1,32 @@
+"""The row loops of k_fused are frozen: on this kernel the ORDER of the instructions is worth +-20 %
+(profiles/r03/sched_strategy_ab.txt), and an edit anywhere in binarize_fused.hip - even in the cold queue-push block - moves it
+(tools/experiments/README.md, round 5).  This test compiles the file to gfx950 assembly (hipcc -S, ~1 min, no GPU) and compares the
+opcode order of every threshold instantiation's row loops with the fingerprint of the measured build
+(profiles/r05/k_fused_hot_loops.json = round 4's code, opcode for opcode).  If it fails after an intended change: measure the
+headline (python bench.py on a GPU box) and refresh the file with `python tools/isa_budget.py --fingerprint > profiles/r05/k_fused_hot_loops.json`.
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and not shutil.which("hipcc"), reason="needs hipcc")
+def test_k_fused_row_loops_are_the_measured_ones(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_budget
+
+    asm = str(tmp_path / "fused.s")
+    isa_budget.compile_asm(asm)
+    got = isa_budget.hot_loop_fingerprints(asm)
+    want = json.load(open(os.path.join(ROOT, "profiles", "r05", "k_fused_hot_loops.json")))
+    assert set(got) == set(want), sorted(set(got) ^ set(want))
+    moved = [k for k in sorted(want) if got[k] != want[k]]
+    assert not moved, "row loops whose instruction order changed: " + ", ".join(moved)
+    # the headline instantiation is among them, with its 12 float32 and 2 integer loops
+    assert want["k_fused<0,6,false>"]["row_loops"] == 14

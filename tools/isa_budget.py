@@ -153,7 +153,49 @@ def hot_loop_mix(src, kernels, marker, min_marker):
     return res
 
 
+def hot_loop_fingerprints(asm):
+    """{kernel tag: sha1 of the opcode sequences of its row loops' usual paths} for every threshold instantiation of k_fused in
+    an assembly file - what `--fingerprint` prints and tests/test_frozen_loop.py compares with profiles/r05/k_fused_hot_loops.json.
+    Register numbers and labels are left out on purpose: what is frozen is the instruction ORDER (worth +-20 %)."""
+    import hashlib
+    text = open(asm).read().splitlines()
+    res = {}
+    for i, ln in enumerate(text):
+        m = re.match(r"^(_Z\w*k_fusedILi(\d+)ELi(\d+)ELb(\d)EE\w*):", ln)
+        if not m:
+            continue
+        end = next(j for j in range(i + 1, len(text)) if text[j].startswith(".Lfunc_end"))
+        body = text[i:end]
+        h = hashlib.sha1()
+        n_loops = 0
+        for lo, hi, cold in row_loops(body, min_sqrt=1):
+            n_loops += 1
+            for k in range(lo, hi + 1):
+                if k in cold:
+                    continue
+                mm = re.match(r"^\s+([a-z_0-9]+)\s", body[k].split(";")[0] + " ")
+                if mm and not mm.group(1).startswith("."):
+                    h.update(mm.group(1).encode() + b"\n")
+            h.update(b"--\n")
+        if n_loops:
+            res[f"k_fused<{m.group(2)},{m.group(3)},{'true' if m.group(4) == '1' else 'false'}>"] = {"row_loops": n_loops, "sha1": h.hexdigest()}
+    return res
+
+
+def compile_asm(out):
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+           "-Wno-pass-failed", "-Wno-unused-command-line-argument", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out,
+           os.path.join(ROOT, "prlib_amd", "csrc", "binarize_fused.hip")]
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def main():
+    if "--fingerprint" in sys.argv:   # python tools/isa_budget.py --fingerprint [file.s] : the frozen row loops' opcode order, hashed
+        i = sys.argv.index("--fingerprint")
+        asm = sys.argv[i + 1] if len(sys.argv) > i + 1 else compile_asm("/tmp/prl_fused_isa.s")
+        print(json.dumps(hot_loop_fingerprints(asm), indent=1, sort_keys=True))
+        return
     if "--mix" in sys.argv:   # python tools/isa_budget.py --mix nlm : the NL-means kernels' inner-loop mix (tools/bench_denoise.py reads it)
         which = sys.argv[sys.argv.index("--mix") + 1]
         assert which == "nlm"
