@@ -30,6 +30,9 @@ def test_struct_layout_matches_header(prl):
     assert _capi.BinarizeParams.k.offset == 8 and _capi.BinarizeParams.feng_alpha1.offset == 24
     assert C.sizeof(_capi.BinarizeGeometry) == 24
     assert C.sizeof(_capi.BinarizeStats) == 64
+    from prlib_amd.deskew import DeskewStats   # prl_deskew_stats: 8 x 64-bit
+
+    assert C.sizeof(DeskewStats) == 64 and DeskewStats.min_page_headroom.offset == 48
 
 
 def test_defaults_are_the_reference_headers(prl):
