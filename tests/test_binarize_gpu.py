@@ -589,6 +589,32 @@ def test_float_pipeline_at_the_largest_sums(prl, oracle, cuda_device, method, wi
     _check(prl, oracle, cuda_device, [white, checker, halves, stripes], method, win, k, 0)
 
 
+def test_wolf_flat_pages_do_not_take_the_candidate_list_from_their_neighbours(prl, oracle, cuda_device):
+    """Wolf-Jolion sweep B (round 5): on a flat or blank page every pixel is a candidate for the variance maximum.  The
+    candidate list is taken per wavefront-row with one atomic, a page may hold a quarter of it in a batch, and a page past its
+    share only marks itself (cand_overflow) - the ordinary pages of the same call keep their candidates and stay on the fast
+    path.  Two big flat pages around four document pages, several calls in a row on one stream: every mask equals the oracle's,
+    no document page falls to the literal pipeline."""
+    import torch
+
+    shape = (900, 1300)
+    docs = _pages(shape, ["doc", "doc", "doc", "doc"], seed=77)
+    batch = [np.full(shape, 137, np.uint8)] + docs[:2] + [np.zeros(shape, np.uint8)] + docs[2:] + [np.full(shape, 255, np.uint8)]
+    t = torch.from_numpy(np.stack(batch)).to(cuda_device)
+    for win, k, morph in ((31, 0.3, 0), (101, 0.01, 2), (15, 0.5, 0)):
+        want = _oracle_batch(oracle, batch, WOLFJOLION, win, k, morph)
+        for rep in range(2):
+            got = prl.binarize(t, prl.make_params(WOLFJOLION, win, k, morph)).cpu().numpy()
+            st = prl.last_stats()
+            for i in range(len(batch)):
+                assert np.array_equal(got[i], want[i]), (win, k, morph, rep, i, int((got[i] != want[i]).sum()))
+            assert st.literal_pages <= 3, (win, st.literal_pages)          # at most the three flat pages, never a document
+    # a single flat page has the whole list: still exact
+    one = torch.from_numpy(batch[0]).to(cuda_device)
+    assert np.array_equal(prl.binarize(one, prl.make_params(WOLFJOLION, 31, 0.3, 0)).cpu().numpy(),
+                          oracle.binarize(batch[0], oracle.make_params(oracle.WOLFJOLION, 31, 0.3, 0)))
+
+
 def test_wolfjolion_batches_larger_than_the_per_call_wavefront_budget(cuda_device):
     """Wolf-Jolion keeps one maximum per wavefront of a call (2^20 slots); a batch with more wavefronts used
     to be rejected with PRL_ERR_BAD_ARG.  The C ABI now cuts such batches into page chunks (fused_max_pages).  The slot
