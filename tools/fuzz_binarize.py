@@ -20,6 +20,8 @@ ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--methods", default="0,1,2,3,4", help="comma-separated method ids to draw from (2 = Wolf-Jolion)")
 ap.add_argument("--wide", type=float, default=0.0, help="probability of a window from {41..129} (the wide-window paths)")
 ap.add_argument("--hooks", type=int, default=0, help="1: load libprlib_hip_testhooks.so (reads the PRL_HIP_* knobs)")
+ap.add_argument("--real", type=float, default=0.0, help="probability that a page is cut from one of the reference's scans (tests/golden/scans, "
+                "tests/golden/stages: random crop, flip, transposition, gain / offset) instead of being synthetic")
 a = ap.parse_args()
 if a.hooks:
     prlib_amd._capi.use_library(prlib_amd._capi.HOOKS_LIB_PATH)
@@ -28,7 +30,34 @@ dev = torch.device("cuda:0")
 METHODS = [int(m) for m in a.methods.split(",")]
 
 
+REAL = []
+if a.real > 0:
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "tests", "golden", "scans", "*.npz"))):
+        REAL.append(np.load(f)["gray"])
+    for f in sorted(glob.glob(os.path.join(root, "tests", "golden", "stages", "chain_*.npz"))):
+        REAL.append(oc.bgr2gray(np.load(f)["bgr"]))
+
+
+def real_page(h, w):
+    g = REAL[int(rng.integers(0, len(REAL)))]
+    if rng.random() < 0.3:
+        g = g.T
+    if g.shape[0] < h or g.shape[1] < w:   # tile up to the size
+        g = np.tile(g, (-(-h // g.shape[0]), -(-w // g.shape[1])))
+    y0, x0 = int(rng.integers(0, g.shape[0] - h + 1)), int(rng.integers(0, g.shape[1] - w + 1))
+    c = g[y0:y0 + h, x0:x0 + w]
+    if rng.random() < 0.5:
+        c = c[:, ::-1]
+    if rng.random() < 0.4:   # exposure: gain / offset, clipped (saturated regions as over- and under-exposed scans have)
+        c = np.clip(c.astype(np.float32) * float(rng.uniform(0.6, 1.6)) + float(rng.uniform(-60, 60)), 0, 255)
+    return np.ascontiguousarray(c).astype(np.uint8)
+
+
 def page(h, w, kind, i):
+    if REAL and rng.random() < a.real:
+        return real_page(h, w)
     if kind == 0:
         return synth.page_numpy(h, w, index=int(rng.integers(0, 1 << 20)))
     if kind == 1:
