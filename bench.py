@@ -287,7 +287,12 @@ def main():
     elif args.scaling == "weak" and args.gpus > 1:
         args.scaling = "both"   # N > 1: the weak-scaling line carries the strong-scaling measurement as well (`strong`)
     traffic, traffic_note = None, "not measured (--traffic 0 or N > 1)"
-    if args.traffic and args.gpus == 1 and args.mode == "auto" and os.environ.get("PRL_BENCH_DRYRUN") != "1":
+    under_profiler = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    if under_profiler:
+        # a profiler's preloaded library has initialised the GPU in this process already: starting the counter passes from
+        # here would be an exec() from a GPU-initialised process, which the pool refuses
+        traffic_note = "not measured: this run is itself under a profiler"
+    elif args.traffic and args.gpus == 1 and args.mode == "auto" and os.environ.get("PRL_BENCH_DRYRUN") != "1":
         traffic, traffic_note = measure_traffic(args)   # child processes, before anything here touches the GPU
     import torch
 

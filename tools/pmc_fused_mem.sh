@@ -2,7 +2,7 @@
 # memory-pipeline counters of k_fused (typed-load float pipeline vs integer pipeline): tools/pmc_fused_mem.sh <tag>
 # every profiler run sits under its own timeout: an unknown counter name can hang rocprofv3
 TAG=${1:-flt}; OUT=$PWD/gpurun_out/pmcmem_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --cpu-seconds 0 --check-pages 0"
+ARGS="--steps 3 --warmup 1 --cpu-seconds 0 --check-pages 0 --traffic 0 --ceilings 0 --worst-case 0 --end-to-end 0"
 run() { n=$1; shift; timeout 150 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$n -- python3 bench.py $ARGS > $OUT/$n.log 2>&1; }
 run p1 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_WAIT_ANY
 run p3 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE
