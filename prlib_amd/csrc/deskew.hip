@@ -1128,6 +1128,56 @@ int deskew_pages_per_pass(int n_pages, int width, int height)
     return (int)std::max<size_t>(1, std::min<size_t>({(size_t)n_pages, (size_t)16384, budget / ppht_bytes_per_page(width, height)}));
 }
 
+// Ink census (round 5): the number of points HoughLinesP will see on each page - the pixels at or below the page's Otsu threshold -
+// from the gray histogram alone (one streaming read of the pages; no mask, no lists).  The chain sizes its passes with it: the
+// search of a pass lasts as long as its heaviest page (0.6 us per point through one CU's atomic path), so a batch of photographs
+// with a dark table in them wants few large passes, text scans the usual ones.  Synchronises `hs`.
+int deskew_ink_census(DeviceCtx* ctx, int n_pages, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
+                      int height, std::vector<unsigned>* points, hipStream_t hs)
+{
+    points->assign((size_t)n_pages, 0u);
+    const size_t gray_page = r256((size_t)width * height);
+    const int sub = channels == 1 ? std::min(n_pages, 4096) : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_pages, ((size_t)512 << 20) / gray_page));
+    std::lock_guard<std::mutex> lk(ctx->ppht_mu);
+    int st = ensure_buffer(&ctx->ppht_buf[0], &ctx->ppht_bytes[0], r256((size_t)sub * 256 * 4) + r256((size_t)sub * 4));
+    if (st != PRL_OK) return st;
+    unsigned* d_hist = static_cast<unsigned*>(ctx->ppht_buf[0]);
+    int* d_thr = reinterpret_cast<int*>(static_cast<uint8_t*>(ctx->ppht_buf[0]) + r256((size_t)sub * 256 * 4));
+    if (channels != 1) {
+        st = ensure_buffer(&ctx->ppht_buf[2], &ctx->ppht_bytes[2], gray_page * (size_t)sub);
+        if (st != PRL_OK) return st;
+    }
+    std::vector<unsigned> h_hist((size_t)sub * 256);
+    std::vector<int> h_thr((size_t)sub);
+    for (int first = 0; first < n_pages; first += sub) {
+        const int cnt = std::min(sub, n_pages - first);
+        PageSet g{};
+        if (channels != 1) {
+            uint8_t* gray_ws = static_cast<uint8_t*>(ctx->ppht_buf[2]);
+            st = prl_hip_bgr2gray_batch_device(cnt, channels, src + (size_t)first * src_page_stride, src_page_stride, src_step, width, height,
+                                               gray_ws, gray_page, (size_t)width, hs);
+            if (st != PRL_OK) return st;
+            g.base = gray_ws; g.page_stride = gray_page; g.step = (size_t)width;
+        } else {
+            g.base = src + (size_t)first * src_page_stride; g.page_stride = src_page_stride; g.step = src_step;
+        }
+        PRL_HIP_CHECK(hipMemsetAsync(d_hist, 0, (size_t)cnt * 256 * 4, hs));
+        const dim3 hg((unsigned)std::min(4, (width + 1023) / 1024), (unsigned)std::min(height, 64), (unsigned)cnt);
+        hipLaunchKernelGGL(k_hist, hg, dim3(256), 0, hs, g, width, height, d_hist);
+        hipLaunchKernelGGL(k_otsu, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, hs, d_hist, width, height, cnt, d_thr);
+        PRL_HIP_CHECK(hipGetLastError());
+        PRL_HIP_CHECK(hipMemcpyAsync(h_hist.data(), d_hist, (size_t)cnt * 256 * 4, hipMemcpyDeviceToHost, hs));
+        PRL_HIP_CHECK(hipMemcpyAsync(h_thr.data(), d_thr, (size_t)cnt * 4, hipMemcpyDeviceToHost, hs));
+        PRL_HIP_CHECK(hipStreamSynchronize(hs));
+        for (int i = 0; i < cnt; ++i) {
+            unsigned long long n = 0;
+            for (int v = 0; v <= std::min(255, std::max(-1, h_thr[(size_t)i])); ++v) n += h_hist[(size_t)i * 256 + v];
+            (*points)[(size_t)(first + i)] = (unsigned)std::min<unsigned long long>(n, 0xffffffffull);
+        }
+    }
+    return PRL_OK;
+}
+
 // First half of prl::deskew on `cnt` pages (cnt <= deskew_pages_per_pass): gray -> Otsu -> HoughLinesP -> angle vote.
 int deskew_find(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
                 int height, DeskewPlan* plan, hipStream_t hs, SearchStart* start)

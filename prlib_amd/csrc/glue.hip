@@ -422,6 +422,33 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
         first_sz = n_pages >= 3 * want_first ? std::min(main_sz, want_first) : main_sz;
         adaptive = cp->denoise && env_knobs().chain_overlap == 2 && env_knobs().chain_pass == 0;
     }
+    // Tail-aware passes (round 5).  The search of a pass takes max(its heaviest page's own time, the pass's share of the chip's
+    // atomic rate): kTailS seconds per point for one page (one CU's path for scattered returning atomics), kRateS per point for
+    // the chip.  On text scans the second term rules and passes of ~192 pages pipeline well; on photographs with dark tables in
+    // them (the reference's own test images: up to 89 % of a page dark after Otsu) every pass pays its heaviest page - 4.4 s -
+    // and two passes cost twice what one would.  A pass is therefore extended for as long as the pages added to it hide behind
+    // its heaviest page (cheap census of the dark pixels per page first; constants from profiles/r05: 7.4e6 points 4.4 s alone,
+    // 256 pages of 0.84e6 points 1.18 s).  The NL-means balance controller stays off for such a batch.
+    std::vector<unsigned> ink;
+    if (cp->deskew && env_knobs().chain_overlap && env_knobs().chain_pass == 0 && n_pages > main_sz) {
+        constexpr double kTailS = 0.6e-6, kRateS = 5.5e-9;
+        st = deskew_ink_census(ctx, n_pages, channels, d_src, src_page_stride, src_step, width, height, &ink, static_cast<hipStream_t>(stream));
+        if (st != PRL_OK) return st;
+        unsigned heaviest = 0;
+        double sum = 0.0;
+        int fit = 0;   // pages of the first pass that hide behind the heaviest of them
+        for (int i = 0; i < std::min(n_pages, chunk); ++i) {
+            heaviest = std::max(heaviest, ink[(size_t)i]);
+            sum += ink[(size_t)i];
+            if (sum * kRateS <= heaviest * kTailS) fit = i + 1;
+        }
+        if (fit > main_sz * 5 / 4) {
+            main_sz = first_sz = std::min(chunk, fit);
+            adaptive = false;
+            if (env_knobs().debug)
+                std::fprintf(stderr, "[prl chain] tail-bound batch: heaviest page %u points, passes of %d pages\n", heaviest, main_sz);
+        }
+    }
     // the largest pass the workspace is sized for (an adaptive schedule may grow by a third)
     const int max_cnt = std::max(1, std::min({chunk, n_pages, adaptive ? std::max(main_sz, first_sz) * 4 / 3 : std::max(main_sz, first_sz)}));
     auto next_count = [&](int first) {

@@ -283,6 +283,9 @@ struct SearchStart {
 };
 int deskew_find(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
                 int height, DeskewPlan* plan, hipStream_t hs, SearchStart* start = nullptr);
+// dark pixels (<= the page's Otsu threshold) per page = the points HoughLinesP will visit; takes ctx->ppht_mu, synchronises hs
+int deskew_ink_census(DeviceCtx* ctx, int n_pages, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
+                      int height, std::vector<unsigned>* points, hipStream_t hs);
 // prl::rotate of every page by its angle (copy where none was found); takes ctx->mu
 int deskew_apply(DeviceCtx* ctx, const DeskewPlan& plan, int cnt, int channels, const uint8_t* src, size_t src_page_stride,
                  size_t src_step, int width, int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, hipStream_t hs);
