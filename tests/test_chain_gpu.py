@@ -229,6 +229,34 @@ print("DONE")
         assert np.array_equal(z["p%d" % i], outs[i].cpu().numpy()), i
 
 
+def test_tail_aware_passes_give_the_same_pages(prl, cuda_device):
+    """More pages than one default pass (192 with denoise) and one page that is almost all ink: the chain's census of the dark
+    pixels finds that the other pages' search hides behind that page's, and runs the batch as one large pass instead of
+    192 + 68 (glue.hip, round 5).  Page by page the results equal those of the same pages sent in two calls small enough to be
+    single default passes (which take no census)."""
+    import torch
+    from prlib_amd import synth
+
+    h, w, n = 120, 176, 260
+    pages = np.stack([np.repeat(synth.text_page_numpy(h, w, 300 + i, skew_deg=(i % 7) - 3.0, shading=0.2)[..., None], 3, axis=2) for i in range(n)])
+    rng = np.random.default_rng(5)
+    pages[17] = np.clip(rng.normal(40, 12, (h, w, 3)), 0, 255).astype(np.uint8)      # a dark photograph: nearly every pixel is a point
+    pages[17, 30:90, 20:150] = 235                                                  # ... with a bright sheet in it
+    t = torch.from_numpy(pages).to(cuda_device)
+    kw = dict(denoise_strength=5.5, thin=0, deskew=True, background_normalization=True)
+    prl.deskew_stats(reset=True)
+    outs, angles = prl.process_pages(t, 3, prl.SAUVOLA, 15, 0.34, 0, **kw)
+    assert prl.deskew_stats().pages == n
+    ref_outs, ref_angles = [], []
+    for lo, hi in ((0, 130), (130, n)):
+        o, a = prl.process_pages(t[lo:hi], 3, prl.SAUVOLA, 15, 0.34, 0, **kw)
+        ref_outs += o
+        ref_angles += list(a)
+    assert list(angles) == ref_angles
+    for i in range(n):
+        assert outs[i].shape == ref_outs[i].shape and torch.equal(outs[i], ref_outs[i]), i
+
+
 def test_chain_on_host_pages(prl, oracle, cuda_device):
     """prl_hip_chain_batch_host: the caller's host pages through upload -> chain -> download, in device chunks of two pages
     (PRL_HIP_CHAIN_HOST_PAGES=2 in a child process) so that upload, chain and download of different chunks overlap; equal
