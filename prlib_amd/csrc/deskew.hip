@@ -165,6 +165,7 @@ struct PphtArgs {
     const float* ttab;          // kNumAngle x {cos, sin}
     int* lines; const unsigned long long* lines_off; const unsigned* lines_cap; unsigned* n_lines;
     int prio;                   // raise the wavefront priority (PRL_HIP_PPHT_PRIO)
+    const int* page_list;       // workgroup b takes page page_list[b], its accumulator is the b-th (null: page b)
     unsigned long long* prof;   // hooks build, PRL_HIP_PPHT_PROF=1: 16 counters per page (cycles per phase, event counts); else null
 };
 
@@ -228,6 +229,7 @@ __device__ __forceinline__ int vote(int* cell, int d) { return __hip_atomic_fetc
 // bit, and the un-votes of a good line can be taken from TWO adjacent cells with one 64-bit subtraction - the low half never
 // borrows from the high one, because a biased cell is never smaller than what is subtracted from it.
 constexpr unsigned kAccBias = 0x80000000u;
+static_assert(kNumAngle % 2 == 0, "a page's accumulator must be a whole number of 8-byte cell pairs (Unvotes)");
 __device__ __forceinline__ int count_of(int stored) { return (int)((unsigned)stored ^ kAccBias); }
 
 // The un-votes of one lane's angle along a line walk.  For a fixed angle the cell index r = round(x cos + y sin) is monotone
@@ -276,11 +278,11 @@ __global__ void __launch_bounds__(64) k_ppht(PphtArgs a)
     // One latency-bound wavefront per page that issues little: in the chain it shares its SIMD with the NL-means wavefronts of
     // the previous pass (glue.hip), which saturate the vector ALU - let the arbiter pick this one first.
     if (a.prio) __builtin_amdgcn_s_setprio(3);
-    const int page = blockIdx.x, lane = threadIdx.x;
+    const int page = a.page_list ? a.page_list[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     const int W = a.width, H = a.height, numrho = a.numrho;
     volatile uint8_t* mask = a.mask + (size_t)page * a.mask_page;
     volatile unsigned* nz = a.nz + a.nz_off[page];
-    int* accum = a.accum + (size_t)page * kNumAngle * numrho;
+    int* accum = a.accum + (size_t)blockIdx.x * kNumAngle * numrho;
     int* lines = a.lines + a.lines_off[page] * 4;
     const unsigned cap = a.lines_cap[page];
     float tc[3], ts[3];
@@ -495,11 +497,11 @@ __global__ void __launch_bounds__(64 * kMwWaves) k_ppht_mw(PphtArgs a)
     __shared__ int s_keys[2][kMwWaves][kBlkMw];
     __shared__ unsigned long long s_ballot[kMwMaxGroups];
     if (a.prio) __builtin_amdgcn_s_setprio(3);
-    const int page = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int page = a.page_list ? a.page_list[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int W = a.width, H = a.height, numrho = a.numrho;
     volatile uint8_t* mask = a.mask + (size_t)page * a.mask_page;
     volatile unsigned* nz = a.nz + a.nz_off[page];
-    int* accum = a.accum + (size_t)page * kNumAngle * numrho;
+    int* accum = a.accum + (size_t)blockIdx.x * kNumAngle * numrho;
     int* lines = a.lines + a.lines_off[page] * 4;
     const unsigned cap = a.lines_cap[page];
     const int ang = wv * 64 + lane;
@@ -967,8 +969,7 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     const size_t b_rows = r256((size_t)n_pages * height * 4), b_cnt = r256((size_t)n_pages * 4), b_off = r256((size_t)n_pages * 8);
     const size_t b_ttab = r256(kNumAngle * 2 * 4);
     const size_t b_mask = mask_page * (size_t)n_pages;
-    const size_t b_accum = r256((size_t)n_pages * kNumAngle * numrho * 4);
-    const size_t fixed = b_hist + b_thr + 2 * b_rows + 3 * b_cnt + 2 * b_off + b_ttab + b_mask + b_accum;
+    const size_t fixed = b_hist + b_thr + 2 * b_rows + 4 * b_cnt + 2 * b_off + b_ttab + b_mask;
     int st = ensure_buffer(&ctx->ppht_buf[0], &ctx->ppht_bytes[0], fixed);
     if (st != PRL_OK) return st;
     uint8_t* w = static_cast<uint8_t*>(ctx->ppht_buf[0]);
@@ -983,8 +984,8 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     unsigned long long* d_nzoff = reinterpret_cast<unsigned long long*>(take(b_off));
     unsigned long long* d_lnoff = reinterpret_cast<unsigned long long*>(take(b_off));
     float* d_ttab = reinterpret_cast<float*>(take(b_ttab));
+    int* d_plist = reinterpret_cast<int*>(take(b_cnt));
     uint8_t* d_mask = take(b_mask);
-    int* d_accum = reinterpret_cast<int*>(take(b_accum));
 
     std::vector<int> h_thr((size_t)n_pages, fixed_thr);
     if (otsu) {
@@ -1037,41 +1038,115 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
         h_ttab[2 * n + 1] = (float)(std::sin((double)n * theta) * irho);
     }
     PRL_HIP_CHECK(hipMemcpyAsync(d_ttab, h_ttab, sizeof(h_ttab), hipMemcpyHostToDevice, stream));
-    PRL_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_accum), (int)kAccBias, (size_t)n_pages * kNumAngle * numrho, stream));   // count 0 = bias
     hipLaunchKernelGGL(k_collect, dim3((unsigned)height, (unsigned)n_pages), dim3(64), 0, stream, width, height, d_mask, mask_page,
                        d_rowoff, d_nzoff, d_nz);
+    PRL_HIP_CHECK(hipGetLastError());
+    PRL_HIP_CHECK(hipMemsetAsync(d_nlines, 0, (size_t)n_pages * 4, stream));
+    if (start && start->ev) PRL_HIP_CHECK(hipEventRecord(start->ev, stream));   // the streaming prelude ends here
+
+    // ---- the transform.  Pages that qualify go to the group kernel (accumulator in LDS, ppht_group.hip); what it does not
+    // finish - pages too large for int16 cells, a group that gave up waiting - is done by k_ppht_mw below, in this call. ----
+    std::vector<unsigned> h_status((size_t)n_pages, 0u);
+    std::vector<unsigned long long> h_gprof;
+    PphtGroupIn gin;
+    const int grp_env = env_knobs().ppht_group;
+    bool group_ran = false;
+    if (grp_env != 0 && ppht_group_eligible(width, height, threshold)) {
+        gin.n_pages = n_pages; gin.width = width; gin.height = height; gin.threshold = threshold; gin.line_length = line_length;
+        gin.line_gap = line_gap; gin.d_mask = d_mask; gin.mask_page = mask_page; gin.d_nz = d_nz; gin.d_nzoff = d_nzoff; gin.d_count = d_count;
+        gin.d_ttab = d_ttab; gin.h_ttab = h_ttab; gin.d_lines = d_lines; gin.d_lnoff = d_lnoff; gin.d_cap = d_cap; gin.d_nlines = d_nlines;
+        gin.h_count = h_count.data(); gin.h_nzoff = h_nzoff.data();
+        gin.page_list.resize((size_t)n_pages);
+        for (int i = 0; i < n_pages; ++i) gin.page_list[(size_t)i] = i;
+        std::stable_sort(gin.page_list.begin(), gin.page_list.end(), [&](int x, int y) { return h_count[(size_t)x] > h_count[(size_t)y]; });
+        gin.status_out = h_status.data();
+#ifdef PRL_TEST_HOOKS
+        if (std::getenv("PRL_HIP_PPHT_PROF")) { h_gprof.assign((size_t)n_pages * 12, 0ull); gin.prof_out = h_gprof.data(); }
+#endif
+        hipEvent_t dbg_ev[3] = {nullptr, nullptr, nullptr};
+        if (env_knobs().debug) {
+            for (hipEvent_t& e : dbg_ev) PRL_HIP_CHECK(hipEventCreate(&e));
+            PRL_HIP_CHECK(hipEventRecord(dbg_ev[2], stream));
+            gin.ev[0] = dbg_ev[0]; gin.ev[1] = dbg_ev[1];
+        }
+        struct EvFree { hipEvent_t* e; ~EvFree() { for (int i = 0; i < 3; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_free{dbg_ev};
+        const int gst = ppht_group_run(ctx, gin, stream);
+        if (gst == PRL_OK && env_knobs().debug) {
+            PRL_HIP_CHECK(hipStreamSynchronize(stream));
+            float ms_pre = 0, ms_k = 0;
+            (void)hipEventElapsedTime(&ms_pre, dbg_ev[2], dbg_ev[0]);
+            (void)hipEventElapsedTime(&ms_k, dbg_ev[0], dbg_ev[1]);
+            std::fprintf(stderr, "[prl ppht] visiting order + bit masks %.2f ms, group kernel %.2f ms\n", ms_pre, ms_k);
+        }
+        group_ran = gst == PRL_OK;
+        if (gst == PRL_ERR_NOMEM) return gst;
+    }
+    if (start) start->launched();
+    std::vector<unsigned> h_nl((size_t)n_pages);
+    std::vector<int> h_lines((size_t)ln_total * 4 + 4);
+    std::vector<int> redo;
+    if (group_ran) {
+        PRL_HIP_CHECK(hipStreamSynchronize(stream));
+        for (int i = 0; i < n_pages; ++i)
+            if (h_status[(size_t)i] != 1u) redo.push_back(i);
+        if (env_knobs().debug)
+            std::fprintf(stderr, "[prl ppht] group kernel: %d pages, %d members per group, %d groups, %d workgroups, %d bytes of LDS; %zu pages left to k_ppht_mw\n",
+                         n_pages, gin.geometry_out[0], gin.geometry_out[1], gin.geometry_out[2], gin.geometry_out[3], redo.size());
+#ifdef PRL_TEST_HOOKS
+        if (gin.prof_out) {
+            std::fprintf(stderr, "{\"ppht_group_prof\": {\"pages\": %d, \"width\": %d, \"height\": %d, \"members\": %d, \"groups\": %d, \"per_page\": [", n_pages, width,
+                         height, gin.geometry_out[0], gin.geometry_out[1]);
+            for (int i = 0; i < std::min(n_pages, 4); ++i) {
+                const int pg = gin.page_list[(size_t)i];
+                const unsigned long long* q = h_gprof.data() + (size_t)pg * 12;
+                std::fprintf(stderr, "%s{\"page\": %d, \"points\": %u, \"exchanges\": %llu, \"blocks\": %llu, \"triggers\": %llu, \"good_lines\": %llu, \"walk_rounds\": %llu, \"cyc\": {\"fetch\": %llu, \"vote\": %llu, \"exchange\": %llu, \"rollback\": %llu, \"walk1\": %llu, \"walk2\": %llu, \"strike\": %llu}}",
+                             i ? ", " : "", pg, h_count[(size_t)pg], q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]);
+            }
+            std::fprintf(stderr, "]}}\n");
+        }
+#endif
+    } else {
+        for (int i = 0; i < n_pages; ++i) redo.push_back(i);
+    }
     PphtArgs a{};
-    a.width = width; a.height = height; a.numrho = numrho; a.threshold = threshold; a.line_length = line_length; a.line_gap = line_gap;
-    a.mask = d_mask; a.mask_page = mask_page; a.nz = d_nz; a.nz_off = d_nzoff; a.count = d_count; a.accum = d_accum; a.ttab = d_ttab;
-    a.lines = d_lines; a.lines_off = d_lnoff; a.lines_cap = d_cap; a.n_lines = d_nlines;
-    a.prio = env_knobs().ppht_prio;
     a.prof = nullptr;
 #ifdef PRL_TEST_HOOKS
     unsigned long long* d_prof = nullptr;
-    if (std::getenv("PRL_HIP_PPHT_PROF")) {
-        PRL_HIP_CHECK(hipMalloc(&d_prof, (size_t)n_pages * 16 * 8));
-        PRL_HIP_CHECK(hipMemsetAsync(d_prof, 0, (size_t)n_pages * 16 * 8, stream));
-        a.prof = d_prof;
-    }
+    struct FreeProf { unsigned long long*& p; ~FreeProf() { if (p) (void)hipFree(p); } } free_prof{d_prof};
 #endif
-    // three wavefronts per page (shorter critical path per page; equal to one per page once the memory system is the limit)
-    const int mw_env = env_knobs().ppht_mw;
-    if (start && start->ev) PRL_HIP_CHECK(hipEventRecord(start->ev, stream));   // the streaming prelude ends here
-    if (mw_env == 1 || (mw_env < 0 && n_pages <= kPphtMwMaxPages)) hipLaunchKernelGGL(k_ppht_mw, dim3((unsigned)n_pages), dim3(64 * kMwWaves), 0, stream, a);
-    else hipLaunchKernelGGL(k_ppht, dim3((unsigned)n_pages), dim3(64), 0, stream, a);
-    if (start) start->launched();
-
-    PRL_HIP_CHECK(hipGetLastError());
-    std::vector<unsigned> h_nl((size_t)n_pages);
-    std::vector<int> h_lines((size_t)ln_total * 4 + 4);
+    if (!redo.empty()) {
+        const int n_redo = (int)redo.size();
+        const size_t b_accum = r256((size_t)n_redo * kNumAngle * numrho * 4);
+        st = ensure_buffer(&ctx->ppht_buf[4], &ctx->ppht_bytes[4], b_accum);
+        if (st != PRL_OK) return st;
+        int* d_accum = static_cast<int*>(ctx->ppht_buf[4]);
+        PRL_HIP_CHECK(hipMemcpyAsync(d_plist, redo.data(), (size_t)n_redo * 4, hipMemcpyHostToDevice, stream));
+        PRL_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_accum), (int)kAccBias, (size_t)n_redo * kNumAngle * numrho, stream));   // count 0 = bias
+        a.width = width; a.height = height; a.numrho = numrho; a.threshold = threshold; a.line_length = line_length; a.line_gap = line_gap;
+        a.mask = d_mask; a.mask_page = mask_page; a.nz = d_nz; a.nz_off = d_nzoff; a.count = d_count; a.accum = d_accum; a.ttab = d_ttab;
+        a.lines = d_lines; a.lines_off = d_lnoff; a.lines_cap = d_cap; a.n_lines = d_nlines;
+        a.prio = env_knobs().ppht_prio;
+        a.page_list = d_plist;
+#ifdef PRL_TEST_HOOKS
+        if (std::getenv("PRL_HIP_PPHT_PROF")) {
+            PRL_HIP_CHECK(hipMalloc(&d_prof, (size_t)n_pages * 16 * 8));
+            PRL_HIP_CHECK(hipMemsetAsync(d_prof, 0, (size_t)n_pages * 16 * 8, stream));
+            a.prof = d_prof;
+        }
+#endif
+        // three wavefronts per page (shorter critical path per page; equal to one per page once the memory system is the limit)
+        const int mw_env = env_knobs().ppht_mw;
+        if (mw_env == 1 || (mw_env < 0 && n_redo <= kPphtMwMaxPages)) hipLaunchKernelGGL(k_ppht_mw, dim3((unsigned)n_redo), dim3(64 * kMwWaves), 0, stream, a);
+        else hipLaunchKernelGGL(k_ppht, dim3((unsigned)n_redo), dim3(64), 0, stream, a);
+        PRL_HIP_CHECK(hipGetLastError());
+    }
     PRL_HIP_CHECK(hipMemcpyAsync(h_nl.data(), d_nlines, (size_t)n_pages * 4, hipMemcpyDeviceToHost, stream));
     PRL_HIP_CHECK(hipMemcpyAsync(h_lines.data(), d_lines, (size_t)ln_total * 16, hipMemcpyDeviceToHost, stream));
     PRL_HIP_CHECK(hipStreamSynchronize(stream));
 #ifdef PRL_TEST_HOOKS
     if (d_prof) {   // one JSON line per call on stderr: the three heaviest pages and the sum, cycles per phase and event counts
         std::vector<unsigned long long> hp((size_t)n_pages * 16);
-        (void)hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost);
-        (void)hipFree(d_prof);
+        if (hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) std::fill(hp.begin(), hp.end(), 0ull);
         std::vector<int> order((size_t)n_pages);
         for (int i = 0; i < n_pages; ++i) order[(size_t)i] = i;
         auto total = [&](int i) { unsigned long long t = 0; for (int k = 0; k < 6; ++k) t += hp[(size_t)i * 16 + k]; return t; };

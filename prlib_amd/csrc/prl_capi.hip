@@ -96,6 +96,12 @@ const EnvKnobs& env_knobs()
         k.nlm_glut = (int)geti("PRL_NLM_GLUT", 0);
         k.ppht_mw = (int)geti("PRL_HIP_PPHT_MW", -1);
         k.ppht_prio = (int)geti("PRL_HIP_PPHT_PRIO", 3);
+        k.ppht_group = (int)geti("PRL_HIP_PPHT_GROUP", -1);
+        k.ppht_group_g = (int)std::max(1ll, std::min(32ll, geti("PRL_HIP_PPHT_GROUP_G", 1)));
+        k.ppht_group_xcd = is0("PRL_HIP_PPHT_GROUP_XCD") ? 0 : 1;
+        k.ppht_group_spin_ms = (int)std::max(1ll, geti("PRL_HIP_PPHT_GROUP_SPIN_MS", 2000));
+        k.ppht_group_kill = (int)geti("PRL_HIP_PPHT_GROUP_KILL", -1);
+        k.ppht_group_cus = (int)std::max(0ll, geti("PRL_HIP_PPHT_GROUP_CUS", 0));
         k.chain_host_pages = (int)std::max(0ll, geti("PRL_HIP_CHAIN_HOST_PAGES", 0));
         k.fake_devices = (int)std::max(0ll, geti("PRL_HIP_FAKE_DEVICES", 0));
         k.chain_pass = (int)std::max(0ll, geti("PRL_HIP_CHAIN_PASS", 0));
@@ -1117,11 +1123,12 @@ int prl_hip_release_workspace(void)
         (void)resolve_all(kv.second.get());
     }
     PRL_HIP_CHECK(hipDeviceSynchronize());
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < DeviceCtx::kPphtBufs; ++i) {
         if (ctx->ppht_buf[i]) PRL_HIP_CHECK(hipFree(ctx->ppht_buf[i]));
         ctx->ppht_buf[i] = nullptr;
         ctx->ppht_bytes[i] = 0;
     }
+    ctx->ppht_rnd_n = 0;
     for (int i = 0; i < 4; ++i) {
         if (ctx->host_buf[i]) PRL_HIP_CHECK(hipFree(ctx->host_buf[i]));
         ctx->host_buf[i] = nullptr;

@@ -73,8 +73,12 @@ struct DeviceCtx {
     // The angle search of prl::deskew has its own workspace, lock and stream: in the chain it runs for the next pass
     // while the other stages of the current one use `scratch` / `mask` / `small` (glue.hip).
     std::mutex ppht_mu;
-    void* ppht_buf[3] = {nullptr, nullptr, nullptr};  // fixed part (mask, accumulators ...), point / segment lists, gray pages
-    size_t ppht_bytes[3] = {0, 0, 0};
+    // fixed part (masks, lists' layout ...), point / segment lists, gray pages, the group kernel's workspace (ppht_group.hip),
+    // accumulators in device memory (k_ppht_mw, for the pages the group kernel did not take), cv::RNG's output
+    static constexpr int kPphtBufs = 6;
+    void* ppht_buf[kPphtBufs] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t ppht_bytes[kPphtBufs] = {0, 0, 0, 0, 0, 0};
+    size_t ppht_rnd_n = 0;          // numbers of cv::RNG(-1)'s sequence resident in ppht_buf[5]
     hipStream_t host_run = nullptr; // stream of prl_hip_chain_batch_host's device work (kept: its per-stream workspaces persist)
     // page buffers and pinned bounce slots of prl_hip_chain_batch_host, kept between calls (allocating and freeing tens of
     // gigabytes per call cost two seconds); one such call at a time per device
@@ -113,6 +117,12 @@ struct EnvKnobs {
     size_t deskew_work_mb = 24576;      // PRL_HIP_DESKEW_WORK_MB
     int ppht_mw = -1;                   // PRL_HIP_PPHT_MW   1 / 0: always / never three wavefronts per page (default: by batch size)
     int ppht_prio = 3;                  // PRL_HIP_PPHT_PRIO=0   k_ppht does not raise its wavefront priority
+    int ppht_group = -1;                // PRL_HIP_PPHT_GROUP    1 / 0: always (where a page qualifies) / never the on-chip group kernel (ppht_group.hip)
+    int ppht_group_g = 1;               // PRL_HIP_PPHT_GROUP_G  at least this many workgroups per page
+    int ppht_group_xcd = 1;             // PRL_HIP_PPHT_GROUP_XCD=0   a group's members on consecutive workgroup ids instead of one XCD
+    int ppht_group_spin_ms = 2000;      // PRL_HIP_PPHT_GROUP_SPIN_MS how long a member waits for its group before the group gives up
+    int ppht_group_kill = -1;           // PRL_HIP_PPHT_GROUP_KILL=n  (tests) member 1 of group 0 falls silent after n exchanges
+    int ppht_group_cus = 0;             // PRL_HIP_PPHT_GROUP_CUS     workgroups of the group kernel at most (0: one per CU)
     int chain_pass = 0, chain_first_pass = 0;   // PRL_HIP_CHAIN_PASS / PRL_HIP_CHAIN_FIRST_PASS   pages per pass of the chain with deskew (0: start at 192 with denoise, then follow the measured search / NL-means times; else 256)
     int chain_overlap = 2;              // PRL_HIP_CHAIN_OVERLAP   0: passes one after the other; 1: the search of the next pass beside all stages
                                         //                         of this one; 2: beside its NL-means kernels only (head / body / tail, glue.hip)
@@ -291,6 +301,25 @@ int deskew_apply(DeviceCtx* ctx, const DeskewPlan& plan, int cnt, int channels, 
                  size_t src_step, int width, int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, hipStream_t hs);
 int deskew_pages(DeviceCtx* ctx, int cnt, int channels, const uint8_t* src, size_t src_page_stride, size_t src_step, int width,
                  int height, uint8_t* dst, size_t dst_page_stride, size_t dst_step, int32_t* out_wh, double* angles, hipStream_t hs);
+// ppht_group.hip: HoughLinesP's second stage with the accumulator in LDS, a group of workgroups per page.  Device pointers are
+// those of ppht_pages' workspace (deskew.hip); the host arrays must stay alive until the stream has been synchronised.
+struct PphtGroupIn {
+    int n_pages = 0, width = 0, height = 0, threshold = 0, line_length = 0, line_gap = 0;
+    const uint8_t* d_mask = nullptr; size_t mask_page = 0;          // byte masks (k_dark_mask)
+    const unsigned* d_nz = nullptr; const unsigned long long* d_nzoff = nullptr; const unsigned* d_count = nullptr;
+    const float* d_ttab = nullptr; const float* h_ttab = nullptr;
+    int* d_lines = nullptr; const unsigned long long* d_lnoff = nullptr; const unsigned* d_cap = nullptr; unsigned* d_nlines = nullptr;
+    const unsigned* h_count = nullptr; const unsigned long long* h_nzoff = nullptr;
+    std::vector<int> page_list;          // pages to process, heaviest first
+    int cu_limit = 0;                    // workgroups at most (0: one per CU)
+    hipEvent_t ev[2] = {nullptr, nullptr};   // optional: recorded before / after the group kernel (diagnostics)
+    unsigned* status_out = nullptr;      // host, n_pages: 1 = finished by the group kernel (valid after the stream sync)
+    unsigned long long* prof_out = nullptr;   // host, 12 per page (optional)
+    int geometry_out[4] = {0, 0, 0, 0};  // members per group, groups, workgroups, LDS bytes
+    std::vector<unsigned char> keep;     // host tables the asynchronous copies read
+};
+bool ppht_group_eligible(int width, int height, int threshold);
+int ppht_group_run(DeviceCtx* ctx, PphtGroupIn& in, hipStream_t stream);
 // glue.hip: pages per pass of the chain and its workspace bytes per page (host_batch.hip sizes device chunks in whole passes)
 int chain_pass_layout(const prl_chain_params* cp, int n_pages, int channels, int width, int height, int* pass_pages,
                       size_t* per_page_out, size_t* desk_page_out);

@@ -4,12 +4,13 @@ import glob, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 os.environ.setdefault("PRL_HIP_PPHT_PROF", "1")
+os.environ.setdefault("PRL_HIP_DEBUG", "1")
 import numpy as np, torch
 import prlib_amd
 from prlib_amd import _capi, synth
 from bench_real import tiled_colour_page
 
-_capi.use_library(_capi.HOOKS_LIB_PATH)
+_capi.use_library(os.environ.get('PRL_LIB', _capi.HOOKS_LIB_PATH))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 H, W = 3508, 2480
 dev = torch.device("cuda:0")
