@@ -1061,7 +1061,7 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
         std::stable_sort(gin.page_list.begin(), gin.page_list.end(), [&](int x, int y) { return h_count[(size_t)x] > h_count[(size_t)y]; });
         gin.status_out = h_status.data();
 #ifdef PRL_TEST_HOOKS
-        if (std::getenv("PRL_HIP_PPHT_PROF")) { h_gprof.assign((size_t)n_pages * 12, 0ull); gin.prof_out = h_gprof.data(); }
+        if (std::getenv("PRL_HIP_PPHT_PROF")) { h_gprof.assign((size_t)n_pages * 16, 0ull); gin.prof_out = h_gprof.data(); }
 #endif
         hipEvent_t dbg_ev[3] = {nullptr, nullptr, nullptr};
         if (env_knobs().debug) {
@@ -1096,11 +1096,19 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
         if (gin.prof_out) {
             std::fprintf(stderr, "{\"ppht_group_prof\": {\"pages\": %d, \"width\": %d, \"height\": %d, \"members\": %d, \"groups\": %d, \"per_page\": [", n_pages, width,
                          height, gin.geometry_out[0], gin.geometry_out[1]);
+            std::vector<int> by_time(gin.page_list);
+            auto cyc = [&](int pg) { unsigned long long t = 0; for (int k = 5; k < 12; ++k) t += h_gprof[(size_t)pg * 16 + k]; return t; };
+            std::sort(by_time.begin(), by_time.end(), [&](int x, int y) { return cyc(x) > cyc(y); });
             for (int i = 0; i < std::min(n_pages, 4); ++i) {
-                const int pg = gin.page_list[(size_t)i];
-                const unsigned long long* q = h_gprof.data() + (size_t)pg * 12;
-                std::fprintf(stderr, "%s{\"page\": %d, \"points\": %u, \"exchanges\": %llu, \"blocks\": %llu, \"triggers\": %llu, \"good_lines\": %llu, \"walk_rounds\": %llu, \"cyc\": {\"fetch\": %llu, \"vote\": %llu, \"exchange\": %llu, \"rollback\": %llu, \"walk1\": %llu, \"walk2\": %llu, \"strike\": %llu}}",
-                             i ? ", " : "", pg, h_count[(size_t)pg], q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]);
+                const int pg = by_time[(size_t)i];
+                const unsigned long long* q = h_gprof.data() + (size_t)pg * 16;
+                std::fprintf(stderr, "%s{\"page\": %d, \"points\": %u, \"exchanges\": %llu, \"blocks\": %llu, \"triggers\": %llu, \"good_lines\": %llu, \"walk_rounds\": %llu, \"cyc\": {\"fetch\": %llu, \"vote\": %llu, \"exchange\": %llu, \"rollback\": %llu, \"walk1\": %llu, \"walk2\": %llu, \"strike\": %llu, \"w1_load\": %llu, \"w1_bar1\": %llu, \"w1_run_bar2\": %llu, \"w1_eval\": %llu}}",
+                             i ? ", " : "", pg, h_count[(size_t)pg], q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11], q[12], q[13], q[14], q[15]);
+            }
+            std::fprintf(stderr, "], \"all_pages_points_triggers_mcycles\": [");
+            for (int i = 0; i < n_pages; ++i) {
+                const int pg = by_time[(size_t)i];
+                std::fprintf(stderr, "%s[%u, %llu, %llu]", i ? ", " : "", h_count[(size_t)pg], h_gprof[(size_t)pg * 16 + 2], cyc(pg) / 1000000ull);
             }
             std::fprintf(stderr, "]}}\n");
         }

@@ -57,9 +57,10 @@ constexpr int kFetch = 256;             // points fetched per round (the first k
 constexpr int kRing = 1024;             // fetched points waiting for their turn (entries of 4 bytes)
 constexpr int kMaxSub = 4;              // a block is up to kMaxSub x 64 points
 constexpr int kU = kGrpWaves >= 16 ? 2 : kGrpWaves >= 8 ? 3 : 5;   // angles of a wavefront voted together
-constexpr int kWalkChunks = kGrpThreads / 128;   // chunks of 64 steps per direction and round of the first walk
-constexpr int kKeep = 4 * kWalkChunks;  // chunks per direction whose points the first walk leaves for the second
-constexpr int kEraseWave0 = kFetch / 64;         // the wavefronts that fetch mask bits do not erase (their loads are not held up by the erasures' completion)
+constexpr int kWalkLoads = 4;           // chunks of 64 steps a wavefront reads per round trip of the first walk
+constexpr int kPostWave = 2;             // posts the next line's exchange while wavefronts 0 and 1 walk the current line
+constexpr int kKeep = 32;               // chunks per direction whose points the first walk leaves for the second
+constexpr int kEraseWave0 = kGrpWaves > 4 ? kFetch / 64 : 1;   // the wavefronts that erase (wavefront 0 polls the mailboxes; with many wavefronts those that fetch mask bits are spared too)
 constexpr int kEraseWaves = kGrpWaves - kEraseWave0;
 constexpr int kMaxA = 180;              // angles per member (a small page is one member's)
 constexpr int kMaxG = 32;               // members per group
@@ -89,6 +90,7 @@ struct GrpArgs {
     const int* tab_n;                   // [G] angles of member g
     const int* tab_dwords;              // [G] accumulator dwords of member g
     const float* ttab;                  // kNumAngle x {cos, sin}
+    const int4* ltab;                   // kNumAngle x {xflag, dx0, dy0, 0}: the walk of a line of that angle
     int* lines; const unsigned long long* lines_off; const unsigned* lines_cap; unsigned* n_lines;
     unsigned long long* mbox;           // [n_groups][kMboxSlots][kMaxG] granules, zeroed
     unsigned* abort_word;               // [n_groups], 64 bytes apart, zeroed
@@ -195,8 +197,8 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
     extern __shared__ unsigned acc[];                   // this member's cells, two to a dword
     __shared__ unsigned ring[kRing];                    // x | y << 16 | live << 31
     __shared__ unsigned s_key[2][kMaxSub * 64];         // per point of the block: count * 256 + 255 - angle where a cell reached the threshold
-    __shared__ unsigned s_any[2], s_x[2];
-    __shared__ unsigned long long s_B[2][kKeep + kWalkChunks], s_V[2][kWalkChunks], s_set2[kGrpWaves];
+    __shared__ unsigned s_any[2], s_x[2], s_post[2], s_hit, s_end[2];
+    __shared__ unsigned long long s_B[2][2][kKeep], s_set2[kGrpWaves];   // s_B[line parity][direction][chunk]
     __shared__ GrpAngle s_ang[kMaxA];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -229,47 +231,78 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
     unsigned seq = 0;
     int kill_left = (group == a.kill_group && member == 1) ? a.kill_after : -1;
 
-    // One exchange: every member publishes `payload` (wavefront 0 / lane 0's value), everybody gets the maximum over the group.
-    // kAborted: the group gave up.  Ends with a workgroup barrier.
-    auto exchange = [&](unsigned payload) -> unsigned {
+    // One exchange: every member publishes a payload (post: wavefront 0 / lane 0's value), everybody gets the maximum over the group
+    // (collect; kAborted: the group gave up; ends with a workgroup barrier).  A posted exchange may be abandoned - nobody collects
+    // it - as long as every member decides so: the transform posts the NEXT line of a block before it walks the current one.
+    unsigned long long dbg_polls = 0, dbg_prehit = 0, dbg_pollcyc = 0, dbg_barcyc = 0;
+    unsigned long long pre_v = 0;   // wavefront 0: the group's granules as read ahead of collect() (prefetch_poll)
+    unsigned pre_seq = 0, pre_ab = 0;
+    auto post = [&](unsigned payload, int pw) {   // wavefront pw publishes (its lane 0's value)
         ++seq;
+        if (wv == pw) {
+            if (lane == 0) {
+                s_post[seq & 1] = payload;
+                if (G > 1)
+                    __hip_atomic_store(mbox + ((size_t)(seq & (kMboxSlots - 1)) * kMaxG + member) * kGranStride,
+                                       ((unsigned long long)seq << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    auto prefetch_poll = [&]() {   // (wavefront 0) reads the granules of the exchange posted last without waiting for them
+        if (wv == 0 && G > 1) {
+            const unsigned long long* box = mbox + (size_t)(seq & (kMboxSlots - 1)) * kMaxG * kGranStride;
+            pre_v = (unsigned long long)seq << 32;
+            if (lane < G) pre_v = __hip_atomic_load(box + lane * kGranStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pre_ab = 0;
+            if (lane == 63) pre_ab = load_sc1(abort_word);
+            pre_seq = seq;
+        }
+    };
+    auto collect = [&](bool post_was_mine) -> unsigned {   // post_was_mine: wavefront 0 posted, with no barrier since (its value is `posted0`)
+        const unsigned long long tc0 = a.prof ? __builtin_readcyclecounter() : 0;
         if (wv == 0) {
-            unsigned res = payload;
-            if (G > 1) {
-                if (kill_left == 0) {   // (tests) this member falls silent; it leaves when the others raise the abort word
-                    res = kAborted;
-                    while (load_sc1(abort_word) == 0) __builtin_amdgcn_s_sleep(32);
-                } else {
-                    if (kill_left > 0) --kill_left;
-                    unsigned long long* box = mbox + (size_t)(seq & (kMboxSlots - 1)) * kMaxG * kGranStride;
-                    if (lane == 0)
-                        __hip_atomic_store(box + member * kGranStride, ((unsigned long long)seq << 32) | payload, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                    unsigned long long t0 = 0;
-                    unsigned spins = 0;
-                    for (;;) {
-                        unsigned long long v = (unsigned long long)seq << 32;
+            unsigned res = 0;
+            if (kill_left == 0) res = kAborted;   // (tests) this member leaves without a word: the others run out of patience, raise the abort word and leave too
+            else if (G == 1) res = s_post[seq & 1];
+            else {
+                if (kill_left > 0) --kill_left;
+                const unsigned long long* box = mbox + (size_t)(seq & (kMboxSlots - 1)) * kMaxG * kGranStride;
+                unsigned long long t0 = 0;
+                unsigned spins = 0;
+                bool have = pre_seq == seq;
+                const bool had = have;
+                for (;;) {
+                    ++dbg_polls;
+                    unsigned long long v = (unsigned long long)seq << 32;
+                    unsigned ab = 0;
+                    if (have) { v = pre_v; ab = pre_ab; have = false; }
+                    else {
                         if (lane < G) v = __hip_atomic_load(box + lane * kGranStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        unsigned ab = 0;
                         if (lane == 63) ab = load_sc1(abort_word);
-                        if (__ballot(ab != 0)) { res = kAborted; break; }
-                        if (!__ballot((unsigned)(v >> 32) != seq)) { res = wave_max_u32((unsigned)v); break; }
-                        if ((++spins & 63u) == 0) {
-                            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-                            if (t0 == 0) t0 = now;
-                            else if (now - t0 > a.spin_budget) {
-                                if (lane == 0) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                res = kAborted;
-                                break;
-                            }
+                    }
+                    if (__ballot(ab != 0)) { res = kAborted; break; }
+                    if (!__ballot((unsigned)(v >> 32) != seq)) { res = wave_max_u32((unsigned)v); if (had && spins == 0) ++dbg_prehit; break; }
+                    if ((++spins & 63u) == 0) {
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                        if (t0 == 0) t0 = now;
+                        else if (now - t0 > a.spin_budget) {
+                            if (lane == 0) __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            res = kAborted;
+                            break;
                         }
                     }
                 }
             }
             if (lane == 0) s_x[seq & 1] = res;
         }
+        const unsigned long long tc1 = a.prof ? __builtin_readcyclecounter() : 0;
         __syncthreads();
+        if (a.prof) { dbg_pollcyc += tc1 - tc0; dbg_barcyc += __builtin_readcyclecounter() - tc1; }
         return s_x[seq & 1];
+    };
+    auto exchange = [&](unsigned payload) -> unsigned {
+        post(payload, 0);
+        return collect(true);
     };
 
     for (;;) {
@@ -281,6 +314,8 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
         const int page = a.page_list[got - 1u];
         const unsigned N = a.count[page];
         const unsigned* order = a.order + a.nz_off[page];
+        const unsigned lines_cap = a.lines_cap[page];
+        const unsigned long long lines_off = a.lines_off[page];
 
         // ---- per page: empty cells, a private copy of the point mask ----
         for (int i = tid; i < acc_dwords; i += kGrpThreads) acc[i] = kCellBias | (kCellBias << 16);
@@ -296,7 +331,8 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
 
         unsigned cursor = 0, head = 0, head_vis = 0, next_order = 0, n_lines = 0, blk = 0;
         int S = kMaxSub;
-        bool pend = false, o_valid = false, pend_stale = false, stale_line = false, erasing = false, prev_trig = false;
+        bool pend = false, o_valid = false, pend_stale = false, stale_line = false, prev_trig = false, late_erase = false;
+        int wb = 0;   // which half of s_B the line being walked uses
         unsigned pg_pt = 0, pg_word = 0, o_reg = 0;
         // the line walked last (whose erasures may still be on their way when the next mask bits are fetched)
         int l_xflag = 0, l_dx0 = 0, l_dy0 = 0, l_j = 0, l_i = 0, l_e0 = 0, l_e1 = 0;
@@ -310,6 +346,25 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
             const int s = (py - l_i) * l_dy0;
             return s >= -l_e1 && s <= l_e0 && ((int)(l_x0 + (unsigned)s * (unsigned)l_dx0) >> 16) == px;
         };
+        // The erasure of a line too short to count is put off until the next line is being walked (or the block ends): the
+        // wavefronts that erase have nothing else to do then.  It erases the LAST line (l_*), whose points the first walk left in
+        // s_B[buf]; only lines within kKeep chunks per direction are put off.
+        auto erase_last_line = [&](int buf) {
+            if (wv < kEraseWave0) return;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int dx = d ? -l_dx0 : l_dx0, dy = d ? -l_dy0 : l_dy0;
+                const unsigned end = (unsigned)(d ? l_e1 : l_e0);
+                for (unsigned myc = (unsigned)(wv - kEraseWave0); myc <= (end >> 6); myc += kEraseWaves) {
+                    const unsigned st = myc * 64u + (unsigned)lane;
+                    if (st <= end && !(d == 1 && st == 0) && ((uni64(s_B[buf][d][myc]) >> lane) & 1ull)) {
+                        int j1, i1;
+                        step_pixel(l_xflag, l_x0, l_y0, dx, dy, st, &j1, &i1);
+                        atomicAnd(pm + (size_t)i1 * rowwords + (j1 >> 5), ~(1u << (j1 & 31)));
+                    }
+                }
+            }
+        };
         auto flush_pend = [&]() {   // the fetched chunk joins the ring (visible to the others after the next barrier)
             if (tid < kFetch && head + tid < N) {
                 unsigned ent = pg_pt | (((pg_word >> (pg_pt & 31u)) & 1u) << 31);
@@ -322,7 +377,7 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
         unsigned n_xchg = 0, n_blocks = 0, n_trig = 0, n_rounds = 0;
         bool aborted = false;
         // (diagnostics: shader-clock cycles per phase, only when the caller asked for them)
-        unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, ph_t = a.prof ? __builtin_readcyclecounter() : 0;
+        unsigned long long ph[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = a.prof ? __builtin_readcyclecounter() : 0;
         auto mark = [&](int k) {
             if (a.prof) {
                 const unsigned long long now = __builtin_readcyclecounter();
@@ -359,8 +414,6 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
             if (tid == 0) s_any[kb ^ 1] = 0;
             const unsigned win = min((unsigned)S * 64u, head_vis - cursor);
             if (win == 0) {   // (nothing fetched yet: start of the page, or a line ended on the last fetched point)
-                if (erasing && wv >= kEraseWave0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                erasing = false;
                 __syncthreads();
                 head_vis = head;
                 mark(0);
@@ -373,7 +426,7 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
 
             // ---- votes of the block: lane = point; a wavefront owns its angles' cells, so that the votes of successive sub-blocks
             // reach a cell in visiting order; all of a wavefront's votes of a block (up to kMaxSub x kU) are in flight together ----
-            unsigned trig_e = 0;
+            unsigned trig_e = 0, trig_w = 0;
             unsigned ent[kMaxSub];
             bool live[kMaxSub];
 #pragma unroll
@@ -398,13 +451,16 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
                     unsigned old[kMaxSub][kU];
 #pragma unroll
                     for (int sub = 0; sub < kMaxSub; ++sub) {
+#pragma unroll
+                        for (int u = 0; u < kU; ++u) { ci[sub][u] = 0; old[sub][u] = 0; }
+                        if (sub >= nsub || (undo && (unsigned)(sub * 64 + 63) <= trig_w)) continue;
                         const float fx = (float)(ent[sub] & 0x7fffu), fy = (float)((ent[sub] >> 16) & 0x7fffu);
                         const bool lv = undo ? (live[sub] && cursor + (unsigned)sub * 64u + (unsigned)lane > trig_e) : live[sub];
 #pragma unroll
                         for (int u = 0; u < kU; ++u) {
+                            if (wv + (u0 + u) * kGrpWaves >= A) continue;
                             ci[sub][u] = b[u] + cv_round_f(fx * c[u] + fy * s[u]);
-                            old[sub][u] = 0;
-                            if (lv && wv + (u0 + u) * kGrpWaves < A) {
+                            if (lv) {
                                 unsigned* cell = acc + (ci[sub][u] >> 1);
                                 const unsigned inc = (ci[sub][u] & 1) ? 0x10000u : 1u;
                                 if (undo) atomicSub(cell, inc);
@@ -415,8 +471,10 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
                     if (undo) continue;
 #pragma unroll
                     for (int sub = 0; sub < kMaxSub; ++sub) {
+                        if (sub >= nsub) continue;
 #pragma unroll
                         for (int u = 0; u < kU; ++u) {
+                            if (wv + (u0 + u) * kGrpWaves >= A) continue;
                             const int cnt = (int)((old[sub][u] >> ((ci[sub][u] & 1) * 16)) & 0xffffu) - (int)kCellBias + 1;
                             const bool mine = live[sub] && wv + (u0 + u) * kGrpWaves < A;
                             unsigned long long m = __ballot(mine && cnt >= thr);
@@ -444,135 +502,159 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
                 }
             };
             votes(false);
-            if (erasing && wv >= kEraseWave0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last line's erasures are in memory ...
-            erasing = false;
-            __syncthreads();                                                                       // ... before anybody walks again
-            unsigned payload = 0;
-            if (wv == 0 && s_any[kb]) {
-                for (int sub = 0; sub < nsub && !payload; ++sub) {
-                    const unsigned k = s_key[kb][sub * 64 + lane];
-                    const unsigned long long bb = __ballot(k != 0);
-                    if (bb) {
-                        const int p = __ffsll((long long)bb) - 1;
-                        payload = ((1023u - (unsigned)(sub * 64 + p)) << 22) | (unsigned)__builtin_amdgcn_readlane((int)k, p);
+            // Erasures are never waited for where they are issued.  The wavefronts that erase drain theirs here and before the barrier
+            // behind every line's strike; so at any time only the LAST line's erasures can be on their way, and whoever reads mask bits
+            // that could be among them (the next fetch, the next first walk) strikes that line's pixels himself.
+            if (wv >= kEraseWave0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            stale_line = false;
+            mark(1);
+            // ---- the lines of this block.  After a line that was too short to count (no votes taken back) the rest of the block
+            // stands as it was voted, unless the walk erased one of its points: the next line is the next point with a key. ----
+            unsigned resume = 0;
+            bool block_done = false;
+            auto next_key = [&](int pw) -> unsigned {   // (wavefront pw) the first point at or behind `resume` whose vote reached the threshold in one of my cells
+                unsigned payload = 0;
+                if (wv == pw && s_any[kb]) {
+                    for (int sub = (int)(resume >> 6); sub < nsub && !payload; ++sub) {
+                        const unsigned k = s_key[kb][sub * 64 + lane];
+                        const unsigned long long bb = __ballot(k != 0 && (unsigned)(sub * 64 + lane) >= resume);
+                        if (bb) {
+                            const int p = __ffsll((long long)bb) - 1;
+                            payload = ((1023u - (unsigned)(sub * 64 + p)) << 22) | (unsigned)__builtin_amdgcn_readlane((int)k, p);
+                        }
                     }
                 }
-            }
-            mark(1);
-            const unsigned res = exchange(payload);
+                return payload;
+            };
+            post(next_key(0), 0);
+            for (;;) {
+            const unsigned res = collect(true);
             mark(2);
             ++n_xchg;
-            head_vis = head;
             if (res == kAborted) { aborted = true; break; }
             if (res == 0) {   // every vote of the block stands
+                if (late_erase) { erase_last_line(wb); late_erase = false; }
                 cursor += win;
                 S = min(2 * S, kMaxSub);
                 prev_trig = false;
-                continue;
+                block_done = true;
+                break;
             }
 
             // ---- a line: the earliest point whose vote reached the threshold, the first angle with the largest count ----
             ++n_trig;
-            const unsigned trig_w = 1023u - (res >> 22);
+            trig_w = 1023u - (res >> 22);
             const int max_n = 255 - (int)(res & 255u);
             trig_e = cursor + trig_w;
-            votes(true);   // the younger points voted on speculation
+            if (tid == 0) s_hit = 0;   // (set after the walks, behind their barriers)
+            // on the assumption that this line is too short to count and erases no point of the block, the next line of the block
+            // is known already: its exchange travels while this line is walked (abandoned if the assumption fails)
+            resume = trig_w + 1u;
+            post(next_key(kPostWave), kPostWave);
+            if (late_erase) {   // (the line before this one; the walk below strikes its pixels from what it reads: stale_line)
+                erase_last_line(wb);
+                late_erase = false;
+            }
+            wb ^= 1;
             if (pend) {   // the chunk in flight read its mask bits before this line is erased: into the ring with it, corrected below
                 flush_pend();
-                head_vis = head;
+                __syncthreads();
             }
-            __syncthreads();
             mark(3);
             const unsigned tq = uni(ring[trig_e & (kRing - 1)]);
             const int j = (int)(tq & 0x7fffu), i = (int)((tq >> 16) & 0x7fffu);
-            const float fa = -a.ttab[2 * max_n + 1], fb = a.ttab[2 * max_n];
+            const int4 lt = a.ltab[max_n];
+            const int xflag = lt.x, dx0 = lt.y, dy0 = lt.z;
             unsigned x0 = (unsigned)j, y0 = (unsigned)i;
-            int dx0, dy0, xflag;
-            if (fabs((double)fa) > fabs((double)fb)) {
-                xflag = 1;
-                dx0 = fa > 0 ? 1 : -1;
-                dy0 = __double2int_rn((double)(fb * 65536.f) / fabs((double)fa));
-                y0 = (y0 << 16) + (1u << 15);
-            } else {
-                xflag = 0;
-                dy0 = fb > 0 ? 1 : -1;
-                dx0 = __double2int_rn((double)(fa * 65536.f) / fabs((double)fb));
-                x0 = (x0 << 16) + (1u << 15);
-            }
-            // first walk (read only), both directions at once, kWalkChunks x 64 steps of each per round trip: the step at which the
-            // walk leaves the page or has seen more than line_gap steps in a row without a point, and the last point before it.
-            // Every step finds the length of the pointless run it ends from the ballots of its direction (no scan over the points:
-            // text lines are dense).
+            if (xflag) y0 = (y0 << 16) + (1u << 15);
+            else x0 = (x0 << 16) + (1u << 15);
+            // first walk (read only): wavefront d walks direction d, kWalkLoads x 64 steps per round trip, and finds on its own (ballots,
+            // no shared memory) the step at which the walk leaves the page or has seen more than line_gap steps in a row without a
+            // point, and the last point before it.  Which steps held a point is left in s_B for the second walk.
             unsigned end_step[2] = {0, 0};
-            int gap[2] = {0, 0};
-            bool stop[2] = {false, false};
-            {
-                const int dir = tid / (kGrpThreads / 2), jj = tid % (kGrpThreads / 2), c = jj >> 6;
+            if (wv < 2) {
+                const int dir = wv;
                 const int dx = dir ? -dx0 : dx0, dy = dir ? -dy0 : dy0;
-                for (unsigned base = 0, r = 0; !(stop[0] && stop[1]) && base < (1u << 17); base += kWalkChunks * 64, ++r) {
+                unsigned end = 0;
+                int gap = 0;
+                bool stop = false;
+                for (unsigned base = 0, r = 0; !stop && base < (1u << 17); base += kWalkLoads * 64, ++r) {
                     ++n_rounds;
-                    const bool cached = (r + 1) * kWalkChunks <= (unsigned)kKeep;
-                    const int slot0 = cached ? (int)(r * kWalkChunks) : kKeep;   // where this round's ballots of a direction go
-                    int j1, i1;
-                    step_pixel(xflag, x0, y0, dx, dy, base + (unsigned)jj, &j1, &i1);
-                    const bool inb = j1 >= 0 && j1 < W && i1 >= 0 && i1 < H;
-                    unsigned w1 = 0;
-                    if (inb && !stop[dir]) w1 = load_sc1(pm + (size_t)i1 * rowwords + (j1 >> 5));
-                    const bool set = inb && ((w1 >> (j1 & 31)) & 1u);
-                    const unsigned long long bs = __ballot(set);
-                    if (lane == 0) s_B[dir][slot0 + c] = bs;
-                    __syncthreads();
-                    if (!stop[dir]) {
-                        // pointless steps right before mine: in my chunk, then the chunks before it, then the rounds before
-                        int run;
-                        const unsigned long long below = bs & ((1ull << lane) - 1ull);
-                        if (below) run = lane - 1 - (63 - __clzll((long long)below));
-                        else {
-                            run = lane;
-                            int cc = c - 1;
-                            for (; cc >= 0; --cc) {
-                                const unsigned long long bw = uni64(s_B[dir][slot0 + cc]);
-                                if (bw) { run += __clzll((long long)bw); break; }
-                                run += 64;
-                            }
-                            if (cc < 0) run += gap[dir];
-                        }
-                        const bool viol = !inb || (!set && run + 1 > a.line_gap);
-                        const unsigned long long bv = __ballot(viol);
-                        if (lane == 0) s_V[dir][c] = bv;
-                    }
-                    __syncthreads();
+                    bool inb[kWalkLoads];
+                    unsigned w1[kWalkLoads], pix[kWalkLoads];
+                    int bitpos[kWalkLoads];
 #pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        if (stop[d]) continue;
-                        int first = -1;
-                        for (int cc = 0; cc < kWalkChunks; ++cc) {
-                            const unsigned long long v = uni64(s_V[d][cc]);
-                            if (v) { first = cc * 64 + __ffsll((long long)v) - 1; break; }
-                        }
-                        const int lim = first >= 0 ? first : kWalkChunks * 64;
-                        int last = -1;
-                        for (int cc = min(kWalkChunks - 1, (lim - 1) >> 6); cc >= 0; --cc) {
-                            unsigned long long bw = uni64(s_B[d][slot0 + cc]);
-                            if (lim < cc * 64 + 64) bw &= (1ull << (lim - cc * 64)) - 1ull;
-                            if (bw) { last = cc * 64 + 63 - __clzll((long long)bw); break; }
-                        }
-                        if (last >= 0) end_step[d] = base + (unsigned)last;
-                        if (first >= 0) stop[d] = true;
-                        else gap[d] = last >= 0 ? kWalkChunks * 64 - 1 - last : gap[d] + kWalkChunks * 64;
+                    for (int h = 0; h < kWalkLoads; ++h) {
+                        int j1, i1;
+                        step_pixel(xflag, x0, y0, dx, dy, base + (unsigned)(h * 64 + lane), &j1, &i1);
+                        inb[h] = j1 >= 0 && j1 < W && i1 >= 0 && i1 < H;
+                        bitpos[h] = j1 & 31;
+                        pix[h] = (unsigned)j1 | ((unsigned)i1 << 16);
+                        w1[h] = 0;
+                        if (inb[h]) w1[h] = load_sc1(pm + (size_t)i1 * rowwords + (j1 >> 5));
                     }
-                    if (!cached) __syncthreads();   // the next round reuses this round's ballot slots
+#pragma unroll
+                    for (int h = 0; h < kWalkLoads; ++h) {
+                        if (stop) continue;
+                        bool set = inb[h] && ((w1[h] >> bitpos[h]) & 1u);
+                        if (stale_line && set) set = !on_last_line(pix[h]);   // (that line's erasures may not have landed yet)
+                        const unsigned long long bs = __ballot(set);
+                        const unsigned chunk = r * kWalkLoads + (unsigned)h;
+                        if (lane == 0 && chunk < (unsigned)kKeep) s_B[wb][dir][chunk] = bs;
+                        // pointless steps right before mine
+                        const unsigned long long below = bs & ((1ull << lane) - 1ull);
+                        const int run = below ? lane - 1 - (63 - __clzll((long long)below)) : lane + gap;
+                        const unsigned long long bv = __ballot(!inb[h] || (!set && run + 1 > a.line_gap));
+                        unsigned long long upto = bs;   // the points before the walk's end
+                        if (bv) {
+                            stop = true;
+                            upto &= (1ull << (__ffsll((long long)bv) - 1)) - 1ull;
+                        }
+                        if (upto) end = base + (unsigned)(h * 64 + 63 - __clzll((long long)upto));
+                        gap = bs ? __clzll((long long)bs) : gap + 64;
+                    }
                 }
+                if (lane == 0) s_end[dir] = end;
             }
+            __syncthreads();
+            end_step[0] = uni(s_end[0]);
+            end_step[1] = uni(s_end[1]);
             mark(4);
+            prefetch_poll();
             int ex[2], ey[2];
             step_pixel(xflag, x0, y0, dx0, dy0, end_step[0], &ex[0], &ey[0]);
             step_pixel(xflag, x0, y0, -dx0, -dy0, end_step[1], &ex[1], &ey[1]);
             const bool good_line = abs(ex[1] - ex[0]) >= a.line_length || abs(ey[1] - ey[0]) >= a.line_length;
+            // the fetched points that lay on the erased stretch are gone
+            l_xflag = xflag; l_dx0 = dx0; l_dy0 = dy0; l_j = j; l_i = i; l_e0 = (int)end_step[0]; l_e1 = (int)end_step[1];
+            l_x0 = x0; l_y0 = y0;
+            bool hit_block = false;   // a point of this block behind the line's was erased: its vote (and what followed it) does not stand
+            for (unsigned e = trig_e + 1u + (unsigned)tid; e < head; e += kGrpThreads) {
+                const unsigned en = ring[e & (kRing - 1)];
+                if ((en >> 31) && on_last_line(en)) {
+                    ring[e & (kRing - 1)] = en & 0x7fffffffu;
+                    hit_block = hit_block || e < cursor + win;
+                }
+            }
+            if (__ballot(hit_block) && lane == 0) s_hit = 1;
+            if (good_line) {
+                if (member == 0 && tid == 0 && n_lines < lines_cap) {
+                    int* ln = a.lines + (lines_off + n_lines) * 4;
+                    ln[0] = ex[0]; ln[1] = ey[0]; ln[2] = ex[1]; ln[3] = ey[1];
+                }
+                ++n_lines;
+            }
+            if (wv >= kEraseWave0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the line before this one: long landed)
+            __syncthreads();     // the ring as corrected; the flag
+            stale_line = true;   // from here on this line's erasures are on their way
+            const bool restart = good_line || s_hit != 0;
+            mark(6);
             // second walk: erase the pixels up to the line's ends (this member's copy; wavefronts kEraseWave0 and up, one step per
             // lane); a good line takes their votes back (every wavefront its angles).  Which steps held a point is known from the
             // first walk's ballots (kKeep chunks per direction); beyond them the mask is read again.
-            for (int d = 0; d < 2; ++d) {
+            late_erase = !restart && (end_step[0] >> 6) < (unsigned)kKeep && (end_step[1] >> 6) < (unsigned)kKeep;
+            for (int d = 0; d < 2 && !late_erase; ++d) {
                 const int dx = d ? -dx0 : dx0, dy = d ? -dy0 : dy0;
                 const unsigned last_chunk = end_step[d] >> 6;
                 for (unsigned ch0 = 0; ch0 <= last_chunk; ch0 += kEraseWaves) {
@@ -586,7 +668,7 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
                         int j1, i1;
                         step_pixel(xflag, x0, y0, dx, dy, st, &j1, &i1);
                         unsigned* wp = pm + (size_t)i1 * rowwords + (j1 >> 5);
-                        if (cached) set = in_range && ((uni64(s_B[d][min(myc, (unsigned)kKeep - 1)]) >> lane) & 1ull);
+                        if (cached) set = in_range && ((uni64(s_B[wb][d][min(myc, (unsigned)kKeep - 1)]) >> lane) & 1ull);
                         else if (in_range) set = (load_sc1(wp) >> (j1 & 31)) & 1u;
                         if (set) atomicAnd(wp, ~(1u << (j1 & 31)));
                         if (!cached) {
@@ -599,7 +681,7 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
                         for (unsigned cc = 0; cc < nch; ++cc) {
                             unsigned long long bits;
                             if (cached) {
-                                bits = uni64(s_B[d][ch0 + cc]);
+                                bits = uni64(s_B[wb][d][ch0 + cc]);
                                 const long long room = (long long)end_step[d] - (long long)((ch0 + cc) * 64u);   // steps of this chunk up to the end
                                 if (room < 63) bits &= (2ull << room) - 1ull;
                                 if (d == 1 && ch0 + cc == 0) bits &= ~1ull;
@@ -631,36 +713,35 @@ __global__ void __launch_bounds__(kGrpThreads) k_ppht_group(GrpArgs a)
                 }
             }
             mark(5);
-            // the fetched points that lay on the erased stretch are gone
-            l_xflag = xflag; l_dx0 = dx0; l_dy0 = dy0; l_j = j; l_i = i; l_e0 = (int)end_step[0]; l_e1 = (int)end_step[1];
-            l_x0 = x0; l_y0 = y0;
-            for (unsigned e = trig_e + 1u + (unsigned)tid; e < head; e += kGrpThreads) {
-                const unsigned en = ring[e & (kRing - 1)];
-                if ((en >> 31) && on_last_line(en)) ring[e & (kRing - 1)] = en & 0x7fffffffu;
+            if (restart) {   // the votes of the younger points no longer stand as they were cast: take them back, vote again behind the line
+                votes(true);
+                cursor = trig_e + 1u;
+                S = prev_trig ? 1 : kMaxSub;   // lines in quick succession: short blocks (fewer votes to take back)
+                prev_trig = true;
+                __syncthreads();
+                break;
             }
-            if (good_line) {
-                if (member == 0 && tid == 0 && n_lines < a.lines_cap[page]) {
-                    int* ln = a.lines + (a.lines_off[page] + n_lines) * 4;
-                    ln[0] = ex[0]; ln[1] = ey[0]; ln[2] = ex[1]; ln[3] = ey[1];
-                }
-                ++n_lines;
+            if (resume >= win) {   // (the exchange posted for the rest of the block is abandoned: there is no rest)
+                if (late_erase) { erase_last_line(wb); late_erase = false; }
+                cursor += win;
+                prev_trig = true;
+                block_done = true;
+                break;
             }
-            stale_line = true;   // the next fetch of mask bits may overtake the erasures: it is corrected with this line
-            erasing = true;      // the wavefronts that erased wait for their atomics before the next block's first barrier
-            cursor = trig_e + 1u;
-            S = prev_trig ? 1 : kMaxSub;   // lines in quick succession: short blocks (fewer votes to take back)
-            prev_trig = true;
-            __syncthreads();   // the ring as corrected, before the next block's votes read it
-            mark(6);
+            }   // lines of this block
+            head_vis = head;
+            if (aborted) break;
+            (void)block_done;
         }
         if (aborted) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (member == 0 && tid == 0) {
             a.n_lines[page] = n_lines;
             if (a.prof) {
-                unsigned long long* pr = a.prof + (size_t)page * 12;
+                unsigned long long* pr = a.prof + (size_t)page * 16;
                 pr[0] = n_xchg; pr[1] = n_blocks; pr[2] = n_trig; pr[3] = n_lines; pr[4] = n_rounds;
                 for (int k = 0; k < 7; ++k) pr[5 + k] = ph[k];
+                pr[12] = dbg_polls; pr[13] = dbg_prehit; pr[14] = dbg_pollcyc; pr[15] = dbg_barcyc;
             }
             __hip_atomic_store(a.status + page, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -780,10 +861,10 @@ int ppht_group_run(DeviceCtx* ctx, PphtGroupIn& in, hipStream_t stream)
     // workspace: bit masks (shared + private), linked lists, order, random numbers, tables, mailboxes
     const size_t b_mask0 = r256(mask_words * 4 * (size_t)n_pages), b_pmask = r256(mask_words * 4 * (size_t)grid);
     const size_t b_list = r256(nz_total * 4 + 256);
-    const size_t b_tab = r256(gp.tab.size() * sizeof(GrpAngle)), b_tabn = r256((size_t)G * 4);
+    const size_t b_tab = r256(gp.tab.size() * sizeof(GrpAngle)), b_tabn = r256((size_t)G * 4), b_ltab = r256(kNumAngle * sizeof(int4));
     const size_t b_mbox = r256((size_t)n_groups * kMboxSlots * kMaxG * kGranStride * 8), b_abort = r256((size_t)n_groups * 64 + 64);
-    const size_t b_pl = r256((size_t)n_list * 4), b_status = r256((size_t)n_pages * 4), b_prof = r256((size_t)n_pages * 96);
-    const size_t total = b_mask0 + b_pmask + 3 * b_list + b_tab + 2 * b_tabn + b_mbox + b_abort + b_pl + b_status + b_prof;
+    const size_t b_pl = r256((size_t)n_list * 4), b_status = r256((size_t)n_pages * 4), b_prof = r256((size_t)n_pages * 128);
+    const size_t total = b_mask0 + b_pmask + 3 * b_list + b_tab + 2 * b_tabn + b_ltab + b_mbox + b_abort + b_pl + b_status + b_prof;
     int st = ensure_buffer(&ctx->ppht_buf[3], &ctx->ppht_bytes[3], total);
     if (st != PRL_OK) return st;
     // cv::RNG(-1)'s output: the same sequence for every page of every call (HoughLinesProbabilistic seeds it anew each time), kept
@@ -819,11 +900,12 @@ int ppht_group_run(DeviceCtx* ctx, PphtGroupIn& in, hipStream_t stream)
     int* d_tabn = reinterpret_cast<int*>(take(b_tabn));
     int* d_tabdw = reinterpret_cast<int*>(take(b_tabn));
     int* d_pl = reinterpret_cast<int*>(take(b_pl));
+    int4* d_ltab = reinterpret_cast<int4*>(take(b_ltab));
     unsigned* d_mask0 = reinterpret_cast<unsigned*>(take(b_mask0));
     unsigned* d_pmask = reinterpret_cast<unsigned*>(take(b_pmask));
 
     // the small host tables, in a block the caller keeps until it has synchronised the stream
-    in.keep.resize(gp.tab.size() * sizeof(GrpAngle) + (size_t)G * 8 + (size_t)n_list * 4);
+    in.keep.resize(gp.tab.size() * sizeof(GrpAngle) + (size_t)G * 8 + (size_t)n_list * 4 + kNumAngle * sizeof(int4));
     unsigned char* k_tab = in.keep.data();
     unsigned char* k_tabn = k_tab + gp.tab.size() * sizeof(GrpAngle);
     unsigned char* k_tabdw = k_tabn + (size_t)G * 4;
@@ -832,6 +914,23 @@ int ppht_group_run(DeviceCtx* ctx, PphtGroupIn& in, hipStream_t stream)
     std::memcpy(k_tabn, gp.tab_n.data(), (size_t)G * 4);
     std::memcpy(k_tabdw, gp.tab_dwords.data(), (size_t)G * 4);
     std::memcpy(k_pl, in.page_list.data(), (size_t)n_list * 4);
+    // how a line of angle n is walked (HoughLinesProbabilistic: a = -sin, b = cos; the longer component steps by one pixel, the other in
+    // 16.16 fixed point)
+    int4* k_ltab = reinterpret_cast<int4*>(k_pl + (size_t)n_list * 4);
+    for (int n = 0; n < kNumAngle; ++n) {
+        const float fa = -in.h_ttab[2 * n + 1], fb = in.h_ttab[2 * n];
+        int4 lt{0, 0, 0, 0};
+        if (std::fabs((double)fa) > std::fabs((double)fb)) {
+            lt.x = 1;
+            lt.y = fa > 0 ? 1 : -1;
+            lt.z = (int)std::lrint((double)(fb * 65536.f) / std::fabs((double)fa));
+        } else {
+            lt.y = (int)std::lrint((double)(fa * 65536.f) / std::fabs((double)fb));
+            lt.z = fb > 0 ? 1 : -1;
+        }
+        std::memcpy(k_ltab + n, &lt, sizeof(lt));
+    }
+    PRL_HIP_CHECK(hipMemcpyAsync(d_ltab, k_ltab, kNumAngle * sizeof(int4), hipMemcpyHostToDevice, stream));
     PRL_HIP_CHECK(hipMemcpyAsync(d_tab, k_tab, gp.tab.size() * sizeof(GrpAngle), hipMemcpyHostToDevice, stream));
     PRL_HIP_CHECK(hipMemcpyAsync(d_tabn, k_tabn, (size_t)G * 4, hipMemcpyHostToDevice, stream));
     PRL_HIP_CHECK(hipMemcpyAsync(d_tabdw, k_tabdw, (size_t)G * 4, hipMemcpyHostToDevice, stream));
@@ -853,7 +952,7 @@ int ppht_group_run(DeviceCtx* ctx, PphtGroupIn& in, hipStream_t stream)
     a.G = G; a.n_groups = n_groups; a.xcd_aligned = xcd ? 1 : 0; a.n_list = n_list;
     a.rowwords = rowwords; a.mask_words = mask_words; a.mask0 = d_mask0; a.pmask = d_pmask;
     a.order = d_order; a.nz_off = in.d_nzoff; a.count = in.d_count;
-    a.tab = d_tab; a.tab_n = d_tabn; a.tab_dwords = d_tabdw; a.ttab = in.d_ttab;
+    a.tab = d_tab; a.tab_n = d_tabn; a.tab_dwords = d_tabdw; a.ttab = in.d_ttab; a.ltab = d_ltab;
     a.lines = in.d_lines; a.lines_off = in.d_lnoff; a.lines_cap = in.d_cap; a.n_lines = in.d_nlines;
     a.mbox = d_mbox; a.abort_word = d_abort; a.queue = d_queue; a.page_list = d_pl; a.status = d_status;
     a.spin_budget = (unsigned long long)std::max(1, knobs.ppht_group_spin_ms) * 100000ull;
@@ -870,7 +969,7 @@ int ppht_group_run(DeviceCtx* ctx, PphtGroupIn& in, hipStream_t stream)
     }
     if (in.ev[1]) PRL_HIP_CHECK(hipEventRecord(in.ev[1], stream));
     if (in.status_out) PRL_HIP_CHECK(hipMemcpyAsync(in.status_out, d_status, (size_t)n_pages * 4, hipMemcpyDeviceToHost, stream));
-    if (in.prof_out) PRL_HIP_CHECK(hipMemcpyAsync(in.prof_out, d_prof, (size_t)n_pages * 96, hipMemcpyDeviceToHost, stream));
+    if (in.prof_out) PRL_HIP_CHECK(hipMemcpyAsync(in.prof_out, d_prof, (size_t)n_pages * 128, hipMemcpyDeviceToHost, stream));
     in.geometry_out[0] = G; in.geometry_out[1] = n_groups; in.geometry_out[2] = grid; in.geometry_out[3] = (int)gp.lds_bytes;
     return PRL_OK;
 }

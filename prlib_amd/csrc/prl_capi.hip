@@ -98,8 +98,8 @@ const EnvKnobs& env_knobs()
         k.ppht_prio = (int)geti("PRL_HIP_PPHT_PRIO", 3);
         k.ppht_group = (int)geti("PRL_HIP_PPHT_GROUP", -1);
         k.ppht_group_g = (int)std::max(1ll, std::min(32ll, geti("PRL_HIP_PPHT_GROUP_G", 1)));
-        k.ppht_group_xcd = is0("PRL_HIP_PPHT_GROUP_XCD") ? 0 : 1;
-        k.ppht_group_spin_ms = (int)std::max(1ll, geti("PRL_HIP_PPHT_GROUP_SPIN_MS", 2000));
+        k.ppht_group_xcd = (int)geti("PRL_HIP_PPHT_GROUP_XCD", 0) ? 1 : 0;
+        k.ppht_group_spin_ms = (int)std::max(1ll, geti("PRL_HIP_PPHT_GROUP_SPIN_MS", 10000));
         k.ppht_group_kill = (int)geti("PRL_HIP_PPHT_GROUP_KILL", -1);
         k.ppht_group_cus = (int)std::max(0ll, geti("PRL_HIP_PPHT_GROUP_CUS", 0));
         k.chain_host_pages = (int)std::max(0ll, geti("PRL_HIP_CHAIN_HOST_PAGES", 0));

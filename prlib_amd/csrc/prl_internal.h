@@ -119,8 +119,8 @@ struct EnvKnobs {
     int ppht_prio = 3;                  // PRL_HIP_PPHT_PRIO=0   k_ppht does not raise its wavefront priority
     int ppht_group = -1;                // PRL_HIP_PPHT_GROUP    1 / 0: always (where a page qualifies) / never the on-chip group kernel (ppht_group.hip)
     int ppht_group_g = 1;               // PRL_HIP_PPHT_GROUP_G  at least this many workgroups per page
-    int ppht_group_xcd = 1;             // PRL_HIP_PPHT_GROUP_XCD=0   a group's members on consecutive workgroup ids instead of one XCD
-    int ppht_group_spin_ms = 2000;      // PRL_HIP_PPHT_GROUP_SPIN_MS how long a member waits for its group before the group gives up
+    int ppht_group_xcd = 0;             // PRL_HIP_PPHT_GROUP_XCD=1   a group's members on one XCD (workgroups b, b + 8, ...) instead of consecutive ids: 24 instead of 28 groups of 9, no faster exchange
+    int ppht_group_spin_ms = 10000;     // PRL_HIP_PPHT_GROUP_SPIN_MS how long a member waits for its group before the group gives up
     int ppht_group_kill = -1;           // PRL_HIP_PPHT_GROUP_KILL=n  (tests) member 1 of group 0 falls silent after n exchanges
     int ppht_group_cus = 0;             // PRL_HIP_PPHT_GROUP_CUS     workgroups of the group kernel at most (0: one per CU)
     int chain_pass = 0, chain_first_pass = 0;   // PRL_HIP_CHAIN_PASS / PRL_HIP_CHAIN_FIRST_PASS   pages per pass of the chain with deskew (0: start at 192 with denoise, then follow the measured search / NL-means times; else 256)
@@ -314,7 +314,7 @@ struct PphtGroupIn {
     int cu_limit = 0;                    // workgroups at most (0: one per CU)
     hipEvent_t ev[2] = {nullptr, nullptr};   // optional: recorded before / after the group kernel (diagnostics)
     unsigned* status_out = nullptr;      // host, n_pages: 1 = finished by the group kernel (valid after the stream sync)
-    unsigned long long* prof_out = nullptr;   // host, 12 per page (optional)
+    unsigned long long* prof_out = nullptr;   // host, 16 per page (optional)
     int geometry_out[4] = {0, 0, 0, 0};  // members per group, groups, workgroups, LDS bytes
     std::vector<unsigned char> keep;     // host tables the asynchronous copies read
 };
