@@ -114,15 +114,7 @@ def test_deskew_matches_oracle(prl, oracle, cuda_device, c):
     assert angles[-1] == 0.0 and outs[-1].shape[:2] == (390, 300)
 
 
-def test_single_wavefront_kernel_gives_the_same_segments():
-    """k_ppht (one wavefront per page, PRL_HIP_PPHT_MW=0: read once per process, hence the child) against the oracle on the
-    cases above; the default is k_ppht_mw (three wavefronts per page)."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
+_CHILD = r'''
 import numpy as np, torch, sys
 sys.path.insert(0, %r)
 import prlib_amd
@@ -139,11 +131,49 @@ outs, angles = prlib_amd.deskew(torch.from_numpy(pages).cuda())
 for i in range(len(pages)):
     want, info = oc.deskew(pages[i])
     bad += angles[i] != info["angle"] or not np.array_equal(outs[i].cpu().numpy(), want)
+big = synth.text_page_numpy(1200, 900, 4, skew_deg=-2.5)       # large enough for a group of several workgroups
+_, binary = oc.otsu(big)
+bad += not np.array_equal(prlib_amd.houghp(torch.from_numpy(255 - binary).cuda(), 100, 112, 20), oc.houghp(255 - binary, 100, 112, 20))
 print("BAD", bad)
-''' % root
-    env = dict(os.environ, PRL_HIP_PPHT_MW="0")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and "BAD 0" in r.stdout, r.stdout + r.stderr
+'''
+
+
+def _run_child(extra_env):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PRL_HIP_DEBUG="1", **extra_env)
+    r = subprocess.run([sys.executable, "-c", _CHILD % root], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "BAD 0" in r.stdout, r.stdout + r.stderr[-3000:]
+    return r.stderr
+
+
+def test_single_wavefront_kernel_gives_the_same_segments():
+    """k_ppht (one wavefront per page: PRL_HIP_PPHT_GROUP=0 PRL_HIP_PPHT_MW=0, read once per process, hence the child) against the
+    oracle on the cases above."""
+    err = _run_child({"PRL_HIP_PPHT_GROUP": "0", "PRL_HIP_PPHT_MW": "0"})
+    assert "group kernel" not in err
+
+
+def test_three_wavefront_kernel_gives_the_same_segments():
+    """k_ppht_mw (the accumulator in device memory, three wavefronts per page: what takes the pages the group kernel leaves)."""
+    err = _run_child({"PRL_HIP_PPHT_GROUP": "0"})
+    assert "group kernel" not in err
+
+
+def test_group_kernel_is_the_default_and_takes_every_page():
+    err = _run_child({})
+    assert "group kernel" in err and all(" 0 pages left to k_ppht_mw" in ln for ln in err.splitlines() if "pages left" in ln), err[-2000:]
+
+
+def test_group_that_gives_up_is_redone_in_the_same_call():
+    """A member that falls silent (hooks build: member 1 of group 0 after 40 exchanges): the others run out of patience (20 ms here),
+    raise the group's abort word and leave; the pages not marked done go through k_ppht_mw in the same call - same segments."""
+    err = _run_child({"PRL_HIP_PPHT_GROUP_KILL": "40", "PRL_HIP_PPHT_GROUP_SPIN_MS": "20"})
+    left = [int(ln.split(";")[1].split()[0]) for ln in err.splitlines() if "pages left to k_ppht_mw" in ln]
+    assert left and max(left) >= 1, err[-2000:]
 
 
 def test_deskew_argument_errors(prl, cuda_device):
