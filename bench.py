@@ -225,9 +225,11 @@ def worst_case_legs(args, prlib_amd, _capi, L, dev, pages, out, params, method, 
     a, b, margin = adv
     b8 = np.zeros(8, np.float64)
     eps1 = None
-    if hasattr(L, "prl_hip_internal_fused_bounds"):
-        L.prl_hip_internal_fused_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-        if L.prl_hip_internal_fused_bounds(C.byref(params), W, H, b8.ctypes.data) == 0:
+    from prlib_amd import _capi as _c
+    if os.path.exists(_c.HOOKS_LIB_PATH):   # the decision margin is a host-side helper of the test-hooks build (not part of the ABI)
+        LH = C.CDLL(_c.HOOKS_LIB_PATH)
+        LH.prl_hip_internal_fused_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        if LH.prl_hip_internal_fused_bounds(C.byref(params), W, H, b8.ctypes.data) == 0:
             eps1 = float(b8[5])
     n_adv = min(pages.shape[0], 16)
     row = torch.tensor([a, b], dtype=torch.uint8, device=dev).repeat((pages.shape[2] + 1) // 2)[: pages.shape[2]]

@@ -10,12 +10,24 @@ import numpy as np
 import pytest
 
 SAUVOLA, NIBLACK, WOLFJOLION, NICK, FENG = range(5)
+_HOOKS = None
+
+
+def _hooks():
+    """libprlib_hip_testhooks.so: the product library exports only what include/prl_hip.h declares; the prl_hip_internal_* entries
+    (host-side helpers of the fused pipeline, no device needed) live in the test-hooks build."""
+    global _HOOKS
+    if _HOOKS is None:
+        from prlib_amd import _capi
+
+        _HOOKS = C.CDLL(_capi.HOOKS_LIB_PATH)
+    return _HOOKS
 
 
 def _bounds(prl, method, w, k, size=4096):
     from prlib_amd import _capi
 
-    L = _capi.lib()
+    L = _hooks()
     L.prl_hip_internal_fused_bounds.argtypes = [C.POINTER(_capi.BinarizeParams), C.c_int, C.c_int, C.POINTER(C.c_double)]
     out = (C.c_double * 8)()
     p = prl.make_params(method, w, k, 0)
@@ -103,7 +115,7 @@ def test_float32_pipeline_q_error_bound(prl, w):
     with the exact integer window sums: |Q~ - Q| <= delta, and no error at all below Qmin."""
     from prlib_amd import _capi
 
-    L = _capi.lib()
+    L = _hooks()
     L.prl_hip_internal_flt_q_error.argtypes = [C.c_int, C.POINTER(C.c_double)]
     out = (C.c_double * 3)()
     assert L.prl_hip_internal_flt_q_error(w, out) == 1
@@ -161,7 +173,7 @@ def test_float32_sweep_a_wide_window_q_error_bound(prl, w):
     with the exact integer window sums.  The S sums of the same shape must be exact."""
     from prlib_amd import _capi
 
-    L = _capi.lib()
+    L = _hooks()
     L.prl_hip_internal_flt_a_q_error.argtypes = [C.c_int, C.POINTER(C.c_double)]
     dq = C.c_double(0)
     assert L.prl_hip_internal_flt_a_q_error(w, C.byref(dq)) == 1
@@ -225,7 +237,19 @@ def test_strip_layout(prl):
     from prlib_amd import _capi
 
     SAUVOLA, NIBLACK, WOLFJOLION, NICK, FENG = range(5)
-    L = _capi.lib()
+_HOOKS = None
+
+
+def _hooks():
+    """libprlib_hip_testhooks.so: the product library exports only what include/prl_hip.h declares; the prl_hip_internal_* entries
+    (host-side helpers of the fused pipeline, no device needed) live in the test-hooks build."""
+    global _HOOKS
+    if _HOOKS is None:
+        from prlib_amd import _capi
+
+        _HOOKS = C.CDLL(_capi.HOOKS_LIB_PATH)
+    return _HOOKS
+    L = _hooks()
     L.prl_hip_internal_strip_layout.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)]
     out = (C.c_int * 2)()
 

@@ -109,3 +109,67 @@ def test_product_does_not_reference_the_oracle():
                 if re.search(r"#include\s+[\"<][^\">]*oracle|from oracle|import oracle|lprl_oracle|prl_oracle_", txt):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_library_exports_exactly_the_header():
+    """libprlib_hip.so exports the functions include/prl_hip.h declares and nothing else (the reference marks exactly its public
+    functions CV_EXPORTS: binarizeSauvola.h:43); the test-hooks build adds the four prl_hip_internal_* entries; both carry the ABI
+    version in their SONAME.  The linker maps are generated from the header (tools/gen_export_map.py)."""
+    import shutil
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_export_map as gem
+
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_export_map.py"), "--check"]).returncode == 0
+    declared = gem.header_functions()
+    assert len(declared) == len(set(declared)) >= 56
+    from prlib_amd import _capi
+
+    assert sorted(_capi.EXPORTED_SYMBOLS) == sorted(declared)
+    if not shutil.which("nm") or not shutil.which("readelf"):
+        pytest.skip("binutils not installed")
+    abi = re.search(r"#define PRL_HIP_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "prl_hip.h")).read()).group(1)
+    for path, extra, soname in ((_capi.LIB_PATH, [], "libprlib_hip.so." + abi),
+                                (_capi.HOOKS_LIB_PATH, gem.INTERNAL, "libprlib_hip_testhooks.so." + abi)):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        got = sorted(ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.split() and ln.split()[-2] in "TtWwDdBbRr")
+        got = [g for g in got if g != "PRLIB_HIP_" + abi]   # (the version node itself is an absolute symbol)
+        assert got == sorted(declared + extra), (path, sorted(set(got) ^ set(declared + extra)))
+        dyn = subprocess.run(["readelf", "-d", path], capture_output=True, text=True, check=True).stdout
+        assert f"[{soname}]" in dyn, dyn
+
+
+def test_cmake_install_tree_builds_the_dropin_sample(tmp_path):
+    """The CMake route (what a PRLib maintainer uses: the reference builds with CMake, CMakeLists.txt:23-33 there): configure, build,
+    install into a scratch prefix; the installed library exports the header's functions only and carries its SONAME; a caller that
+    keeps the reference's #include lines (tests/cpp/test_dropin_sample.cpp) builds against the INSTALLED tree alone."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("cmake") or not os.path.exists("/opt/rocm/bin/hipcc") or not shutil.which("g++"):
+        pytest.skip("cmake / hipcc / g++ not installed")
+    b, prefix = str(tmp_path / "b"), str(tmp_path / "prefix")
+    for cmd in (["cmake", "-S", ROOT, "-B", b, "-DCMAKE_INSTALL_PREFIX=" + prefix], ["cmake", "--build", b, "-j", str(min(8, os.cpu_count() or 1))],
+                ["cmake", "--install", b]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, " ".join(cmd) + "\n" + r.stdout[-3000:] + r.stderr[-3000:]
+    abi = re.search(r"#define PRL_HIP_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "prl_hip.h")).read()).group(1)
+    so = os.path.join(prefix, "lib", "libprlib_hip.so." + abi)
+    assert os.path.exists(so) and os.path.exists(os.path.join(prefix, "lib", "libprlib_hip_host.a"))
+    assert os.path.exists(os.path.join(prefix, "lib", "cmake", "prlib_hip", "prlib_hipConfig.cmake"))
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    names = sorted(ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.split() and ln.split()[-2] in "TtWw")
+    from prlib_amd import _capi
+
+    assert names == sorted(_capi.EXPORTED_SYMBOLS)
+    from oracle import capi as oc
+
+    oc.build()   # (the sample checks itself against the oracle when it runs on a GPU box; here it only has to build)
+    exe = str(tmp_path / "dropin")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I" + os.path.join(prefix, "include", "prl"),
+                        os.path.join(ROOT, "tests", "cpp", "test_dropin_sample.cpp"), "-L" + os.path.join(prefix, "lib"), "-lprlib_hip_host", "-lprlib_hip",
+                        "-L" + os.path.join(ROOT, "oracle"), "-lprl_oracle", "-Wl,-rpath," + os.path.join(prefix, "lib"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+                        "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0 and os.path.exists(exe), r.stderr[-3000:]
