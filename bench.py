@@ -100,9 +100,10 @@ def measure_traffic(args):
 
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", {"shader_clock_ghz": None, "gui_active_cycles_per_launch": None, "clock_note": "rocprofv3 not found"}
     vals = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    clock = {"shader_clock_ghz": None, "gui_active_cycles_per_launch": None, "clock_note": None}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"):
         tmp = tempfile.mkdtemp(prefix="prl_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
                "--gpus", "1", "--steps", "3", "--warmup", "1", "--pages", str(args.pages), "--size", str(args.size),
@@ -112,20 +113,57 @@ def measure_traffic(args):
         env = dict(os.environ, TMPDIR="/tmp")
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
-            per = []
+            per, dur = [], []
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
                         if row.get("Counter_Name") == counter and "k_fused" in row.get("Kernel_Name", ""):
                             per.append(float(row["Counter_Value"]))
+                            try:
+                                dur.append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+                            except (KeyError, ValueError):
+                                pass
+            if counter == "GRBM_GUI_ACTIVE":
+                # The clock the kernel really ran at (boxes of the pool differ by > 10 %: power-capped clocks): GRBM_GUI_ACTIVE
+                # sums the busy cycles of the 8 XCDs; over the same dispatches' own duration in this pass.
+                if per and len(dur) == len(per) and sum(dur) > 0:
+                    clock["gui_active_cycles_per_launch"] = round(sum(per) / len(per) / 8.0)
+                    clock["shader_clock_ghz"] = round(sum(per) / 8.0 / sum(dur), 4)
+                    clock["clock_note"] = "GRBM_GUI_ACTIVE / 8 XCDs over the dispatches' duration, rocprofv3 --pmc child pass of this run"
+                else:
+                    clock["clock_note"] = f"GRBM_GUI_ACTIVE: no usable k_fused rows (rc {r.returncode})"
+                continue
             if not per:
-                return None, f"{counter}: no k_fused rows (rc {r.returncode}): {(r.stderr or '')[-200:]}"
+                return None, f"{counter}: no k_fused rows (rc {r.returncode}): {(r.stderr or '')[-200:]}", clock
             vals[counter] = sum(per) / len(per)
         except Exception as e:  # (timeout, profiler refused)
-            return None, f"{counter}: {e!r}"
+            if counter == "GRBM_GUI_ACTIVE":
+                clock["clock_note"] = f"GRBM_GUI_ACTIVE: {e!r}"
+                continue
+            return None, f"{counter}: {e!r}", clock
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0), "2 x FETCH_SIZE + WRITE_SIZE (KiB), rocprofv3 --pmc, separate passes, this run"
+    return (int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0), "2 x FETCH_SIZE + WRITE_SIZE (KiB), rocprofv3 --pmc, separate passes, this run",
+            clock)
+
+
+def simd_cycles_per_row(clock, args, W, g, n_pages):
+    """Shader cycles of one k_fused launch x the chip's 1024 SIMDs / the wavefront-rows of the launch (pages x output rows x strips of
+    512 padded columns; the strip count is the library's own: a host-side helper of the test-hooks build)."""
+    if not clock.get("gui_active_cycles_per_launch"):
+        return None
+    try:
+        from prlib_amd import _capi as _c
+        LH = C.CDLL(_c.HOOKS_LIB_PATH)
+        uo = (C.c_int * 2)()
+        LH.prl_hip_internal_strip_layout.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_int)]
+        from prlib_amd import binarizations as _b
+        strips = LH.prl_hip_internal_strip_layout(_b.METHODS[args.method], g.w, W, g.out_w, 1 if args.morph else 0, uo)
+        if strips <= 0:
+            return None
+        return round(clock["gui_active_cycles_per_launch"] * 1024.0 / (n_pages * g.out_h * strips), 1)
+    except Exception:
+        return None
 
 
 def cpu_baseline(pages_host, params_oracle, budget_s):
@@ -289,13 +327,14 @@ def main():
     elif args.scaling == "weak" and args.gpus > 1:
         args.scaling = "both"   # N > 1: the weak-scaling line carries the strong-scaling measurement as well (`strong`)
     traffic, traffic_note = None, "not measured (--traffic 0 or N > 1)"
+    clock = {"shader_clock_ghz": None, "gui_active_cycles_per_launch": None, "clock_note": "not measured (--traffic 0 or N > 1)"}
     under_profiler = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
     if under_profiler:
         # a profiler's preloaded library has initialised the GPU in this process already: starting the counter passes from
         # here would be an exec() from a GPU-initialised process, which the pool refuses
         traffic_note = "not measured: this run is itself under a profiler"
     elif args.traffic and args.gpus == 1 and args.mode == "auto" and os.environ.get("PRL_BENCH_DRYRUN") != "1":
-        traffic, traffic_note = measure_traffic(args)   # child processes, before anything here touches the GPU
+        traffic, traffic_note, clock = measure_traffic(args)   # child processes, before anything here touches the GPU
     import torch
 
     if args.lib or args.hooks:
@@ -525,6 +564,11 @@ def main():
                 "frac_whole_call": round(call_gbs / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "traffic_note": traffic_note,
+                # which box this was: the kernel's own clock and what a wavefront-row cost in SIMD cycles (a build's speed is the
+                # second number, a box's the first)
+                "shader_clock_ghz": clock["shader_clock_ghz"],
+                "simd_cycles_per_wavefront_row": simd_cycles_per_row(clock, args, W, g, n_mine),
+                "clock_note": clock["clock_note"],
                 "kernel": "k_fused" if args.mode == "auto" else "literal chain",
                 "kernel_ms": round(kernel_ms, 4),
                 "call_ms": round(call_ms, 4),

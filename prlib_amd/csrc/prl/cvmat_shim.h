@@ -41,6 +41,7 @@ enum Code {   // opencv2/core/base.hpp
     StsBadArg = -5,
     StsUnsupportedFormat = -210,
     StsOutOfRange = -211,
+    StsNotImplemented = -213,
     StsAssert = -215,
     GpuApiCallError = -217,
 };

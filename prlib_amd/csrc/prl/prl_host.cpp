@@ -5,6 +5,7 @@
 // (tests/cpp/opencv_api/).  With OpenCV present the colour conversion is OpenCV's own cv::cvtColor, as in the reference.
 #include "prl.h"
 
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -235,12 +236,15 @@ double prl::findAngle(const cv::Mat& inputImage)
 // (cv::adaptiveThreshold, :78) and asks Leptonica's pixOrientDetectDwa / makeOrientDecision for one of four orientations
 // (:91, :101).  prl::deskew - its only caller (:238) - always hands it the 1-channel thresholded page, for which the gray page
 // is EMPTY: the function leaves through its NULL-pix exit with 0 (:80-84) or throws inside adaptiveThreshold, depending on the
-// OpenCV version.  This layer returns that 0.0 for every input: the orientation step of the hot path is a no-op
-// (SURVEY.md Appendix D), and Leptonica's DWA text-orientation detector is outside the
-// path's scope.  A 3-channel caller therefore always gets "up" (L_TEXT_ORIENT_UNKNOWN -> 0.0, :125-128).
+// OpenCV version.  This layer answers that 0.0 for every input that is not 3-channel: the orientation step of the hot path is a
+// no-op.  For a 3-CHANNEL caller the reference really looks (and can answer 90 / 180 / 270): Leptonica's
+// DWA text-orientation detector is outside this library's scope and its source is not available to restate - such
+// a call fails loudly instead of answering "up" without having looked.
 double prl::findOrientation(const cv::Mat& inputImage)
 {
-    (void)inputImage;
+    if (!inputImage.empty() && inputImage.channels() == 3)
+        PRL_FAIL_CV(cv::Error::StsNotImplemented,
+                    "prl::findOrientation on a 3-channel image needs Leptonica's pixOrientDetectDwa (deskew.cpp:91), which this library does not provide");
     return 0.0;
 }
 
@@ -250,14 +254,21 @@ void thin_impl(int method, cv::Mat& inputImage, cv::Mat& outputImage)
     if (inputImage.empty()) throw std::invalid_argument("Input image for thinning is empty");
     if (inputImage.type() != CV_8UC3 && inputImage.type() != CV_8UC1)
         throw std::invalid_argument("Invalid type of image for thinning (required 8 or 24 bits per pixel)");
-    // the reference works on the caller's buffer when input and output share data, else on a clone (:71-80)
+    // The reference works on the caller's buffer when input and output share data, else on a clone (thinZhangSuen.cpp:71-80).
+    // In place, 1 channel: every step (&= 1, the iterations, *= 255 at :100-103) writes through the shared buffer; the two headers
+    // stay as they are.  In place, 3 channels: cvtColor (:84) gives the working Mat a new 1-channel buffer, the skeleton is
+    // computed there and dropped - neither of the caller's Mats changes (reproduced: nothing to compute).
     const bool in_place = inputImage.data == outputImage.data;
+    if (in_place && inputImage.channels() == 3) return;
     cv::Mat work = in_place ? inputImage : inputImage.clone();
     if (work.channels() == 3) bgr2gray_inplace(work);
     cv::Mat result(work.rows, work.cols, CV_8UC1);
     const int st = prl_hip_thin_host(method, work.data, work.step, work.cols, work.rows, result.data, result.step);
     if (st != PRL_OK) raise(st);
-    if (in_place) inputImage = result;
+    if (in_place) {
+        for (int y = 0; y < result.rows; ++y) std::memcpy(inputImage.ptr(y), result.ptr(y), (size_t)result.cols);
+        return;
+    }
     outputImage = result;
 }
 }  // namespace

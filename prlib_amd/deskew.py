@@ -95,7 +95,10 @@ def find_orientation(pages):
     """prl::findOrientation.  The reference builds its gray page only for 3-channel input (deskew.cpp:73-76) and then needs
     Leptonica's pixOrientDetectDwa (:91); for the 1-channel page prl::deskew hands it (:238) the gray page is empty and the
     function returns 0 through its NULL-pix exit (:81-84) or throws, depending on the OpenCV version.  Canonical result: 0.0
-    (SURVEY.md Appendix D)."""
+    (SURVEY.md Appendix D).  `pages`: H x W or N x H x W (1 channel).  A 3-channel page (H x W x 3 / N x H x W x 3) is where the
+    reference really runs Leptonica's detector: not provided here, NotImplementedError instead of a silent 0."""
+    if pages.dim() == 4 or (pages.dim() == 3 and pages.shape[-1] == 3):
+        raise NotImplementedError("prl::findOrientation on 3-channel pages needs Leptonica's pixOrientDetectDwa (deskew.cpp:91)")
     return 0.0 if pages.dim() == 2 else np.zeros(pages.shape[0], dtype=np.float64)
 
 

@@ -217,6 +217,42 @@ static void test_gpu()
         for (int y = 0; y < sk.rows; ++y) bad += std::memcmp(sk.ptr(y), &tw[(size_t)y * mk.cols], (size_t)mk.cols) != 0;
         CHECK(bad == 0);
     }
+    // in place (input and output share their data, thinZhangSuen.cpp:71-74): the skeleton is written THROUGH the caller's buffer
+    // (:100-103) - same data pointer, same step afterwards, also for a ROI view; a 3-channel in-place call changes nothing (the
+    // reference's cvtColor re-allocates its working Mat, :84, and the result is dropped)
+    {
+        CHECK(prl_oracle_thin(0, mk.data, mk.step, mk.cols, mk.rows, tw.data(), (size_t)mk.cols, nullptr) == PRL_OK);
+        cv::Mat wide(mk.rows, mk.cols + 24, CV_8UC1);
+        std::memset(wide.data, 7, (size_t)wide.rows * wide.step);
+        cv::Mat view = wide(cv::Rect(11, 0, mk.cols, mk.rows));
+        for (int y = 0; y < mk.rows; ++y) std::memcpy(view.ptr(y), mk.ptr(y), (size_t)mk.cols);
+        cv::Mat same = view;
+        unsigned char* before = view.data;
+        prl::thinZhangSuen(view, same);
+        CHECK(view.data == before && same.data == before && view.step == wide.step && view.cols == mk.cols);
+        bad = 0;
+        for (int y = 0; y < mk.rows; ++y) {
+            bad += std::memcmp(view.ptr(y), &tw[(size_t)y * mk.cols], (size_t)mk.cols) != 0;
+            bad += wide.at<unsigned char>(y, 10) != 7 || wide.at<unsigned char>(y, 11 + mk.cols) != 7;   // nothing outside the view
+        }
+        CHECK(bad == 0);
+        cv::Mat c3(20, 30, CV_8UC3);
+        std::memset(c3.data, 200, (size_t)c3.rows * c3.step);
+        cv::Mat c3same = c3;
+        prl::thinGuoHall(c3, c3same);
+        CHECK(c3.type() == CV_8UC3 && c3same.data == c3.data && c3.at<unsigned char>(5, 7) == 200);
+    }
+    // prl::findOrientation (deskew.h:52): 0.0 for the 1-channel page prl::deskew hands it (deskew.cpp:238, :73-84); a 3-channel
+    // caller would get Leptonica's detector in the reference - here a cv::Exception that says so, not a silent "up"
+    {
+        cv::Mat g1 = synth_page(40, 50, 3);
+        CHECK(prl::findOrientation(g1) == 0.0);
+        cv::Mat c3(40, 50, CV_8UC3);
+        std::memset(c3.data, 128, (size_t)c3.rows * c3.step);
+        bool not_impl = false;
+        try { (void)prl::findOrientation(c3); } catch (const cv::Exception& e) { not_impl = e.code == cv::Error::StsNotImplemented && std::strstr(e.what(), "pixOrientDetectDwa") != nullptr; }
+        CHECK(not_impl);
+    }
 }
 
 // a page of horizontal "text lines" drawn at a small slope, for deskew
