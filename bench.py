@@ -241,7 +241,8 @@ def worst_case_legs(args, prlib_amd, _capi, L, dev, pages, out, params, method, 
     """What the same call costs when the input defeats the fast path.  (a) `literal`: the benchmark's own pages through
     PRL_MODE_LITERAL (float64 integral planes, 16 B per padded pixel, in chunks) - what every page costs that overflows a
     queue.  (b) `adversarial`: pages of two-level stripes chosen so that half of all pixels sit inside the float32 decision
-    band (adversarial_stripes): the threshold sweep queues them, the queue overflows, the page is flagged and redone by the
+    band (adversarial_stripes): the threshold sweep queues them, the queue overflows, the page is flagged and redone by the exact sweep
+    (k_fused_exact: integer sums, the float64 interval test inline; until round 5: by the
     literal pipeline - auto mode's worst case = fused pass + literal pass + the host round trip per flagged page."""
     import numpy as np
     import torch
@@ -282,8 +283,8 @@ def worst_case_legs(args, prlib_amd, _capi, L, dev, pages, out, params, method, 
         "pages": int(n_adv), "ms_per_step": round(t * 1e3, 3), "value": round(n_adv * px_page / t / 1e6, 1), "unit": "Mpixels/s",
         "pattern": f"vertical stripes of period 2, levels {a} / {b}: T* - (p - 0.5) = {margin:.2e} on every interior pixel of the "
                    f"{a}-columns (decision band eps1 = {eps1})",
-        "literal_pages": int(st.literal_pages), "refined_pixels": int(st.refined_pixels), "exact_pixels": int(st.exact_pixels),
-        "mismatching_pixels_page0": bad,
+        "exact_sweep_pages": int(st.exact_sweep_pages), "literal_pages": int(st.literal_pages), "refined_pixels": int(st.refined_pixels),
+        "exact_pixels": int(st.exact_pixels), "mismatching_pixels_page0": bad,
     }
     return res
 

@@ -110,8 +110,9 @@ typedef struct prl_binarize_stats {
     uint64_t refined_pixels;    /* decided by the in-kernel float64 interval test instead of the float32 one */
     uint64_t exact_pixels;      /* decided by the absolute-integral literal evaluation (fix-up kernel) */
     uint64_t literal_pages;     /* pages that ran the full literal pipeline */
-    uint64_t wolf_candidates;   /* Wolf-Jolion: pixels whose deviation was evaluated literally to find devianceMax */
-    uint64_t reserved[3];
+    uint64_t wolf_candidates;   /* Wolf-Jolion: pixels whose deviation was evaluated literally to find devianceMax (a lower bound: a wavefront stops counting once its page's list is full) */
+    uint64_t exact_sweep_pages; /* pages whose refine queue overflowed and which the exact sweep redid (the float64 interval test inline; was reserved[0]) */
+    uint64_t reserved[2];
 } prl_binarize_stats;
 
 /* ---- library / device ------------------------------------------------------------------- */

@@ -89,7 +89,8 @@ class BinarizeStats(C.Structure):
         ("exact_pixels", C.c_uint64),
         ("literal_pages", C.c_uint64),
         ("wolf_candidates", C.c_uint64),
-        ("reserved", C.c_uint64 * 3),
+        ("exact_sweep_pages", C.c_uint64),
+        ("reserved", C.c_uint64 * 2),
     ]
 
 

@@ -387,12 +387,20 @@ __device__ __forceinline__ void store_tail(gptr o, unsigned lo, unsigned hi, int
 // One wavefront: a strip of SW padded columns x a segment of output rows.
 //   EDGE  : the strip touches the left/right page border (replicate clamp, partial stores)
 //           the leaving row and the compared pixels are never re-read from memory
-template <int METHOD, int SH, bool EDGE, bool WIDE>
+// EXACT (k_fused_exact, the second chance of a page whose queue overflowed): what the float32 test leaves open is decided HERE by the
+// float64 interval test on the exact sums this loop holds (refine64, what k_refine would do with a queued pixel) and the mask byte is
+// set before it is stored; only what that leaves open too - true ties - goes to the fix-up list.  Nothing is queued.
+struct ExactOut {
+    WorkItem* wl = nullptr;      // the fix-up list (counters[1] entries), its corner accumulators and arrival counts
+    CornerAcc* acc = nullptr;
+    unsigned* done = nullptr;
+};
+template <int METHOD, int SH, bool EDGE, bool WIDE, bool EXACT = false>
 __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, size_t ostep,
                                            const FusedParams& fp, int page, int xs, int ys, int ye, int lane,
                                            const PageK& pk, unsigned wid, PageGlobals* __restrict__ g,
                                            RefItem* __restrict__ rl, WorkItem* __restrict__ cand,
-                                           unsigned* __restrict__ counters, bool last_ext = false)
+                                           unsigned* __restrict__ counters, bool last_ext = false, const ExactOut& xo = ExactOut{})
 {
     constexpr bool SWEEP = (METHOD == kWolfMax || METHOD == kWolfCollect);
     // WIDE: w - 1 > 181, S does not fit the mantissa trick (eval32)
@@ -454,6 +462,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
 
     float vmax_lane = 0.0f;  // Wolf sweep A
     bool page_flagged = false;   // (wave-uniform) a push of this wavefront found its queue bucket full
+    [[maybe_unused]] unsigned x_refined = 0;   // EXACT: pixels this lane decided by the interval test (statistics, one atomic per lane at the end)
     uint2 vnew_n = load_win(ys + w);  // entering row of the first iteration, fetched one iteration ahead
 #pragma unroll 1
     for (int y = ys; y < ye; ++y) {
@@ -666,6 +675,33 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                         float v32;
                         const float t = eval32<METHOD, WIDE>(fp, S, Q, fmaf((float)p, kZ, pk.p0), pk, &v32);
                         if ((fabsf(t) > pk.eps1) && (v32 > fp.vthr32)) continue;
+                        if constexpr (EXACT) {
+                            const unsigned r = refine64<METHOD>(fp, S - sbias, Q, p, (double)g[page].imin, g[page].coeff, 0.0,
+                                                                METHOD == PRL_WOLFJOLION ? g[page].coeff_rel : 0.0);
+                            if (r != 2) {
+                                if (c < 4) lo = (lo & ~(0xffu << (8 * c))) | (r << (8 * c));
+                                else hi = (hi & ~(0xffu << (8 * (c - 4)))) | (r << (8 * (c - 4)));
+                                ++x_refined;
+                            } else {   // a true tie: absolute corners and the literal sequence decide (fix-up list, as k_refine fills it)
+                                atomicAdd(&g[page].n_exact, 1u);
+                                if (METHOD == PRL_WOLFJOLION) atomicOr(&g[page].need_literal, 1u);
+                                const unsigned idx = atomicAdd(&counters[1], 1u);
+                                if (idx < fp.wl_cap) {
+                                    WorkItem wi;
+                                    wi.page = page;
+                                    wi.y = y;
+                                    wi.x = x0 + c;
+                                    wi.pad = 0;
+                                    xo.wl[idx] = wi;
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k) xo.acc[idx].a[k] = 0ull;
+                                    xo.done[idx] = 0u;
+                                } else {
+                                    atomicOr(&g[page].worklist_overflow, 2u);
+                                }
+                            }
+                            continue;
+                        }
                         RefItem it;
                         it.page = page;
                         it.y = y;
@@ -708,6 +744,9 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             VS[c] += (unsigned)d;
             VQ[c] += (unsigned)(d * sm);
         }
+    }
+    if constexpr (EXACT) {
+        if (x_refined) atomicAdd(&g[page].n_refined, x_refined);
     }
     if (METHOD == kWolfMax) {
 #pragma unroll
@@ -1203,6 +1242,90 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
                                            fp.ext && strip == fp.n_strips - 1);
 }
 
+// ---- the second chance of a flagged page ("next" 2) ------------------------------------------------------------------
+// A page is flagged when the refine queue overflowed: more pixels inside the float32 decision band than the queue holds (pages
+// of stripes whose levels sit on their own threshold; DESIGN.md 6, worst_case.adversarial).  Those pixels are not undecidable -
+// they are 1e-4 from their threshold and the float64 interval test settles them - there were only too many to queue.  This
+// kernel is k_fused's integer loop with that test INLINE (strip_loop<..., EXACT>): same wavefront -> strip / segment mapping,
+// exact integer sums for every strip (no float32 loop), no queue; true ties go to the fix-up list.  The literal pipeline
+// (48 bytes per pixel) remains for pages that overflow even that list (2^17 ties).
+template <int METHOD, int SH, bool WIDE>
+__global__ void __launch_bounds__(256) k_fused_exact(PageSet src, PageSetOut dst, FusedParams fp, PageGlobals* __restrict__ g,
+                                                    unsigned* __restrict__ counters, WorkItem* __restrict__ wl,
+                                                    CornerAcc* __restrict__ acc, unsigned* __restrict__ done)
+{
+    const ThrParams& tp = fp.tp;
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned wpb = blockDim.x >> 6;
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned wv = threadIdx.x >> 6;
+    unsigned u = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * wpb + wv);
+    unsigned wid = 0;
+    int trows = 0, tsegs = 1, trow0 = 0;
+    bool found = false;
+    for (int k = 0; k < fp.n_tiers; ++k) {
+        const unsigned n = fp.tier[k].waves;
+        const unsigned lo = (unsigned)(((unsigned long long)n * xcd) >> 3), hi = (unsigned)(((unsigned long long)n * (xcd + 1u)) >> 3);
+        if (u < hi - lo) {
+            wid = lo + u;
+            trows = fp.tier[k].rows; tsegs = fp.tier[k].segs; trow0 = fp.tier[k].row0;
+            found = true;
+            u = fp.tier[k].first;
+            break;
+        }
+        u -= hi - lo;
+    }
+    if (!found) return;
+    const int per_page = fp.n_strips * tsegs;
+    const int page = (int)(wid / (unsigned)per_page);
+    const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
+    const int seg = rem / fp.n_strips;
+    const int strip = rem - seg * fp.n_strips;
+    wid += u;
+    gcptr img = (gcptr)src.page(page);
+    gptr out = (gptr)dst.page(page);
+    const int xs = strip * fp.uo;
+    const int ys = trow0 + seg * trows;
+    const int ye = min(ys + trows, tp.oh);
+    PageK pk;
+    pk.c1 = fp.c1;
+    pk.imin = 0.0f;
+    pk.p0 = -0.5f * kZ;
+    pk.eps1 = fp.eps1;
+    if (METHOD == PRL_FENG) {
+        const double imin = (double)g[page].imin;
+        const double c3 = (tp.k2 * imin + (-imin)) + 0.0;
+        pk.p0 = (float)((-0.5 - c3) * (double)kZ);
+    } else if (METHOD == PRL_WOLFJOLION) {
+        // (the interval coefficient of k_wolf_interval is known by now - the host made this launch wait for it: the float32 test
+        // uses it with the same margin arithmetic as k_fused uses sweep A's estimate; what it leaves open refine64 decides with
+        // the coefficient's own bound)
+        pk.imin = (float)g[page].imin * kZ;
+        const float kmax = __uint_as_float(g[page].v32max_bits);
+        const float klow = kmax / (1.0f + fp.rho) - fp.kabs;
+        const float fl = (float)tp.f;
+        if (klow > fp.vthr32 && klow > 64.0f * fp.ev2) {
+            const float c = (float)tp.k / (__builtin_amdgcn_sqrtf(kmax) * fl);
+            const float delta = 0.51f * fp.rho + (0.26f * fp.ev2 + 0.51f * fp.kabs) / klow + 4.8e-7f;
+            const float ac = fabsf(c) * (1.0f + delta);
+            pk.c1 = c * fl;
+            pk.eps1 = fp.eps1 + kZ * (2.02f * 255.0f * ac * fp.es_max + 1.02f * 255.0f * fabsf((float)tp.k) * delta);
+        } else {
+            pk.c1 = 0.0f;
+            pk.eps1 = __builtin_inff();
+        }
+    }
+    ExactOut xo;
+    xo.wl = wl; xo.acc = acc; xo.done = done;
+    const int first_col = xs + 1 - tp.half;
+    const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
+    if (interior)
+        strip_loop<METHOD, SH, false, WIDE, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, nullptr, nullptr, counters, false, xo);
+    else
+        strip_loop<METHOD, SH, true, WIDE, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, nullptr, nullptr, counters,
+                                                 fp.ext && strip == fp.n_strips - 1, xo);
+}
+
 // ---- second stage: float64 interval test of the queued pixels ------------------------------------------------------
 // One thread per queued pixel, on the window sums that travel with it: exact ones from the integer pipeline; from the
 // float32 pipeline an exact S and a Q~ within flt_dq of the exact sum, which enters the interval as extra uncertainty of q
@@ -1304,7 +1427,7 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
                     for (int k = 0; k < 8; ++k) acc[idx].a[k] = 0ull;  // (instead of a 1 MB memset per call: nothing is queued as a rule)
                     done[idx] = 0u;
                 } else {
-                    atomicOr(&g[it.page].worklist_overflow, 1u);
+                    atomicOr(&g[it.page].worklist_overflow, 2u);
                 }
             }
         }
@@ -1545,7 +1668,7 @@ __global__ void k_wolf_literal_coeff(FusedParams fp, PageGlobals* __restrict__ g
     PageGlobals& pg = g[i];
     if (!pg.need_literal) return;
     if (pg.cand_overflow) {   // the candidate list does not hold every candidate of this page: the literal pipeline redoes it
-        pg.worklist_overflow = 1u;
+        pg.worklist_overflow = 2u;   // (bit 1: nothing short of the literal pipeline helps)
         return;
     }
     const double smax = pg.smax_found ? __longlong_as_double((long long)pg.smax_bits)
@@ -1860,18 +1983,50 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
     return PRL_OK;
 }
 
+// the threshold sweep of a flagged page's second chance (k_fused_exact)
+template <int METHOD>
+int launch_sweep_exact(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp, PageGlobals* g,
+                       unsigned* cnt, WorkItem* wl, CornerAcc* acc, unsigned* done)
+{
+    const unsigned blocks = 8u * fp.xcd_waves;
+    const dim3 grid(blocks), block(64);
+    const bool wide = fp.tp.w - 1 > 181;
+#define PRL_LAUNCH_EXACT(SHV)                                                                                                  \
+    do {                                                                                                                       \
+        if (wide) hipLaunchKernelGGL((k_fused_exact<METHOD, SHV, true>), grid, block, 0, stream, src, dst, fp, g, cnt, wl, acc, done);   \
+        else hipLaunchKernelGGL((k_fused_exact<METHOD, SHV, false>), grid, block, 0, stream, src, dst, fp, g, cnt, wl, acc, done);       \
+    } while (0)
+    switch (sh) {
+    case 0: PRL_LAUNCH_EXACT(0); break;
+    case 2: PRL_LAUNCH_EXACT(2); break;
+    case 4: PRL_LAUNCH_EXACT(4); break;
+    case 6: PRL_LAUNCH_EXACT(6); break;
+    default: return PRL_ERR_BAD_ARG;
+    }
+#undef PRL_LAUNCH_EXACT
+    PRL_HIP_CHECK(hipGetLastError());
+    return PRL_OK;
+}
+
 template <int METHOD>
 int launch_fused(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
                  PageGlobals* g, RefItem* rl, WorkItem* wl, WorkItem* cand, CornerAcc* acc, unsigned* cnt,
                  hipEvent_t ev_start, hipEvent_t ev_stop, int n_pages, const GroupArrays& ga,
-                 hipEvent_t before_refine = nullptr, CornerAcc* cacc = nullptr)
+                 hipEvent_t before_refine = nullptr, CornerAcc* cacc = nullptr, bool exact = false)
 {
+    unsigned* done = reinterpret_cast<unsigned*>(fp.segmax + kSegmaxCap);  // arrivals per queued pixel (see fused_small_bytes)
     if (ev_start) PRL_HIP_CHECK(hipEventRecord(ev_start, stream));
-    int st = launch_sweep<METHOD>(sh, stream, src, dst, fp, g, rl, cand, cnt);
+    int st;
+    if (exact) {
+        // (Wolf-Jolion: the inline interval test needs k / devianceMax with its bound, which the side stream is still working out)
+        if (before_refine) PRL_HIP_CHECK(hipStreamWaitEvent(stream, before_refine, 0));
+        st = launch_sweep_exact<METHOD>(sh, stream, src, dst, fp, g, cnt, wl, acc, done);
+    } else {
+        st = launch_sweep<METHOD>(sh, stream, src, dst, fp, g, rl, cand, cnt);
+    }
     if (st != PRL_OK) return st;
     if (ev_stop) PRL_HIP_CHECK(hipEventRecord(ev_stop, stream));
     if (before_refine) PRL_HIP_CHECK(hipStreamWaitEvent(stream, before_refine, 0));   // (Wolf-Jolion: the literal k / devianceMax of the side stream)
-    unsigned* done = reinterpret_cast<unsigned*>(fp.segmax + kSegmaxCap);  // arrivals per queued pixel (see fused_small_bytes)
     // (float pipeline: a wavefront per queued pixel, a few microseconds each; big batches queue ~10^4 of them: 4096 wavefronts
     // instead of 1024 took k_refine from 0.14 to 0.05 ms on 256 A4 pages (Niblack w=31); small calls keep the cheaper launch)
     const unsigned refine_blocks = fp.flt ? (fp.total_waves > 20000u ? 1024u : 256u) : 64u;
@@ -2178,7 +2333,7 @@ int fused_max_pages(const ThrParams& tp)
 // The whole pipeline of one call: threshold sweep, k_refine, literal fix-up (the last two find their queues on the device).
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst, void* small,
               PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, bool bit_out,
-              bool counters_zeroed, PageGlobals* host_globals, const WolfSide* wolf_side)
+              bool counters_zeroed, PageGlobals* host_globals, const WolfSide* wolf_side, bool exact)
 {
     FusedParams fp{};
     fp.tp = tp;
@@ -2187,7 +2342,7 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     // window rows that ARE re-read (the leaving row, the compared-pixel row): 4.31-4.47 -> 4.15 ms on 256 x 4K pages
     fp.nt_store = env_knobs().nt_store ? 1 : 0;
     double cq = 1.0, dq = 0.0;
-    fp.flt = flt_usable(tp, src.step, &cq, &dq) ? 1 : 0;
+    fp.flt = !exact && flt_usable(tp, src.step, &cq, &dq) ? 1 : 0;   // (exact: the integer loop for every strip - exact sums)
     fp.flt_dq = fp.flt ? dq : 0.0;
     fp.n_strips = strip_layout(tp, fp.flt != 0, bit_out, &fp.uo, &fp.ext);
     // Row segments.  Long segments amortise the (w-1)-row warm-up, short ones fill the chip and keep the tail short when it
@@ -2424,17 +2579,17 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
                 before_refine = wolf_side->ev_coeff;
             }
             return launch_fused<PRL_WOLFJOLION>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga,
-                                                before_refine, cacc);
+                                                before_refine, cacc, exact);
         };
         const int st = forked();
         if (st != PRL_OK && wolf_side) (void)hipStreamSynchronize(wolf_side->stream);
         return st;
     }
     switch (tp.method) {
-    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga);
-    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga);
-    case PRL_NICK: return launch_fused<PRL_NICK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga);
-    case PRL_FENG: return launch_fused<PRL_FENG>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga);
+    case PRL_SAUVOLA: return launch_fused<PRL_SAUVOLA>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga, nullptr, nullptr, exact);
+    case PRL_NIBLACK: return launch_fused<PRL_NIBLACK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga, nullptr, nullptr, exact);
+    case PRL_NICK: return launch_fused<PRL_NICK>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga, nullptr, nullptr, exact);
+    case PRL_FENG: return launch_fused<PRL_FENG>(sh, stream, src, dst, fp, d_globals, rl, wl, cand, acc, cnt, ev_start, ev_stop, n_pages, ga, nullptr, nullptr, exact);
     default: return PRL_ERR_BAD_ARG;
     }
 }

@@ -136,7 +136,7 @@ struct PendingCall {
 };
 
 struct CallStats {
-    uint64_t seq = 0, pixels = 0, refined = 0, exact = 0, literal_pages = 0, wolf_candidates = 0;
+    uint64_t seq = 0, pixels = 0, refined = 0, exact = 0, literal_pages = 0, wolf_candidates = 0, exact_sweep_pages = 0;
 };
 
 struct StreamWs {
@@ -705,6 +705,86 @@ int redo_pages_literal(StreamWs* ws, const PendingCall& pc, const std::vector<in
     return PRL_OK;
 }
 
+// The second chance of pages whose REFINE QUEUE overflowed (bit 0 of worklist_overflow: more pixels inside the float32 decision band
+// than the queue holds - pages of stripes whose levels sit near their own threshold): the exact sweep (k_fused_exact: integer sums
+// for every strip, the float64 interval test inline, no queue) over those pages as one batch, ties through the usual fix-up, then
+// the morphology pass.  `still` receives the pages that overflowed the fix-up list on the way (true ties by the 10^5): those go to
+// the literal pipeline.  Own workspace layout inside ws->scratch; synchronises the stream (it reads the flags back).
+int redo_pages_exact(StreamWs* ws, const PendingCall& pc, const std::vector<int>& idx, std::vector<int>* still, CallStats* cs)
+{
+    const int n = (int)idx.size();
+    if (n == 0) return PRL_OK;
+    prl_binarize_geometry g;
+    int st = geometry_impl(&pc.params, pc.width, pc.height, &g);
+    if (st != PRL_OK) return st;
+    const ThrParams tp = make_thr_params(&pc.params, g, pc.width, pc.height);
+    const int morph = pc.params.morph_iterations;
+    const size_t mask_step = ((size_t)g.out_w + 63) / 64 * 64, mask_page = r256(mask_step * (size_t)g.out_h);
+    const bool large = morph != 0 && std::abs(morph) > kMorphMaxFusedRadius;
+    const int chunk = std::min(n, std::max(1, fused_max_pages(tp)));
+    const size_t masks = morph != 0 ? mask_page * (size_t)chunk * (large ? 2 : 1) : 0;
+    const size_t fused_bytes = r256(fused_small_bytes(chunk));
+    const size_t tab_bytes = r256(sizeof(void*) * (size_t)n), glob_bytes = r256(sizeof(PageGlobals) * (size_t)n);
+    // [byte masks x chunk (morph != 0)][second mask buffer (large radii)][fused work area][PageGlobals x n][src table][dst table]
+    st = ws_grow(&ws->scratch, &ws->scratch_bytes, masks + fused_bytes + glob_bytes + 2 * tab_bytes, ws->stream);
+    if (st != PRL_OK) return st;
+    auto* base = static_cast<uint8_t*>(ws->scratch);
+    uint8_t* d_mask = base;
+    uint8_t* d_mask2 = d_mask + mask_page * (size_t)chunk;
+    uint8_t* d_fused = base + masks;
+    auto* d_g = reinterpret_cast<PageGlobals*>(d_fused + fused_bytes);
+    auto** d_src_tab = reinterpret_cast<const uint8_t**>(d_fused + fused_bytes + glob_bytes);
+    auto** d_dst_tab = reinterpret_cast<uint8_t**>(d_fused + fused_bytes + glob_bytes + tab_bytes);
+    std::vector<const uint8_t*> h_src((size_t)n);
+    std::vector<uint8_t*> h_dst((size_t)n);
+    for (int j = 0; j < n; ++j) {
+        const size_t i = (size_t)idx[(size_t)j];
+        h_src[(size_t)j] = pc.src_tab.empty() ? pc.src.base + i * pc.src.page_stride : pc.src_tab[i];
+        h_dst[(size_t)j] = pc.dst_tab.empty() ? pc.dst.base + i * pc.dst.page_stride : pc.dst_tab[i];
+    }
+    PRL_HIP_CHECK(hipMemcpyAsync(d_src_tab, h_src.data(), sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ws->stream));
+    PRL_HIP_CHECK(hipMemcpyAsync(d_dst_tab, h_dst.data(), sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, ws->stream));
+    PRL_HIP_CHECK(hipStreamSynchronize(ws->stream));   // (the host vectors go out of scope; pageable memory)
+    for (int c0 = 0; c0 < n; c0 += chunk) {
+        const int cnt = std::min(chunk, n - c0);
+        st = init_globals_run(d_g + c0, cnt, ws->stream, d_fused);   // (+ the counter block)
+        if (st != PRL_OK) return st;
+        PageSet src{};
+        src.table = d_src_tab + c0;
+        src.step = pc.src.step;
+        PageSetOut out{};
+        out.table = d_dst_tab + c0;
+        out.step = pc.dst.step;
+        PageSetOut thr = out;
+        if (morph != 0) {
+            thr = PageSetOut{};
+            thr.base = d_mask;
+            thr.page_stride = mask_page;
+            thr.step = mask_step;
+        }
+        const WolfSide* wolf_side = (tp.method == PRL_WOLFJOLION && ws->wolf.stream) ? &ws->wolf : nullptr;
+        st = fused_run(tp, src, cnt, thr, d_fused, d_g + c0, ws->stream, nullptr, nullptr, false, true, nullptr, wolf_side, true);
+        if (st != PRL_OK) return st;
+        if (morph == 0) continue;
+        PageSet msrc{};
+        msrc.base = d_mask;
+        msrc.page_stride = mask_page;
+        msrc.step = mask_step;
+        if (!large) st = morph_binary_run(morph, msrc, cnt, g.out_w, g.out_h, out, ws->stream);
+        else st = morph_large_run(morph, msrc, cnt, g.out_w, g.out_h, out, d_mask2, mask_step, ws->stream);
+        if (st != PRL_OK) return st;
+    }
+    std::vector<PageGlobals> hg((size_t)n);
+    PRL_HIP_CHECK(hipMemcpyAsync(hg.data(), d_g, sizeof(PageGlobals) * (size_t)n, hipMemcpyDeviceToHost, ws->stream));
+    PRL_HIP_CHECK(hipStreamSynchronize(ws->stream));
+    for (int j = 0; j < n; ++j) {
+        cs->refined += hg[(size_t)j].n_refined;
+        cs->exact += hg[(size_t)j].n_exact;
+        if (hg[(size_t)j].worklist_overflow) still->push_back(idx[(size_t)j]);
+    }
+    return PRL_OK;
+}
+
 // Look at the flags of the oldest pending call (waits for that call's work): statistics, literal redo of overflow pages.
 int resolve_front(StreamWs* ws)
 {
@@ -718,16 +798,25 @@ int resolve_front(StreamWs* ws)
     CallStats cs;
     cs.seq = pc.seq;
     cs.pixels = pc.pixels;
-    std::vector<int> flagged;
+    // Flagged pages.  Bit 0 alone: the refine queue overflowed - the exact sweep redoes the page (a few times a page's usual
+    // cost, not bounded by the literal budget).  Bit 1 (then, or after that sweep): the fix-up list overflowed - the literal pipeline.
+    std::vector<int> flagged, second;
     for (int i = 0; i < pc.n_pages; ++i) {
         cs.refined += hg[(size_t)i].n_refined;
         cs.exact += hg[(size_t)i].n_exact;
         cs.wolf_candidates += hg[(size_t)i].n_cand;
-        if (hg[(size_t)i].worklist_overflow) {
-            cs.literal_pages += 1;
-            flagged.push_back(i);
-        }
+        if (hg[(size_t)i].worklist_overflow & 2u) flagged.push_back(i);
+        else if (hg[(size_t)i].worklist_overflow) second.push_back(i);
     }
+    cs.exact_sweep_pages = second.size();
+    ws->last = cs;
+    if (!second.empty()) {
+        ws->clean_pages = 0;   // (the stream's state is no longer what the last call's epilogue left)
+        const int st2 = redo_pages_exact(ws, pc, second, &flagged, &cs);
+        if (st2 != PRL_OK) return st2;
+        std::sort(flagged.begin(), flagged.end());
+    }
+    cs.literal_pages = flagged.size();
     ws->last = cs;
     const int budget = literal_budget();
     if (budget >= 0 && (int)flagged.size() > budget) {   // the caller's cost bound: report, do not redo
@@ -1182,6 +1271,7 @@ int prl_hip_last_stats(prl_binarize_stats* out)
     out->refined_pixels = ws->last.refined;
     out->exact_pixels = ws->last.exact;
     out->literal_pages = ws->last.literal_pages;
+    out->exact_sweep_pages = ws->last.exact_sweep_pages;
     out->wolf_candidates = ws->last.wolf_candidates;
     return PRL_OK;
 }

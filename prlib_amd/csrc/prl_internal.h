@@ -216,7 +216,7 @@ struct PageGlobals {
     double coeff;                   // k / devianceMax             binarizeWolfJolion.cpp:121
     unsigned int n_refined;         // pixels decided by the float64 interval test
     unsigned int n_exact;           // pixels sent to the absolute-integral fix-up
-    unsigned int worklist_overflow; // fix-up list overflowed -> page must rerun literally
+    unsigned int worklist_overflow; // bit 0: the refine queue overflowed (too many pixels inside the float32 band: the exact sweep redoes the page); bit 1: the fix-up list or Wolf-Jolion's candidate list overflowed (the literal pipeline redoes it)
     unsigned int v32max_bits;       // Wolf fused sweep A: float32 bits of the page's largest variance estimate
     unsigned int n_cand;            // Wolf: candidate pixels for the literal devianceMax (sweep B; statistics)
     unsigned int need_literal;      // Wolf: a pixel of this page reached the literal fix-up -> the literal devianceMax is computed (lazily)
@@ -252,7 +252,8 @@ size_t fused_small_bytes(int n_pages);
 int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSetOut& dst,
               void* small, PageGlobals* d_globals, hipStream_t stream, hipEvent_t ev_start,
               hipEvent_t ev_stop, bool bit_out = false, bool counters_zeroed = false,
-              PageGlobals* host_globals = nullptr, const WolfSide* wolf_side = nullptr);  // host_globals (pinned, n_pages entries): see FusedParams::ep_host
+              PageGlobals* host_globals = nullptr, const WolfSide* wolf_side = nullptr,   // host_globals (pinned, n_pages entries): see FusedParams::ep_host
+              bool exact = false);   // exact: the second chance of flagged pages (k_fused_exact: the float64 interval test inline, no queue)
 bool fused_supports(const ThrParams& tp);
 int fused_max_pages(const ThrParams& tp);  // pages one fused_run call can take (Wolf-Jolion: per-wavefront maxima storage)
 

@@ -837,3 +837,42 @@ def test_ragged_strips(prl, oracle, cuda_device, method, k, win, outs):
     wd = outs[1] + 1 if method in (SAUVOLA, NIBLACK) else outs[1] + win
     _check(prl, oracle, cuda_device, _pages((win + 45, wd), ["doc", "noise"], seed=5), method, win, k, 2)   # bit plane: multiple of 8
     _check(prl, oracle, cuda_device, _pages((win + 45, wd), ["doc", "noise"], seed=6), method, win, k, -1)
+
+
+@pytest.mark.parametrize("method,w,k", [(SAUVOLA, 31, 0.34), (NIBLACK, 31, 0.2), (NICK, 21, -0.1), (SAUVOLA, 101, 0.34)])
+def test_queue_overflow_takes_the_exact_sweep_not_the_literal_pipeline(prl, oracle, cuda_device, method, w, k):
+    """Pages of two-level stripes whose levels sit inside the float32 decision band on every second pixel (bench.py's
+    adversarial_stripes: the closed forms of SURVEY.md A.1 / A.2 / A.4): the threshold sweep would queue half of all pixels, the
+    refine queue overflows and the page is flagged (bit 0).  Those pixels are ~1e-4 from their threshold - the float64 interval
+    test settles every one of them - so the page gets a second chance through the exact sweep (k_fused_exact: integer sums for
+    every strip, refine64 inline, no queue) instead of the 48-bytes-per-pixel literal pipeline; only pages that ALSO overflow
+    the fix-up list (true ties by the 10^5: the tests above) still go there.  With and without the morphology pass, through
+    the batch and the page-table entry, beside ordinary pages, byte for byte the oracle."""
+    import os
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    a, b, margin = bench.adversarial_stripes(method, w, k, None)
+    assert margin < 2e-3
+    h, wd = 1900, 2300                                       # (a wavefront's share of a page this size overflows its queue bucket)
+    stripes = np.where(np.arange(wd) % 2 == 0, a, b).astype(np.uint8)[None, :].repeat(h, 0)
+    doc = _pages((h, wd), ["doc"], seed=131)[0]
+    mixed = stripes.copy()
+    mixed[200:420, 300:800] = doc[200:420, 300:800]          # an island of ordinary content: interior, edge and border strips all queue
+    for morph in (0, 2):
+        st = _check(prl, oracle, cuda_device, [doc, stripes, mixed], method, w, k, morph)
+        assert st.exact_sweep_pages == 2 and st.literal_pages == 0, (st.exact_sweep_pages, st.literal_pages)
+        # (what the first sweep queued before it gave up, plus what the exact sweep's own float32 test - the integer loop's
+        # narrower band - still left to the inline interval test)
+        assert st.refined_pixels > 1 << 20
+    # a budget of zero literal pages does not stand in the way of the second chance (it bounds the literal pipeline only)
+    prl.set_literal_page_budget(0)
+    try:
+        st = _check(prl, oracle, cuda_device, [stripes], method, w, k, 0)
+        assert st.exact_sweep_pages == 1 and st.literal_pages == 0
+    finally:
+        prl.set_literal_page_budget(-1)
