@@ -2445,7 +2445,9 @@ int fused_run(const ThrParams& tp, const PageSet& src, int n_pages, const PageSe
     fp.wl_cap = kWorkCap;
     // a page's share of the candidate list: the whole list for a single page, never less than a quarter of it in a batch
     // (real scans queue ~400 candidates a page, profiles/r04/real_scans.jsonl; a flat page would queue every pixel)
-    fp.cand_page_cap = n_pages <= 1 ? kWorkCap : kWorkCap / 4;
+    // (a page's share of the candidate list: a quarter for small calls; for batches an n-th, but never below what the reference's
+    // own scans need (~10^4) - four flat pages of a big batch no longer fill the list for every document page behind them)
+    fp.cand_page_cap = n_pages <= 1 ? kWorkCap : std::max(kWorkCap / (unsigned)std::max(4, n_pages), std::min(kWorkCap / 4u, 10000u));
     // need_p0 = 0 only where T > -0.5 for every window, so a black pixel can never come out white in the float32 sign test (the
     // literal clamps T8 at 0).  Beyond T >= 0 two families qualify: a small negative k of Niblack / NICK - s <= sqrt(q) and
     // q <= 255 m (Q = sum P^2 <= 255 sum P), so T >= m - |k| sqrt(255 m) >= -k^2 255 / 4, above -0.45 for |k| < 0.084 (NICK's header

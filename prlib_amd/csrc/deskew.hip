@@ -1128,6 +1128,10 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
         st = ensure_buffer(&ctx->ppht_buf[4], &ctx->ppht_bytes[4], b_accum);
         if (st != PRL_OK) return st;
         int* d_accum = static_cast<int*>(ctx->ppht_buf[4]);
+        // (the paired un-votes address the cells as 64-bit words: every page's accumulator starts on an 8-byte boundary - hipMalloc
+        // gives 256, a page is kNumAngle x numrho x 4 bytes with kNumAngle even - and a biased cell never borrows:
+        // count > -2^31 + W H)
+        if (reinterpret_cast<uintptr_t>(d_accum) % 8 != 0) return PRL_ERR_BAD_ARG;
         PRL_HIP_CHECK(hipMemcpyAsync(d_plist, redo.data(), (size_t)n_redo * 4, hipMemcpyHostToDevice, stream));
         PRL_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_accum), (int)kAccBias, (size_t)n_redo * kNumAngle * numrho, stream));   // count 0 = bias
         a.width = width; a.height = height; a.numrho = numrho; a.threshold = threshold; a.line_length = line_length; a.line_gap = line_gap;

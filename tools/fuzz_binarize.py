@@ -22,6 +22,9 @@ ap.add_argument("--wide", type=float, default=0.0, help="probability of a window
 ap.add_argument("--hooks", type=int, default=0, help="1: load libprlib_hip_testhooks.so (reads the PRL_HIP_* knobs)")
 ap.add_argument("--real", type=float, default=0.0, help="probability that a page is cut from one of the reference's scans (tests/golden/scans, "
                 "tests/golden/stages: random crop, flip, transposition, gain / offset) instead of being synthetic")
+ap.add_argument("--adversarial", type=float, default=0.0, help="probability of a call on large pages of stripes whose levels sit inside the "
+                "float32 decision band on every second pixel (bench.adversarial_stripes; methods 0, 1, 3): the refine queue overflows, the "
+                "exact sweep redoes the pages")
 a = ap.parse_args()
 if a.hooks:
     prlib_amd._capi.use_library(prlib_amd._capi.HOOKS_LIB_PATH)
@@ -77,7 +80,8 @@ def page(h, w, kind, i):
 t_end = time.time() + a.seconds
 calls = pixels = bad_calls = 0
 first_bad = None
-stats = {"refined": 0, "exact": 0, "literal_pages": 0}
+stats = {"refined": 0, "exact": 0, "literal_pages": 0, "exact_sweep_pages": 0, "adversarial_calls": 0}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 while time.time() < t_end:
     method = METHODS[int(rng.integers(0, len(METHODS)))]
     win = int(rng.choice([3, 5, 9, 15, 21, 31, 41, 63, 101])) if rng.random() < 0.9 else int(rng.integers(1, 60)) * 2 + 1
@@ -87,7 +91,26 @@ while time.time() < t_end:
     n = int(rng.choice([1, 1, 2, 3, 5, 8]))
     k = float(rng.choice([0.34, 0.2, -0.2, 0.01, -0.1, 0.5, 0.0])) if rng.random() < 0.8 else float(rng.normal(0, 0.4))
     morph = int(rng.choice([0, 0, 0, 1, 2, -1, -2, 3]))
-    pages = np.stack([page(h, w, int(rng.integers(0, 6)), i) for i in range(n)])
+    pages = None
+    if a.adversarial > 0 and rng.random() < a.adversarial and win % 2 == 1 and win >= 5:
+        import bench
+        method = int(rng.choice([m for m in METHODS if m in (0, 1, 3)] or [0]))
+        adv = bench.adversarial_stripes(method, win, k, None)
+        if adv is not None and adv[2] < 5e-3:
+            lv_a, lv_b, _ = adv
+            h, w, n = int(rng.integers(1400, 2400)), int(rng.integers(1600, 2600)), int(rng.choice([1, 2, 3]))
+            base = np.where((np.arange(w) + int(rng.integers(0, 2))) % 2 == 0, lv_a, lv_b).astype(np.uint8)[None, :].repeat(h, 0)
+            pgs = []
+            for i in range(n):
+                pg = base.copy()
+                if rng.random() < 0.5:   # an island of other content
+                    y0, x0 = int(rng.integers(0, h - 200)), int(rng.integers(0, w - 300))
+                    pg[y0:y0 + 200, x0:x0 + 300] = page(200, 300, int(rng.integers(0, 6)), i)
+                pgs.append(pg)
+            pages = np.stack(pgs)
+            stats["adversarial_calls"] += 1
+    if pages is None:
+        pages = np.stack([page(h, w, int(rng.integers(0, 6)), i) for i in range(n)])
     mode = 1 if rng.random() < 0.05 else 0
     p = prlib_amd.make_params(method, win, k, morph)
     if mode:
@@ -99,6 +122,7 @@ while time.time() < t_end:
             prlib_amd.set_exec_mode(0)
     st = prlib_amd.last_stats()
     stats["refined"] += int(st.refined_pixels); stats["exact"] += int(st.exact_pixels); stats["literal_pages"] += int(st.literal_pages)
+    stats["exact_sweep_pages"] += int(st.exact_sweep_pages)
     po = oc.make_params(method, win, k, morph)
     bad = sum(int((got[i] != oc.binarize(pages[i], po)).sum()) for i in range(n))
     calls += 1

@@ -194,7 +194,11 @@ def main():
     if "--fingerprint" in sys.argv:   # python tools/isa_budget.py --fingerprint [file.s] : the frozen row loops' opcode order, hashed
         i = sys.argv.index("--fingerprint")
         asm = sys.argv[i + 1] if len(sys.argv) > i + 1 else compile_asm("/tmp/prl_fused_isa.s")
-        print(json.dumps(hot_loop_fingerprints(asm), indent=1, sort_keys=True))
+        import hashlib
+        fp = hot_loop_fingerprints(asm)
+        ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout
+        fp["_compiler"] = {"hipcc_version_sha1": hashlib.sha1(ver.encode()).hexdigest(), "first_lines": ver.strip().splitlines()[:2]}
+        print(json.dumps(fp, indent=1, sort_keys=True))
         return
     if "--mix" in sys.argv:   # python tools/isa_budget.py --mix nlm : the NL-means kernels' inner-loop mix (tools/bench_denoise.py reads it)
         which = sys.argv[sys.argv.index("--mix") + 1]
