@@ -1051,7 +1051,7 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     PphtGroupIn gin;
     const int grp_env = env_knobs().ppht_group;
     bool group_ran = false;
-    if (grp_env != 0 && ppht_group_eligible(width, height, threshold)) {
+    if (grp_env != 0 && !(start && start->prefer_mw && grp_env < 0) && ppht_group_eligible(width, height, threshold)) {
         gin.n_pages = n_pages; gin.width = width; gin.height = height; gin.threshold = threshold; gin.line_length = line_length;
         gin.line_gap = line_gap; gin.d_mask = d_mask; gin.mask_page = mask_page; gin.d_nz = d_nz; gin.d_nzoff = d_nzoff; gin.d_count = d_count;
         gin.d_ttab = d_ttab; gin.h_ttab = h_ttab; gin.d_lines = d_lines; gin.d_lnoff = d_lnoff; gin.d_cap = d_cap; gin.d_nlines = d_nlines;

@@ -478,9 +478,32 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
         void join() { if (th.joinable()) th.join(); }
         ~Finder() { join(); if (start.ev) (void)hipEventDestroy(start.ev); }
     } finder;
-    auto start_find = [&](int first, int cnt) {
+    // Which kernel searches a pass (round 6).  The group kernel (accumulator in LDS) is 3 to 5 times faster than k_ppht_mw but fills the
+    // LDS of every CU it runs on: beside this chain's NL-means it does not hide, it takes turns with it.  k_ppht_mw lives on memory-side
+    // atomics and does hide behind NL-means - when it is clearly shorter than the body it runs beside.  Measured on 1024 synthetic A4
+    // text scans (profiles/r06/chain_1024_schedules.txt): group kernel for every pass, the pass size following the controller down
+    // to 64 pages (the tails of search and body interleave) 6.14 s; group kernel, passes of 192-208 pages 6.40 s; k_ppht_mw for the
+    // passes whose estimate fits the body (alternating with the group kernel) 6.54 s - its 192-page search takes 1.3 s beside NL-means,
+    // not the 0.9 s it takes alone; round 5 (k_ppht_mw throughout) 6.16 s.  So k_ppht_mw is preferred only where its estimate is
+    // HALF the body's (pages with few points): costs as measured, k_ppht_mw max(5.5 ns per point of the pass, 0.6 us per point of its
+    // heaviest page), NL-means 4.35 ms per 3508 x 3508 x 3 page.
+    auto search_prefers_mw = [&](int first, int cnt, int beside_cnt) -> bool {
+        if (!cp->denoise || env_knobs().chain_overlap != 2 || beside_cnt <= 0 || ink.empty()) return false;
+        double sum = 0.0, heaviest = 0.0;
+        for (int i = first; i < first + cnt; ++i) {
+            sum += ink[(size_t)i];
+            heaviest = std::max(heaviest, (double)ink[(size_t)i]);
+        }
+        const double est_mw = std::max(sum * 5.5e-9, heaviest * 0.6e-6);
+        const double est_nlm = 4.35e-3 * beside_cnt * ((double)len * len) / (3508.0 * 3508.0);
+        return est_mw <= 0.5 * est_nlm;
+    };
+    auto start_find = [&](int first, int cnt, int beside_cnt = 0) {
         finder.st = PRL_OK;
         finder.start.reset();
+        finder.start.prefer_mw = search_prefers_mw(first, cnt, beside_cnt);
+        if (env_knobs().debug)
+            std::fprintf(stderr, "[prl chain] search of pages %d..%d: %s\n", first, first + cnt - 1, finder.start.prefer_mw ? "k_ppht_mw (hides behind NL-means)" : "group kernel");
         finder.th = std::thread([&, first, cnt] {
             struct Done { Finder* f; std::chrono::steady_clock::time_point t; ~Done() { f->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); f->start.finish(); } } done{&finder, std::chrono::steady_clock::now()};
             if (hipSetDevice(dev) != hipSuccess) { finder.st = PRL_ERR_NO_DEVICE; return; }
@@ -606,7 +629,7 @@ int prl_hip_chain_pages_device(const prl_chain_params* cp, int n_pages, int chan
             if (beside) {
                 PRL_HIP_CHECK(hipStreamSynchronize(hs));   // the head is through before the next search takes the memory system
                 ncnt = next_count(nfirst);
-                start_find(nfirst, ncnt);
+                start_find(nfirst, ncnt, cnt);
                 st = behind_search_start();
                 if (st != PRL_OK) return st;
             }

@@ -284,6 +284,7 @@ struct DeskewPlan {                   // what the angle search of a pass hands t
 // ended without getting there (finish() is called by whoever ran deskew_find).
 struct SearchStart {
     hipEvent_t ev = nullptr;
+    bool prefer_mw = false;   // this search runs beside compute-bound work that needs the CUs (the chain's NL-means) and would hide behind it: take k_ppht_mw (accumulators in device memory, no LDS) instead of the group kernel
     std::mutex mu;
     std::condition_variable cv;
     bool recorded = false, done = false;

@@ -23,7 +23,7 @@ import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'lib': '$lib'
   done
 done > $OUT/morph_fast_path_ab.jsonl 2>&1
 # 6. kernel trace of one deskew call of 64 text pages
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o deskew64 -- python3 tools/dbg/ppht_group_prof.py 64 > $OUT/trace.log 2>&1
+PRL_HIP_PPHT_PROF= timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/dbg/ppht_group_prof.py 64 > $OUT/trace.log 2>&1
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/deskew64_kernel_stats.csv \;
 rm -rf $OUT/trace
 echo done
