@@ -536,15 +536,6 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
         rag1 = s1 && !full1;
     };
     classify(A);
-    // Interior strips (every strip but a row's first and last, when the destination rows keep their alignment): lanes 2 .. 63 store
-    // their first chunk whole, lanes 0 .. 62 their second, nothing is ragged - known once per wavefront, so the row loop stores
-    // through two fixed lane masks instead of classifying every half row (the exec-mask bookkeeping of the general path was 0.4 of
-    // the kernel's issue cycles: docs/history.md 9).
-#ifndef PRL_MORPH_NO_FAST   // (A/B builds: tools/ab)
-    const bool all_full = fixed_a && __ballot(full0) == ~3ull && __ballot(full1) == ~(1ull << 63) && __ballot(rag0 || rag1) == 0ull;
-#else
-    const bool all_full = false;
-#endif
 
     unsigned ring1[K], ring2[K];
 #pragma unroll
@@ -617,15 +608,6 @@ __global__ void __launch_bounds__(256) k_morph_bits(PageSet src, PageSetOut dst,
         unsigned oprev, onext;
         neighbours(o, lane, &oprev, &onext);
         const unsigned bits = shift_up(o, oprev, A);
-        if (all_full) {   // wave-uniform
-            typedef unsigned u4v __attribute__((ext_vector_type(4)));
-            const int px0 = base_px + 16 * lane - (int)A;
-            const uint4 d0 = unpack16(bits & 0xffffu), d1 = unpack16(bits >> 16);
-            const u4v v0 = {d0.x, d0.y, d0.z, d0.w}, v1 = {d1.x, d1.y, d1.z, d1.w};
-            if (lane >= 2) __builtin_nontemporal_store(v0, reinterpret_cast<u4v*>((uint8_t*)(orow + px0)));
-            if (lane <= 62) __builtin_nontemporal_store(v1, reinterpret_cast<u4v*>((uint8_t*)(orow + px0 + 1024)));
-            continue;
-        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const bool full = half ? full1 : full0, ragged = half ? rag1 : rag0;

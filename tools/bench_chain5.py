@@ -41,12 +41,15 @@ ap.add_argument("--window", type=int, default=31)
 ap.add_argument("--strength", type=float, default=10.0)
 ap.add_argument("--stages", type=int, default=1, help="also time the stages one by one on the first --stage-pages pages")
 ap.add_argument("--stage-pages", type=int, default=64)
+ap.add_argument("--hooks", type=int, default=0, help="1: libprlib_hip_testhooks.so (reads the PRL_HIP_* knobs, e.g. PRL_HIP_CHAIN_PASS)")
 ap.add_argument("--repeat", type=int, default=1, help="run the one-call chain this many times (the first call allocates the workspaces)")
 ap.add_argument("--host", type=int, default=0, help="also time prl_hip_chain_batch_host on the same pages in host memory (end to end)")
 ap.add_argument("--check-pages", type=int, default=0, help="pages compared with the composed CPU oracle (slow: NL-means on the host)")
 ap.add_argument("--cpu-pages", type=int, default=-1, help="pages of the CPU baseline leg: the composed oracle chain on that many of the same pages, "
                 "run side by side on all host cores (-1: one page per 32 cores, at least 2; 0: skip)")
 a = ap.parse_args()
+if a.hooks:
+    prlib_amd._capi.use_library(prlib_amd._capi.HOOKS_LIB_PATH)
 world, rank, local_rank = pdist.init()
 if world != a.gpus:
     raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
