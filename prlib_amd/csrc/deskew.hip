@@ -1083,7 +1083,6 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
     }
     if (start) start->launched();
     std::vector<unsigned> h_nl((size_t)n_pages);
-    std::vector<int> h_lines((size_t)ln_total * 4 + 4);
     std::vector<int> redo;
     if (group_ran) {
         PRL_HIP_CHECK(hipStreamSynchronize(stream));
@@ -1102,7 +1101,7 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
             for (int i = 0; i < std::min(n_pages, 4); ++i) {
                 const int pg = by_time[(size_t)i];
                 const unsigned long long* q = h_gprof.data() + (size_t)pg * 16;
-                std::fprintf(stderr, "%s{\"page\": %d, \"points\": %u, \"exchanges\": %llu, \"blocks\": %llu, \"triggers\": %llu, \"good_lines\": %llu, \"walk_rounds\": %llu, \"cyc\": {\"fetch\": %llu, \"vote\": %llu, \"exchange\": %llu, \"rollback\": %llu, \"walk1\": %llu, \"walk2\": %llu, \"strike\": %llu, \"w1_load\": %llu, \"w1_bar1\": %llu, \"w1_run_bar2\": %llu, \"w1_eval\": %llu}}",
+                std::fprintf(stderr, "%s{\"page\": %d, \"points\": %u, \"exchanges\": %llu, \"blocks\": %llu, \"triggers\": %llu, \"good_lines\": %llu, \"walk_rounds\": %llu, \"cyc\": {\"fetch\": %llu, \"vote\": %llu, \"collect\": %llu, \"post\": %llu, \"walk\": %llu, \"erase\": %llu, \"strike\": %llu}, \"polls\": %llu, \"prefetched_polls\": %llu, \"collect_poll_cyc\": %llu, \"collect_barrier_cyc\": %llu}",
                              i ? ", " : "", pg, h_count[(size_t)pg], q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11], q[12], q[13], q[14], q[15]);
             }
             std::fprintf(stderr, "], \"all_pages_points_triggers_mcycles\": [");
@@ -1152,8 +1151,17 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
         else hipLaunchKernelGGL(k_ppht, dim3((unsigned)n_redo), dim3(64), 0, stream, a);
         PRL_HIP_CHECK(hipGetLastError());
     }
+    // The segments: first how many each page has, then those and no more (the lists' capacity is a loose bound - a segment per
+    // line_length / (line_gap + 1) points: 0.9 GB for 256 of the reference's scans, of which 7 MB hold segments).
     PRL_HIP_CHECK(hipMemcpyAsync(h_nl.data(), d_nlines, (size_t)n_pages * 4, hipMemcpyDeviceToHost, stream));
-    PRL_HIP_CHECK(hipMemcpyAsync(h_lines.data(), d_lines, (size_t)ln_total * 16, hipMemcpyDeviceToHost, stream));
+    PRL_HIP_CHECK(hipStreamSynchronize(stream));
+    lines_out->assign((size_t)n_pages, {});
+    for (int i = 0; i < n_pages; ++i) {
+        const size_t have = std::min<size_t>(h_nl[(size_t)i], h_cap[(size_t)i]);
+        (*lines_out)[(size_t)i].resize(have * 4);
+        if (have)
+            PRL_HIP_CHECK(hipMemcpyAsync((*lines_out)[(size_t)i].data(), d_lines + h_lnoff[(size_t)i] * 4, have * 16, hipMemcpyDeviceToHost, stream));
+    }
     PRL_HIP_CHECK(hipStreamSynchronize(stream));
 #ifdef PRL_TEST_HOOKS
     if (d_prof) {   // one JSON line per call on stderr: the three heaviest pages and the sum, cycles per phase and event counts
@@ -1189,14 +1197,11 @@ static int ppht_pages(DeviceCtx* ctx, int n_pages, const PageSet& gray, int widt
             ds.max_page_points = std::max<uint64_t>(ds.max_page_points, h_count[(size_t)i]);
         }
     }
-    lines_out->assign((size_t)n_pages, {});
     for (int i = 0; i < n_pages; ++i) {
         if (h_nl[(size_t)i] > h_cap[(size_t)i]) {
             set_error_detail("HoughLinesP: segment list overflow");
             return PRL_ERR_NOMEM;
         }
-        const int* p = h_lines.data() + h_lnoff[(size_t)i] * 4;
-        (*lines_out)[(size_t)i].assign(p, p + (size_t)h_nl[(size_t)i] * 4);
     }
     return PRL_OK;
 }

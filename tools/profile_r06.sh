@@ -22,8 +22,8 @@ import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'lib': '$lib'
 import json,sys; d=json.loads(sys.stdin.read()); print(json.dumps({'lib': '$lib', 'workload': d['config']['workload'], 'ms_per_step': d['ms_per_step'], 'call_ms': d['roofline']['call_ms'], 'kernel_ms': d['roofline']['kernel_ms']}))"
   done
 done > $OUT/morph_fast_path_ab.jsonl 2>&1
-# 6. kernel trace of one deskew call of 64 text pages
-PRL_HIP_PPHT_PROF= timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/dbg/ppht_group_prof.py 64 > $OUT/trace.log 2>&1
-find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/deskew64_kernel_stats.csv \;
-rm -rf $OUT/trace
+
+
+
+
 echo done
