@@ -876,3 +876,19 @@ def test_queue_overflow_takes_the_exact_sweep_not_the_literal_pipeline(prl, orac
         assert st.exact_sweep_pages == 1 and st.literal_pages == 0
     finally:
         prl.set_literal_page_budget(-1)
+
+
+def test_on_threshold_patch_that_fills_a_queue_bucket_does_not_take_the_literal_pipeline(prl, oracle, cuda_device):
+    """A flat patch of 100 x 160 pixels whose level sits on its own threshold (to ~1e-13), inside one strip of an ordinary page:
+    the wavefronts that own it queue more than the 8192 entries of a refine-queue bucket, so the page is flagged (bit 0) - until
+    round 5 that meant the literal pipeline for the whole page.  Now the exact sweep redoes the page, its interval test leaves the
+    patch's pixels open (true ties), they go to the fix-up list (10^4 entries of 2^17) and the literal sequence decides them:
+    no literal page.  Beside an ordinary page, with and without morphology."""
+    w, c = 15, 200
+    k = _flat_boundary_k(c, w, c)
+    h, wd = 1500, 1800
+    doc, other = _pages((h, wd), ["doc", "doc"], seed=141)
+    doc[600:700 + w, 520:680 + w] = c     # (window-sized margin: 100 x 160 output pixels see nothing but the patch)
+    for morph in (0, 2):
+        st = _check(prl, oracle, cuda_device, [other, doc], SAUVOLA, w, k, morph)
+        assert st.literal_pages == 0 and st.exact_pixels >= 100 * 160, (st.literal_pages, st.exact_sweep_pages, st.exact_pixels)
