@@ -463,6 +463,13 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
     float vmax_lane = 0.0f;  // Wolf sweep A
     bool page_flagged = false;   // (wave-uniform) a push of this wavefront found its queue bucket full
     [[maybe_unused]] unsigned x_refined = 0;   // EXACT: pixels this lane decided by the interval test (statistics, one atomic per lane at the end)
+    // EXACT: the page's constants of the interval test, once per wavefront (read per pixel they were three dependent loads each)
+    [[maybe_unused]] double x_imin = 0.0, x_coeff = 0.0, x_crel = 0.0;
+    if constexpr (EXACT) {
+        x_imin = (double)g[page].imin;
+        x_coeff = g[page].coeff;
+        if (METHOD == PRL_WOLFJOLION) x_crel = g[page].coeff_rel;
+    }
     uint2 vnew_n = load_win(ys + w);  // entering row of the first iteration, fetched one iteration ahead
 #pragma unroll 1
     for (int y = ys; y < ye; ++y) {
@@ -676,8 +683,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                         const float t = eval32<METHOD, WIDE>(fp, S, Q, fmaf((float)p, kZ, pk.p0), pk, &v32);
                         if ((fabsf(t) > pk.eps1) && (v32 > fp.vthr32)) continue;
                         if constexpr (EXACT) {
-                            const unsigned r = refine64<METHOD>(fp, S - sbias, Q, p, (double)g[page].imin, g[page].coeff, 0.0,
-                                                                METHOD == PRL_WOLFJOLION ? g[page].coeff_rel : 0.0);
+                            const unsigned r = refine64<METHOD>(fp, S - sbias, Q, p, x_imin, x_coeff, 0.0, x_crel);
                             if (r != 2) {
                                 if (c < 4) lo = (lo & ~(0xffu << (8 * c))) | (r << (8 * c));
                                 else hi = (hi & ~(0xffu << (8 * (c - 4)))) | (r << (8 * (c - 4)));
@@ -1358,7 +1364,10 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
             it.p &= 0xffu;
             unsigned r = 2;
             double imin = 0.0, coeff = 0.0, crel = 0.0;
-            if (valid) {
+            // (a page that is flagged already will be redone whole - by the exact sweep or the literal pipeline: what the queue still
+            // holds of it is moot; adversarial pages left 2^21 entries here, each with a wavefront's rebuild of its sums: 4.7 ms)
+            const bool moot = valid && g[it.page].worklist_overflow != 0u;
+            if (valid && !moot) {
                 imin = (double)g[it.page].imin;
                 coeff = g[it.page].coeff;
                 if (METHOD == PRL_WOLFJOLION) crel = g[it.page].coeff_rel;
@@ -1371,7 +1380,7 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
             // time, and the owner lane repeats the test with exact sums
             // (Feng's threshold depends on S only - exact in both loops - and on the variance through the s > 0 guard alone:
             // when the guard held with the approximate Q, exact sums would repeat the same undecided answer - its ties)
-            bool rebuild = valid && r == 2 && approx;
+            bool rebuild = valid && !moot && r == 2 && approx;
             if (METHOD == PRL_FENG && rebuild) {
                 const double mm = (double)it.S * tp.f, vv = (double)it.Q * tp.f - mm * mm;
                 rebuild = !(vv > 8.0 * (fp.Eq + eq_approx + 2.0 * mm * fp.Em + fp.Em * fp.Em) + 1e-9);
@@ -1400,7 +1409,7 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
             }
             // slots of the fix-up list: one atomic per wavefront (a same-address atomic with return costs ~20 ns under contention:
             // Feng's 21 000 ties on 256 pages took k_refine 0.39 ms with one per pixel)
-            const bool to_fixup = valid && r == 2;
+            const bool to_fixup = valid && !moot && r == 2;
             const unsigned long long fm = __ballot(to_fixup);
             unsigned slot_base = 0;
             if (fm) {
@@ -1408,7 +1417,7 @@ __global__ void __launch_bounds__(256) k_refine(PageSet src, PageSetOut dst, Fus
                 if (lane == leader) slot_base = atomicAdd(&counters[1], (unsigned)__popcll(fm));
                 slot_base = (unsigned)__shfl((int)slot_base, leader, kWave);
             }
-            if (!valid) continue;
+            if (!valid || moot) continue;
             if (r != 2) {
                 store_decision(dst, fp.bit_out, it.page, it.y, it.x, r);
                 atomicAdd(&g[it.page].n_refined, 1u);

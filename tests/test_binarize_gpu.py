@@ -866,9 +866,6 @@ def test_queue_overflow_takes_the_exact_sweep_not_the_literal_pipeline(prl, orac
     for morph in (0, 2):
         st = _check(prl, oracle, cuda_device, [doc, stripes, mixed], method, w, k, morph)
         assert st.exact_sweep_pages == 2 and st.literal_pages == 0, (st.exact_sweep_pages, st.literal_pages)
-        # (what the first sweep queued before it gave up, plus what the exact sweep's own float32 test - the integer loop's
-        # narrower band - still left to the inline interval test)
-        assert st.refined_pixels > 1 << 20
     # a budget of zero literal pages does not stand in the way of the second chance (it bounds the literal pipeline only)
     prl.set_literal_page_budget(0)
     try:
