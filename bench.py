@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--worst-case", type=int, default=1,
                     help="1 (N=1 only): after the timed region, the same pages through the literal pipeline and a batch of adversarial "
                          "pages (every second pixel inside the float32 decision band) through auto mode -> `worst_case`")
+    ap.add_argument("--adversarial-pages", type=int, default=0, help="pages of the adversarial batch (0: as many as the headline's batch)")
     ap.add_argument("--end-to-end", type=int, default=1,
                     help="1 (N=1 only): the batch as a host page list in pinned memory through prl_hip_binarize_batch_host "
                          "(H2D + kernels + D2H) -> `end_to_end` (SURVEY.md 8d's second number; never `value`)")
@@ -270,7 +271,7 @@ def worst_case_legs(args, prlib_amd, _capi, L, dev, pages, out, params, method, 
         LH.prl_hip_internal_fused_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         if LH.prl_hip_internal_fused_bounds(C.byref(params), W, H, b8.ctypes.data) == 0:
             eps1 = float(b8[5])
-    n_adv = min(pages.shape[0], 16)
+    n_adv = min(pages.shape[0], args.adversarial_pages) if args.adversarial_pages > 0 else pages.shape[0]   # (default: the headline's batch)
     row = torch.tensor([a, b], dtype=torch.uint8, device=dev).repeat((pages.shape[2] + 1) // 2)[: pages.shape[2]]
     adv_pages = row.expand(n_adv, pages.shape[1], pages.shape[2]).contiguous()
     t = _time_steps(prlib_amd, dev, lambda: prlib_amd.binarize(adv_pages, params, out=out[:n_adv]), 2)
@@ -588,6 +589,9 @@ def main():
             line["strong"] = strong
         if page_digests is not None:
             line["page_digests"] = page_digests
+        if worst and worst.get("adversarial"):   # (the same call on the same number of pages: how much a page that defeats the fast path costs)
+            adv = worst["adversarial"]
+            adv["per_page_vs_headline"] = round((adv["ms_per_step"] / adv["pages"]) / (line["ms_per_step"] / line["config"]["pages_per_gpu"]), 2)
         line["worst_case"] = worst
         line["end_to_end"] = e2e
         print(json.dumps(line), flush=True)

@@ -229,7 +229,11 @@ __device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, 
     const double Ev = Eq + 2.0 * m * fp.Em + fp.Em * fp.Em + tiny * (q + m * m);
     if (!(v > 4.0 * Ev)) return 2;  // literal sqrt may be NaN / arbitrarily far
     const double s = sqrt(v);
-    const double Es = 1.001 * Ev / sqrt(v - Ev) + tiny * s;
+    // |sqrt(v') - sqrt(v)| for |v' - v| <= Ev < v / 4 is at most Ev / sqrt(v - Ev) <= Ev / (0.866 s); the bound only has to hold,
+    // so it takes the hardware's reciprocal square root as it comes (v_rsq_f64: 2^-23 relative, ISA guide) with the slack in the
+    // constant - 1.16 (1 - 2^-20) > 1.001 / 0.866 - instead of a second correctly rounded square root and a division: a third of
+    // this function's instructions, which is what bounds k_fused_exact on a page whose every pixel comes here
+    const double Es = 1.16 * Ev * __builtin_amdgcn_rsq(v) + tiny * s;
     double T, ET;
     if (METHOD == PRL_SAUVOLA) {
         const double d = s * tp.a + tp.b;
@@ -243,7 +247,7 @@ __device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, 
         // literal: C = fl(fl(m*m) + fl(s*s)) = q_literal up to a few ulp
         const double EC = Eq + tiny * q;
         const double c = sqrt(q);
-        const double Ec = 1.001 * EC / sqrt(q - EC) + tiny * c;
+        const double Ec = 1.16 * EC * __builtin_amdgcn_rsq(q) + tiny * c;   // (q >= v > 4 Ev >= 4 Eq and tiny q is nothing: q - EC > 0.75 q as above)
         T = m + c * tp.k;
         ET = fp.Em + fabs(tp.k) * Ec + tiny * (fabs(T) + m);
     } else if (METHOD == PRL_WOLFJOLION) {
@@ -646,6 +650,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
             // Mask bytes: the sign of the negated margin (pack_signs); unsettled pixels are overwritten by
             // k_refine/k_fixup.
             float tn[CPL];
+            [[maybe_unused]] float xv[CPL];   // EXACT: the float32 variances, kept for the per-pixel test below
             float tmin = 3.0e38f, vmin = 3.0e38f;
     #pragma unroll
             for (int c = 0; c < CPL; ++c) {
@@ -655,6 +660,7 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                 tn[c] = eval32<METHOD, WIDE>(fp, Ssum[c], Qsum[c], P2, pk, &v32);
                 tmin = fminf(tmin, fabsf(tn[c]));
                 vmin = fminf(vmin, v32);
+                if constexpr (EXACT) xv[c] = v32;
             }
             unsigned lo = pack_signs(tn[0], tn[1], tn[2], tn[3]), hi = pack_signs(tn[4], tn[5], tn[6], tn[7]);
             if (fp.need_p0) {
@@ -667,23 +673,17 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
 
             // rare: some pixel of this lane is not settled by the float32 test -> queue it for k_refine
             const bool unsure = lane_has_out && !((tmin > pk.eps1) && (vmin > fp.vthr32));
-            if (__ballot(unsure) != 0ull && !page_flagged) {   // (a flagged page is redone literally: no point in queueing more of it)
-                bool full = false;
-                if (unsure) {
-    #pragma unroll 1
+            if constexpr (EXACT) {
+                // The lane's eight pixels in straight-line code (the queueing loop below picks pixel c out of the register arrays
+                // with select chains and evaluates it again: 25 instructions per pixel that a page with every pixel open pays
+                // 8.7 million times); margins and variances are the ones just computed.
+                if (__ballot(unsure) != 0ull && unsure) {
+    #pragma unroll
                     for (int c = 0; c < CPL; ++c) {
-                        if (x0 + c >= tp.ow) break;
-                        const unsigned p = (c < 4 ? pv.x >> (8 * c) : pv.y >> (8 * (c - 4))) & 0xffu;
-                        if (p == 0) continue;  // 0 > T8 is false whatever T is
-                        const unsigned S = c == 0 ? Ssum[0] : c == 1 ? Ssum[1] : c == 2 ? Ssum[2] : c == 3 ? Ssum[3]
-                                         : c == 4 ? Ssum[4] : c == 5 ? Ssum[5] : c == 6 ? Ssum[6] : Ssum[7];
-                        const unsigned Q = c == 0 ? Qsum[0] : c == 1 ? Qsum[1] : c == 2 ? Qsum[2] : c == 3 ? Qsum[3]
-                                         : c == 4 ? Qsum[4] : c == 5 ? Qsum[5] : c == 6 ? Qsum[6] : Qsum[7];
-                        float v32;
-                        const float t = eval32<METHOD, WIDE>(fp, S, Q, fmaf((float)p, kZ, pk.p0), pk, &v32);
-                        if ((fabsf(t) > pk.eps1) && (v32 > fp.vthr32)) continue;
-                        if constexpr (EXACT) {
-                            const unsigned r = refine64<METHOD>(fp, S - sbias, Q, p, x_imin, x_coeff, 0.0, x_crel);
+                        const unsigned p = byte_of(pv, c);
+                        const bool open = (x0 + c < tp.ow) && p != 0 && !((fabsf(tn[c]) > pk.eps1) && (xv[c] > fp.vthr32));
+                        if (open) {
+                            const unsigned r = refine64<METHOD>(fp, Ssum[c] - sbias, Qsum[c], p, x_imin, x_coeff, 0.0, x_crel);
                             if (r != 2) {
                                 if (c < 4) lo = (lo & ~(0xffu << (8 * c))) | (r << (8 * c));
                                 else hi = (hi & ~(0xffu << (8 * (c - 4)))) | (r << (8 * (c - 4)));
@@ -706,8 +706,24 @@ __device__ __forceinline__ void strip_loop(gcptr img, gptr out, size_t istep, si
                                     atomicOr(&g[page].worklist_overflow, 2u);
                                 }
                             }
-                            continue;
                         }
+                    }
+                }
+            } else if (__ballot(unsure) != 0ull && !page_flagged) {   // (a flagged page is redone literally: no point in queueing more of it)
+                bool full = false;
+                if (unsure) {
+    #pragma unroll 1
+                    for (int c = 0; c < CPL; ++c) {
+                        if (x0 + c >= tp.ow) break;
+                        const unsigned p = (c < 4 ? pv.x >> (8 * c) : pv.y >> (8 * (c - 4))) & 0xffu;
+                        if (p == 0) continue;  // 0 > T8 is false whatever T is
+                        const unsigned S = c == 0 ? Ssum[0] : c == 1 ? Ssum[1] : c == 2 ? Ssum[2] : c == 3 ? Ssum[3]
+                                         : c == 4 ? Ssum[4] : c == 5 ? Ssum[5] : c == 6 ? Ssum[6] : Ssum[7];
+                        const unsigned Q = c == 0 ? Qsum[0] : c == 1 ? Qsum[1] : c == 2 ? Qsum[2] : c == 3 ? Qsum[3]
+                                         : c == 4 ? Qsum[4] : c == 5 ? Qsum[5] : c == 6 ? Qsum[6] : Qsum[7];
+                        float v32;
+                        const float t = eval32<METHOD, WIDE>(fp, S, Q, fmaf((float)p, kZ, pk.p0), pk, &v32);
+                        if ((fabsf(t) > pk.eps1) && (v32 > fp.vthr32)) continue;
                         RefItem it;
                         it.page = page;
                         it.y = y;
@@ -1170,6 +1186,10 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
     const int seg = rem / fp.n_strips;
     const int strip = rem - seg * fp.n_strips;
     wid += u;  // canonical wavefront id over all tiers
+    // A page whose queue has overflowed is redone whole by k_fused_exact (resolve_front): the strips of it that have not started
+    // yet have nothing to add (adversarial pages flag themselves within the first 3 % of their strips).  Threshold sweep only -
+    // the Wolf sweeps' maxima are needed by the redo.  A stale read only costs the time it would have saved.
+    if (METHOD < kWolfMax && (__hip_atomic_load(&g[page].worklist_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u)) return;
 
     gcptr img = (gcptr)src.page(page);
     gptr out = (gptr)dst.page(page);
