@@ -2,11 +2,14 @@
 (profiles/r03/sched_strategy_ab.txt), and an edit anywhere in binarize_fused.hip - even in the cold queue-push block - moves it
 (tools/experiments/README.md, round 5).  This test compiles the file to gfx950 assembly (hipcc -S, ~1 min, no GPU) and compares the
 opcode order of every threshold instantiation's row loops with the fingerprint of the measured build
-(profiles/r06/k_fused_hot_loops.json = round 4's code, opcode for opcode, plus the identity of the compiler that produced it: another
+(profiles/r06/k_fused_hot_loops.json = round 4's code, opcode for opcode, MINUS one v_readlane_b32 per row loop - see below -, plus the
+identity of the compiler that produced it: another
 hipcc orders instructions differently without any source change, and the test then skips instead of failing).  If it fails after an
 intended change: measure the headline (python bench.py on a GPU box) and refresh the file with
 `python tools/isa_budget.py --fingerprint > profiles/r06/k_fused_hot_loops.json`.  Round 6 added k_fused_exact (its own kernel, its own
-instantiation of the integer loop): the threshold instantiations of k_fused are unchanged.
+instantiation of the integer loop): the threshold instantiations of k_fused were unchanged by that.  Refreshed once, in round 6: the early
+exit of a flagged page's strips (one load in k_fused's prologue) made the register allocator drop the SGPR reload that sat in every row loop
+("cosmetic") and moved nothing else; interleaved A/B on one box: profiles/r06/headline_ab_early_exit.txt, configs_ab_early_exit.txt.
 """
 import hashlib
 import json
