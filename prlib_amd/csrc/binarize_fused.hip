@@ -323,6 +323,7 @@ __device__ f32x4 buf_load_fmt_xyzw(i32x4 rsrc, int voffset, int soffset, int aux
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ void buf_store_x2(i32x2 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
 __device__ i32x2 buf_load_x2(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2i32");
+__device__ void buf_store_u8(unsigned char data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i8");
 #pragma clang diagnostic pop
 
 // Raw buffer resource over the first `limit` bytes of ONE row of an output page (the range check of a raw buffer covers the
@@ -838,12 +839,18 @@ __device__ __forceinline__ float bpermf(int addr, float v)
 // come as packed bytes from a clamped address, are put in place by strip_loop's two v_perm_b32 and converted when the
 // slide uses them (16 conversions a row more than an interior strip, still a quarter fewer vector instructions than the
 // integer loop: 2 of the 9 strips of a 4096-column page, 2 of the 6 of an A4 page); partial stores at the row end.
-template <int METHOD, int SH, int LO, bool FAST, bool EDGE>
+// QINT (k_fused_q, windows wider than 31 - VERDICT r5 "next" 7): pixels, column sums VS / VQ (<= 180 x 65025 < 2^24) and every S
+// quantity (<= 180 x 180 x 255 < 2^24) stay exact in float32; the column sums of squares are converted once per row
+// (v_cvt_u32_f32) and the HORIZONTAL Q sums - in-lane prefixes, the W chain, the window sum, which pass 2^24 - run on integers
+// like strip_loop's.  S and (float)Q reach eval32f with exactly the values the integer loop hands it: same decisions, same
+// margins, exact sums in the queue.  What is saved is the byte unpacking of the two window rows (46 SDWA instructions a row).
+template <int METHOD, int SH, int LO, bool FAST, bool EDGE, bool QINT = false>
 __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, size_t ostep, const FusedParams& fp,
                                              int page, int xs, int ys, int ye, int lane, const PageK& pk, unsigned wid,
                                              PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
                                              unsigned* __restrict__ counters)
 {
+    static_assert(!QINT || LO == 4, "QINT: the wavefront-scan form of the W chain");
     constexpr bool SWEEP_A = METHOD == kWolfMax;  // Wolf-Jolion's variance-maximum sweep: sums and K~ only, no decision
     const ThrParams& tp = fp.tp;
     const int H = tp.height, h = tp.half, w = tp.w;
@@ -864,7 +871,7 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     const EdgeFix ew = EDGE ? make_edge(col0, tp.width) : EdgeFix{0, 0u, 0u};
     const EdgeFix ep = EDGE ? make_edge(x0, tp.width) : EdgeFix{0, 0u, 0u};  // lanes without output fetch a clamped (ignored) location
     // ragged strip whose last lane keeps 4 bytes: range-clipped buffer stores instead of a divergent partial store (wave-uniform)
-    const bool clip4 = !FAST && !EDGE && !fp.bit_out && fp.nt_store && (fp.uo & 7) == 4;
+    const bool clip4 = !QINT && !FAST && !EDGE && !fp.bit_out && fp.nt_store && (fp.uo & 7) == 4;   // (QINT: uo is a multiple of 8)
     unsigned long long orow = (unsigned long long)(uint8_t*)out + (unsigned long long)ys * ostep;   // row y of the output page (clip4)
     auto to_f8 = [](uint2 b) -> F8 {
         F8 r;
@@ -886,8 +893,16 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     };
 
     float VS[CPL], VQ[CPL];
+    // QINT: the column sums of squares live as 2^23 + VQ (exact below 2^24: w - 1 <= 128), whose bit pattern is the integer
+    // 0x4B000000 + VQ - no conversion instruction; every horizontal Q sum then carries a known multiple of 0x4B000000, and a window
+    // sum exactly (w - 1) of them (mod 2^32), taken off once per row (qbias)
+    constexpr float kVQ0 = QINT ? 8388608.0f : 0.0f;
+    [[maybe_unused]] const unsigned qbias = (unsigned)(w - 1) * 0x4B000000u;
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) VS[c] = VQ[c] = 0.0f;
+    for (int c = 0; c < CPL; ++c) {
+        VS[c] = 0.0f;
+        VQ[c] = kVQ0;
+    }
     float pmin = 255.0f, vmax_lane = 0.0f;  // sweep A: running page minimum (see strip_loop) and variance maximum
     auto track_min = [&](const F8& v) {
         if (!SWEEP_A) return;
@@ -953,6 +968,16 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             tot_s = accs;
             tot_q = accq;
         }
+        [[maybe_unused]] unsigned EQi[CPL], Qi[CPL], tot_qi = 0u, w0qi = 0u, w1qi = 0u;
+        if constexpr (QINT) {
+            unsigned acc = 0u;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                EQi[c] = acc;
+                acc += __float_as_uint(VQ[c]);
+            }
+            tot_qi = acc;
+        }
         float w0s = 0.0f, w0q = 0.0f, w1s = tot_s, w1q = tot_q;
 #define PRL_W_STEP()                      \
     do {                                  \
@@ -965,6 +990,27 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             if (LO >= 1) PRL_W_STEP();  // w - 1 <= 30: at most 3 steps
             if (LO >= 2) PRL_W_STEP();
             if (LO >= 3) PRL_W_STEP();
+        } else if constexpr (QINT) {
+            // strip_loop's form: one wavefront scan of the lane totals (DPP), W = the difference of its values at the two lanes -
+            // 4 ds_bpermute and no wave-uniform branches, where the doubling form below takes 10 and five branches on loff (this
+            // loop has a decision behind it: its LDS pipe is not idle).  S: a scan value is at most 64 lanes x 8 columns x 128 rows
+            // x 255 < 2^24 - exact.
+            auto scan_f = [](float v) -> float {
+                int x = __float_as_int(v);
+                x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false)));
+                x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false)));
+                x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false)));
+                x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false)));
+                x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false)));
+                x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false)));
+                return __int_as_float(x);
+            };
+            const float ps = scan_f(tot_s) - tot_s;
+            const unsigned pq = wave_scan_incl(tot_qi) - tot_qi, pqb = pq + qbias;
+            w0s = bpermf(far_addr0, ps) - ps;
+            w1s = bpermf(far_addr1, ps) - ps;
+            w0qi = (unsigned)__builtin_amdgcn_ds_bpermute(far_addr0, (int)pq) - pqb;
+            w1qi = (unsigned)__builtin_amdgcn_ds_bpermute(far_addr1, (int)pq) - pqb;
         } else {
             // W over `loff` (5..16) lanes starting at this one: sums of 2, 4, 8 (16) consecutive lanes by doubling - the
             // operand of lane + 2^k comes through ds_bpermute (the LDS pipe has room, the vector ALU has not) - then the
@@ -1007,12 +1053,24 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
 #undef PRL_W_STEP
 #pragma unroll
         for (int c = 0; c < CPL; ++c) Ssum[c] = bpermf((c + SH) >= 8 ? far_addr1 : far_addr0, ES[(c + SH) & 7]);
+        if constexpr (QINT) {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) Qi[c] = (unsigned)__builtin_amdgcn_ds_bpermute((c + SH) >= 8 ? far_addr1 : far_addr0, (int)EQi[(c + SH) & 7]);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) Ssum[c] = (Ssum[c] - ES[c]) + ((c + SH) >= 8 ? w1s : w0s);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                Qi[c] = (Qi[c] - EQi[c]) + ((c + SH) >= 8 ? w1qi : w0qi);
+                Qsum[c] = (float)Qi[c];   // (the integer loop's conversion: the same rounding above 2^24)
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < CPL; ++c) Qsum[c] = bpermf((c + SH) >= 8 ? far_addr1 : far_addr0, EQ[(c + SH) & 7]);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) Ssum[c] = (Ssum[c] - ES[c]) + ((c + SH) >= 8 ? w1s : w0s);
 #pragma unroll
         for (int c = 0; c < CPL; ++c) Qsum[c] = (Qsum[c] - EQ[c]) + ((c + SH) >= 8 ? w1q : w0q);
+        }
 
         if constexpr (SWEEP_A) {
 #pragma unroll
@@ -1081,6 +1139,10 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
                     it.S = (unsigned)Sv;
                     it.Q = (unsigned)Qv;
                     it.p = byte_of(pvb, c) | kRefApprox;
+                    if constexpr (QINT) {   // exact sums, as the integer loop queues them
+                        it.Q = c == 0 ? Qi[0] : c == 1 ? Qi[1] : c == 2 ? Qi[2] : c == 3 ? Qi[3] : c == 4 ? Qi[4] : c == 5 ? Qi[5] : c == 6 ? Qi[6] : Qi[7];
+                        it.p = byte_of(pvb, c);
+                    }
                     full |= ref_push(rl, counters, g, wid, it);
                 }
             }
@@ -1091,7 +1153,8 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             if (!FAST && fp.bit_out) {
                 unsigned b = (((lo & 0x01010101u) * 0x01020408u) >> 24) | ((((hi & 0x01010101u) * 0x01020408u) >> 20) & 0xf0u);
                 if (EDGE && !full8) b &= (1u << (tp.ow - x0)) - 1u;  // pixels past the row end stay 0
-                out[(size_t)y * ostep + (x0 >> 3)] = (uint8_t)b;
+                if constexpr (QINT) buf_store_u8((unsigned char)b, clip_rsrc(orow, -1), x0 >> 3, 0, 0);   // (no 64-bit address per row)
+                else out[(size_t)y * ostep + (x0 >> 3)] = (uint8_t)b;
             } else if (!FAST && clip4) {
                 i32x2 o = {(int)lo, (int)hi};
                 buf_store_x2(o, clip_rsrc(orow, xlim), x0, 0, 2);   // aux 2: non-temporal
@@ -1350,6 +1413,84 @@ __global__ void __launch_bounds__(256) k_fused_exact(PageSet src, PageSetOut dst
     else
         strip_loop<METHOD, SH, true, WIDE, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, nullptr, nullptr, counters,
                                                  fp.ext && strip == fp.n_strips - 1, xo);
+}
+
+// ---- the threshold sweep for windows of 32 .. 181 columns with float window rows ("next" 7; strip_loop_f<..., QINT>) -----
+// k_fused's wavefront -> strip / segment mapping; interior strips take the float loop with integer horizontal Q sums, the border
+// strips the float loop's border form, the extended last one the integer loop.  Sauvola, Niblack, NICK, Wolf-Jolion's threshold sweep.  Its own
+// kernel name: the instantiations of k_fused keep theirs (tests/test_frozen_loop.py).
+template <int METHOD, int SH>
+__global__ void __launch_bounds__(256) k_fused_q(PageSet src, PageSetOut dst, FusedParams fp, PageGlobals* __restrict__ g,
+                                                RefItem* __restrict__ rl, WorkItem* __restrict__ cand, unsigned* __restrict__ counters,
+                                                int edge_float)
+{
+    const ThrParams& tp = fp.tp;
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned wpb = blockDim.x >> 6;
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned wv = threadIdx.x >> 6;
+    unsigned u = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * wpb + wv);
+    unsigned wid = 0;
+    int trows = 0, tsegs = 1, trow0 = 0;
+    bool found = false;
+    for (int k = 0; k < fp.n_tiers; ++k) {
+        const unsigned n = fp.tier[k].waves;
+        const unsigned lo = (unsigned)(((unsigned long long)n * xcd) >> 3), hi = (unsigned)(((unsigned long long)n * (xcd + 1u)) >> 3);
+        if (u < hi - lo) {
+            wid = lo + u;
+            trows = fp.tier[k].rows; tsegs = fp.tier[k].segs; trow0 = fp.tier[k].row0;
+            found = true;
+            u = fp.tier[k].first;
+            break;
+        }
+        u -= hi - lo;
+    }
+    if (!found) return;
+    const int per_page = fp.n_strips * tsegs;
+    const int page = (int)(wid / (unsigned)per_page);
+    const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
+    const int seg = rem / fp.n_strips;
+    const int strip = rem - seg * fp.n_strips;
+    wid += u;
+    if (__hip_atomic_load(&g[page].worklist_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) return;   // (as k_fused)
+    gcptr img = (gcptr)src.page(page);
+    gptr out = (gptr)dst.page(page);
+    const int xs = strip * fp.uo;
+    const int ys = trow0 + seg * trows;
+    const int ye = min(ys + trows, tp.oh);
+    PageK pk;
+    pk.c1 = fp.c1;
+    pk.imin = 0.0f;
+    pk.p0 = -0.5f * kZ;
+    pk.eps1 = fp.eps1;
+    if (METHOD == PRL_WOLFJOLION) {   // (k_fused's arithmetic: the coefficient from sweep A's float32 maximum, the margin widened by what it can be off)
+        pk.imin = (float)g[page].imin * kZ;
+        const float kmax = __uint_as_float(g[page].v32max_bits);
+        const float klow = kmax / (1.0f + fp.rho) - fp.kabs;
+        const float fl = (float)tp.f;
+        if (klow > fp.vthr32 && klow > 64.0f * fp.ev2) {
+            const float c = (float)tp.k / (__builtin_amdgcn_sqrtf(kmax) * fl);
+            const float delta = 0.51f * fp.rho + (0.26f * fp.ev2 + 0.51f * fp.kabs) / klow + 4.8e-7f;
+            const float ac = fabsf(c) * (1.0f + delta);
+            pk.c1 = c * fl;
+            pk.eps1 = fp.eps1 + kZ * (2.02f * 255.0f * ac * fp.es_max + 1.02f * 255.0f * fabsf((float)tp.k) * delta);
+        } else {
+            pk.c1 = 0.0f;
+            pk.eps1 = __builtin_inff();
+        }
+    }
+    const int first_col = xs + 1 - tp.half;
+    const bool interior = (first_col >= 0) && (first_col + SW <= tp.width) && (xs + fp.uo <= tp.ow);
+    const bool fast = !fp.bit_out && fp.nt_store && !fp.need_p0 && !(fp.uo & 7);   // (as k_fused: wave-uniform, once per wavefront)
+    if (interior) {
+        if (fast) strip_loop_f<METHOD, SH, 4, true, false, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
+        else strip_loop_f<METHOD, SH, 4, false, false, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
+    } else if (!edge_float || (fp.ext && strip == fp.n_strips - 1)) {   // (the extended last strip: the lanes beyond the wavefront are the integer loop's business)
+        strip_loop<METHOD, SH, true, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters,
+                                            fp.ext && strip == fp.n_strips - 1);
+    } else {
+        strip_loop_f<METHOD, SH, 4, false, true, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
+    }
 }
 
 // ---- second stage: float64 interval test of the queued pixels ------------------------------------------------------
@@ -1985,6 +2126,25 @@ template <int METHOD>
 int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
                  PageGlobals* g, RefItem* rl, WorkItem* cand, unsigned* cnt)
 {
+    if constexpr (METHOD == PRL_SAUVOLA || METHOD == PRL_NIBLACK || METHOD == PRL_NICK || METHOD == PRL_WOLFJOLION) {
+        // windows of 33 .. 129 columns: float window rows, integer horizontal Q sums (k_fused_q); typed loads address a page with
+        // 32-bit offsets
+        const int n1 = fp.tp.w - 1;
+        if (env_knobs().fused_qint && !fp.flt && n1 > 30 && n1 <= 128 && !(n1 & 1) &&
+            (unsigned long long)src.step * (unsigned long long)fp.tp.height < 0x7fffffffull) {
+            const dim3 grid(8u * fp.xcd_waves), block(64);
+            const int ef = env_knobs().fused_qint >= 2 ? 1 : 0;
+            switch (sh) {
+            case 0: hipLaunchKernelGGL((k_fused_q<METHOD, 0>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt, ef); break;
+            case 2: hipLaunchKernelGGL((k_fused_q<METHOD, 2>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt, ef); break;
+            case 4: hipLaunchKernelGGL((k_fused_q<METHOD, 4>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt, ef); break;
+            case 6: hipLaunchKernelGGL((k_fused_q<METHOD, 6>), grid, block, 0, stream, src, dst, fp, g, rl, cand, cnt, ef); break;
+            default: return PRL_ERR_BAD_ARG;
+            }
+            PRL_HIP_CHECK(hipGetLastError());
+            return PRL_OK;
+        }
+    }
     // wavefronts are independent; one per workgroup schedules best (256 x 4K pages: 4 per workgroup 4.38 ms, 2: 4.18,
     // 1: 4.13 - a finished wavefront's slot is refilled at once instead of when its whole workgroup has drained)
     unsigned wpb = 1u;

@@ -82,6 +82,7 @@ const EnvKnobs& env_knobs()
         if (k.rows_per_seg) k.rows_per_seg = std::max(4, k.rows_per_seg);
         k.tiers = !is0("PRL_HIP_TIERS");
         k.ext_strip = !is0("PRL_HIP_EXT_STRIP");
+        k.fused_qint = (int)geti("PRL_HIP_FUSED_QINT", 2);
         k.ragged_uo = !is0("PRL_HIP_RAGGED_UO");
         k.wolf_side = !is0("PRL_HIP_WOLF_SIDE");
         k.wolf_tier_max = (int)std::max(32ll, std::min(512ll, geti("PRL_HIP_WOLF_TIER_MAX", 128)));

@@ -104,6 +104,7 @@ struct EnvKnobs {
     int rows_per_seg = 0;         // PRL_HIP_ROWS_PER_SEG (0 = chosen from the batch size)
     bool tiers = true;            // PRL_HIP_TIERS=0      one segment length for the whole call (A/B of the tiered schedule)
     bool ext_strip = true;        // PRL_HIP_EXT_STRIP=0  no extended last strip (binarize_fused.hip strip_layout)
+    int fused_qint = 2;           // PRL_HIP_FUSED_QINT=0 windows of 33..129 columns stay on k_fused's integer loop (1: k_fused_q for interior strips only, 2: border strips too)
     bool ragged_uo = true;        // PRL_HIP_RAGGED_UO=0  outputs per strip always a multiple of 8
     bool wolf_side = true;        // PRL_HIP_WOLF_SIDE=0  Wolf-Jolion on one stream, the threshold sweep after the literal devianceMax (round-3 schedule)
     int wolf_tier_max = 128;      // PRL_HIP_WOLF_TIER_MAX longest row segment of a tiered Wolf-Jolion call (profiles/r03/wolf_tier_max.txt)

@@ -643,6 +643,53 @@ print("MISMATCH", bad)
     assert "MISMATCH 0" in r.stdout, r.stdout + r.stderr
 
 
+def test_wide_windows_float_rows_kernel_equals_the_integer_loop_and_the_oracle():
+    """k_fused_q (windows of 33..129 columns: float window rows, integer horizontal Q sums - VERDICT r5 "next" 7) is the default for
+    Sauvola / Niblack / NICK / Wolf-Jolion's threshold sweep.  A child per setting of PRL_HIP_FUSED_QINT (hooks build: 0 = k_fused's
+    integer loop, 1 = interior strips only, 2 = border strips too) binarizes the same pages - documents wide enough for interior
+    strips, a ragged width, a page of stripes sitting on their threshold (the queue receives exact sums), byte masks and bit
+    planes (morph != 0) - and prints a CRC per call; all three equal each other and the oracle."""
+    import subprocess
+    import sys
+
+    code = r'''
+import numpy as np, torch, sys, zlib
+sys.path.insert(0, %r)
+import prlib_amd, bench
+prlib_amd._capi.use_library(prlib_amd._capi.HOOKS_LIB_PATH)
+from oracle import capi as oc
+from prlib_amd import synth
+rng = np.random.default_rng(5)
+docs = [synth.page_numpy(700, 2100, index=3), synth.page_numpy(333, 1501, index=4), synth.text_page_numpy(900, 1300, 2, skew_deg=1.0)]
+noise = rng.integers(0, 256, (420, 1777)).astype(np.uint8)
+cases = []
+for method, w, k in ((0, 101, 0.34), (1, 101, 0.01), (3, 41, -0.1), (2, 101, 0.01), (0, 33, 0.2), (1, 129, 0.2), (0, 131, 0.34), (3, 75, -0.2)):
+    for morph in (0, 2):
+        for img in docs + [noise]:
+            cases.append((method, w, k, morph, img))
+adv = bench.adversarial_stripes(0, 51, 0.34, None)
+stripes = np.tile(np.array([adv[0], adv[1]], np.uint8), (600, 800))
+cases.append((0, 51, 0.34, 0, stripes))
+bad = 0
+crc = 0
+for method, w, k, morph, img in cases:
+    got = prlib_amd.binarize(torch.from_numpy(img).cuda(), prlib_amd.make_params(method, w, k, morph)).cpu().numpy()
+    want = oc.binarize(img, oc.make_params(method, w, k, morph))
+    bad += int((got != want).sum())
+    crc = zlib.crc32(got.tobytes(), crc)
+print("MISMATCH", bad, "CRC", crc, "CASES", len(cases))
+''' % ROOT
+    outs = []
+    for q in ("0", "1", "2"):
+        env = dict(os.environ, PRL_HIP_FUSED_QINT=q)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("MISMATCH")]
+        assert line and line[0].startswith("MISMATCH 0 "), (q, r.stdout + r.stderr)
+        outs.append(line[0])
+    assert outs[0] == outs[1] == outs[2], outs
+
+
 def test_deferred_completion_and_two_streams(prl, oracle, cuda_device):
     """prl_hip_set_deferred_completion(1): calls return after enqueuing, the per-page flags (and the literal redo of an
     overflowing page) are handled by later calls / prl_hip_finish.  Two torch streams use separate workspaces."""
