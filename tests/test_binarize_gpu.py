@@ -667,6 +667,10 @@ for method, w, k in ((0, 101, 0.34), (1, 101, 0.01), (3, 41, -0.1), (2, 101, 0.0
     for morph in (0, 2):
         for img in docs + [noise]:
             cases.append((method, w, k, morph, img))
+white = np.full((300, 1500), 255, np.uint8)   # the largest sums the float rows have to hold exactly: 128 x 65025 + 2^23 < 2^24, 64 x 8 x 128 x 255 < 2^24
+white[::7, ::5] = 254
+for method, w, k in ((1, 129, 0.2), (0, 129, 0.34), (3, 101, -0.1)):
+    cases.append((method, w, k, 0, white))
 adv = bench.adversarial_stripes(0, 51, 0.34, None)
 stripes = np.tile(np.array([adv[0], adv[1]], np.uint8), (600, 800))
 cases.append((0, 51, 0.34, 0, stripes))
