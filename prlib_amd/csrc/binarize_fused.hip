@@ -848,9 +848,12 @@ template <int METHOD, int SH, int LO, bool FAST, bool EDGE, bool QINT = false>
 __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, size_t ostep, const FusedParams& fp,
                                              int page, int xs, int ys, int ye, int lane, const PageK& pk, unsigned wid,
                                              PageGlobals* __restrict__ g, RefItem* __restrict__ rl,
-                                             unsigned* __restrict__ counters)
+                                             unsigned* __restrict__ counters, bool last_ext = false)
 {
     static_assert(!QINT || LO == 4, "QINT: the wavefront-scan form of the W chain");
+    // QINT && EDGE && last_ext: the extended last strip (strip_layout, strip_loop's `ext`): lane 63 and everything right of it is the
+    // replicated border column; the far lane is clamped to 63 and the totals of the lanes that do not exist - 8 V each - are added to W
+    const bool ext = QINT && EDGE && last_ext;
     constexpr bool SWEEP_A = METHOD == kWolfMax;  // Wolf-Jolion's variance-maximum sweep: sums and K~ only, no decision
     const ThrParams& tp = fp.tp;
     const int H = tp.height, h = tp.half, w = tp.w;
@@ -858,14 +861,15 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
     const int x0 = xs + CPL * lane;            // first output column of this lane
     // interior strips with uo a multiple of 8 (FAST): every lane below uo has its 8 outputs.  Otherwise the last lane with
     // outputs may hold fewer: the row ends (EDGE), or uo is not a multiple of 8 (strip_layout: a ragged uo that saves a strip)
-    const int xlim = min(xs + fp.uo, tp.ow);
+    const int xlim = ext ? tp.ow : min(xs + fp.uo, tp.ow);
     const bool lane_has_out = FAST ? CPL * lane < fp.uo : x0 < xlim;
     const bool full8 = FAST ? lane_has_out : x0 + CPL <= xlim;
     // LO 0..3: the number of whole lanes between a window's two edges, W gathered by that many DPP steps.  LO == 4 (sweep A
     // with wide windows): fp.lane_off lanes, W by doubling (see below)
     constexpr bool SCAN = LO == 4;
     const int loff = SCAN ? fp.lane_off : LO;
-    const int far_addr0 = (lane + loff) * 4, far_addr1 = far_addr0 + 4;
+    const int far_addr0 = QINT ? min(lane + loff, 63) * 4 : (lane + loff) * 4, far_addr1 = QINT ? min(lane + loff + 1, 63) * 4 : far_addr0 + 4;
+    [[maybe_unused]] const unsigned xn0 = ext ? 8u * (unsigned)max(lane + loff - 63, 0) : 0u, xn1 = ext ? 8u * (unsigned)max(lane + loff + 1 - 63, 0) : 0u;
     const i32x4 rsrc = page_rsrc(img);
     const int step = (int)istep;
     const EdgeFix ew = EDGE ? make_edge(col0, tp.width) : EdgeFix{0, 0u, 0u};
@@ -1011,6 +1015,14 @@ __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, 
             w1s = bpermf(far_addr1, ps) - ps;
             w0qi = (unsigned)__builtin_amdgcn_ds_bpermute(far_addr0, (int)pq) - pqb;
             w1qi = (unsigned)__builtin_amdgcn_ds_bpermute(far_addr1, (int)pq) - pqb;
+            if (ext) {   // wave-uniform.  n V: below 2^24 in float; the biased VQ brings its own share of qbias (8 per missing lane)
+                const float vs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(VS[CPL - 1]), 63));
+                const unsigned vq = (unsigned)__builtin_amdgcn_readlane(__float_as_int(VQ[CPL - 1]), 63);
+                w0s = fmaf((float)xn0, vs, w0s);
+                w1s = fmaf((float)xn1, vs, w1s);
+                w0qi += xn0 * vq;
+                w1qi += xn1 * vq;
+            }
         } else {
             // W over `loff` (5..16) lanes starting at this one: sums of 2, 4, 8 (16) consecutive lanes by doubling - the
             // operand of lane + 2^k comes through ds_bpermute (the LDS pipe has room, the vector ALU has not) - then the
@@ -1485,11 +1497,12 @@ __global__ void __launch_bounds__(256) k_fused_q(PageSet src, PageSetOut dst, Fu
     if (interior) {
         if (fast) strip_loop_f<METHOD, SH, 4, true, false, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
         else strip_loop_f<METHOD, SH, 4, false, false, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
-    } else if (!edge_float || (fp.ext && strip == fp.n_strips - 1)) {   // (the extended last strip: the lanes beyond the wavefront are the integer loop's business)
+    } else if (!edge_float) {
         strip_loop<METHOD, SH, true, false>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, cand, counters,
                                             fp.ext && strip == fp.n_strips - 1);
     } else {
-        strip_loop_f<METHOD, SH, 4, false, true, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters);
+        strip_loop_f<METHOD, SH, 4, false, true, true>(img, out, src.step, dst.step, fp, page, xs, ys, ye, lane, pk, wid, g, rl, counters,
+                                                       fp.ext && strip == fp.n_strips - 1);
     }
 }
 
