@@ -839,11 +839,12 @@ __device__ __forceinline__ float bpermf(int addr, float v)
 // come as packed bytes from a clamped address, are put in place by strip_loop's two v_perm_b32 and converted when the
 // slide uses them (16 conversions a row more than an interior strip, still a quarter fewer vector instructions than the
 // integer loop: 2 of the 9 strips of a 4096-column page, 2 of the 6 of an A4 page); partial stores at the row end.
-// QINT (k_fused_q, windows wider than 31 - VERDICT r5 "next" 7): pixels, column sums VS / VQ (<= 180 x 65025 < 2^24) and every S
-// quantity (<= 180 x 180 x 255 < 2^24) stay exact in float32; the column sums of squares are converted once per row
-// (v_cvt_u32_f32) and the HORIZONTAL Q sums - in-lane prefixes, the W chain, the window sum, which pass 2^24 - run on integers
-// like strip_loop's.  S and (float)Q reach eval32f with exactly the values the integer loop hands it: same decisions, same
-// margins, exact sums in the queue.  What is saved is the byte unpacking of the two window rows (46 SDWA instructions a row).
+// QINT (k_fused_q, windows of 33 .. 129 columns - VERDICT r5 "next" 7): pixels, the column sums VS / VQ (<= 128 x 65025 < 2^23) and
+// every S quantity (a wavefront scan value is at most 64 x 8 x 128 x 255 < 2^24) stay exact in float32; VQ lives as 2^23 + VQ, whose
+// bits are the integer 0x4B000000 + VQ (no conversion), and the HORIZONTAL Q sums - in-lane prefixes, the W chain, the window sum,
+// which pass 2^24 - run on integers like strip_loop's, the known multiple of 0x4B000000 taken off once per row.  S and (float)Q
+// reach eval32f with exactly the values the integer loop hands eval32: same decisions, same margins, exact sums in the queue.
+// What is saved is the byte unpacking of the two window rows (46 SDWA instructions a row): 713 issue cycles a row against 826-875.
 template <int METHOD, int SH, int LO, bool FAST, bool EDGE, bool QINT = false>
 __device__ __forceinline__ void strip_loop_f(gcptr img, gptr out, size_t istep, size_t ostep, const FusedParams& fp,
                                              int page, int xs, int ys, int ye, int lane, const PageK& pk, unsigned wid,
@@ -1427,7 +1428,7 @@ __global__ void __launch_bounds__(256) k_fused_exact(PageSet src, PageSetOut dst
                                                  fp.ext && strip == fp.n_strips - 1, xo);
 }
 
-// ---- the threshold sweep for windows of 32 .. 181 columns with float window rows ("next" 7; strip_loop_f<..., QINT>) -----
+// ---- the threshold sweep for windows of 33 .. 129 columns with float window rows ("next" 7; strip_loop_f<..., QINT>) -----
 // k_fused's wavefront -> strip / segment mapping; interior strips take the float loop with integer horizontal Q sums, the border
 // strips the float loop's border form, the extended last one the integer loop.  Sauvola, Niblack, NICK, Wolf-Jolion's threshold sweep.  Its own
 // kernel name: the instantiations of k_fused keep theirs (tests/test_frozen_loop.py).
