@@ -2144,7 +2144,7 @@ int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOu
         // windows of 33 .. 129 columns: float window rows, integer horizontal Q sums (k_fused_q); typed loads address a page with
         // 32-bit offsets
         const int n1 = fp.tp.w - 1;
-        if (env_knobs().fused_qint && !fp.flt && n1 > 30 && n1 <= 128 && !(n1 & 1) &&
+        if (env_knobs().fused_qint && env_knobs().flt && !fp.flt && n1 > 30 && n1 <= 128 && !(n1 & 1) &&
             (unsigned long long)src.step * (unsigned long long)fp.tp.height < 0x7fffffffull) {
             const dim3 grid(8u * fp.xcd_waves), block(64);
             const int ef = env_knobs().fused_qint >= 2 ? 1 : 0;
