@@ -1344,6 +1344,46 @@ __global__ void __launch_bounds__(256) k_fused(PageSet src, PageSetOut dst, Fuse
                                            fp.ext && strip == fp.n_strips - 1);
 }
 
+// k_fused's wavefront -> (page, strip, row segment) mapping for the kernels that share it (k_fused_exact, k_fused_q; k_fused keeps
+// its own copy inline - its code is frozen): XCD x = blockIdx & 7 takes the x-th eighth of every tier of segments, tier 0 first.
+struct WaveJob {
+    bool found;
+    int page, strip, ys, ye;
+    unsigned wid;   // canonical wavefront id over all tiers
+};
+__device__ __forceinline__ WaveJob find_wave_job(const FusedParams& fp)
+{
+    WaveJob j{};
+    const unsigned wpb = blockDim.x >> 6;
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned wv = threadIdx.x >> 6;
+    unsigned u = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * wpb + wv);
+    unsigned wid = 0;
+    int trows = 0, tsegs = 1, trow0 = 0;
+    for (int k = 0; k < fp.n_tiers; ++k) {
+        const unsigned n = fp.tier[k].waves;
+        const unsigned lo = (unsigned)(((unsigned long long)n * xcd) >> 3), hi = (unsigned)(((unsigned long long)n * (xcd + 1u)) >> 3);
+        if (u < hi - lo) {
+            wid = lo + u;
+            trows = fp.tier[k].rows; tsegs = fp.tier[k].segs; trow0 = fp.tier[k].row0;
+            j.found = true;
+            u = fp.tier[k].first;
+            break;
+        }
+        u -= hi - lo;
+    }
+    if (!j.found) return j;
+    const int per_page = fp.n_strips * tsegs;
+    j.page = (int)(wid / (unsigned)per_page);
+    const int rem = (int)(wid - (unsigned)j.page * (unsigned)per_page);
+    const int seg = rem / fp.n_strips;
+    j.strip = rem - seg * fp.n_strips;
+    j.wid = wid + u;
+    j.ys = trow0 + seg * trows;
+    j.ye = min(j.ys + trows, fp.tp.oh);
+    return j;
+}
+
 // ---- the second chance of a flagged page ("next" 2) ------------------------------------------------------------------
 // A page is flagged when the refine queue overflowed: more pixels inside the float32 decision band than the queue holds (pages
 // of stripes whose levels sit on their own threshold; DESIGN.md 6, worst_case.adversarial).  Those pixels are not undecidable -
@@ -1358,37 +1398,13 @@ __global__ void __launch_bounds__(256) k_fused_exact(PageSet src, PageSetOut dst
 {
     const ThrParams& tp = fp.tp;
     const int lane = threadIdx.x & (kWave - 1);
-    const unsigned wpb = blockDim.x >> 6;
-    const unsigned xcd = blockIdx.x & 7u;
-    const unsigned wv = threadIdx.x >> 6;
-    unsigned u = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * wpb + wv);
-    unsigned wid = 0;
-    int trows = 0, tsegs = 1, trow0 = 0;
-    bool found = false;
-    for (int k = 0; k < fp.n_tiers; ++k) {
-        const unsigned n = fp.tier[k].waves;
-        const unsigned lo = (unsigned)(((unsigned long long)n * xcd) >> 3), hi = (unsigned)(((unsigned long long)n * (xcd + 1u)) >> 3);
-        if (u < hi - lo) {
-            wid = lo + u;
-            trows = fp.tier[k].rows; tsegs = fp.tier[k].segs; trow0 = fp.tier[k].row0;
-            found = true;
-            u = fp.tier[k].first;
-            break;
-        }
-        u -= hi - lo;
-    }
-    if (!found) return;
-    const int per_page = fp.n_strips * tsegs;
-    const int page = (int)(wid / (unsigned)per_page);
-    const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
-    const int seg = rem / fp.n_strips;
-    const int strip = rem - seg * fp.n_strips;
-    wid += u;
+    const WaveJob job = find_wave_job(fp);
+    if (!job.found) return;
+    const int page = job.page, strip = job.strip, ys = job.ys, ye = job.ye;
+    const unsigned wid = job.wid;
     gcptr img = (gcptr)src.page(page);
     gptr out = (gptr)dst.page(page);
     const int xs = strip * fp.uo;
-    const int ys = trow0 + seg * trows;
-    const int ye = min(ys + trows, tp.oh);
     PageK pk;
     pk.c1 = fp.c1;
     pk.imin = 0.0f;
@@ -1439,38 +1455,14 @@ __global__ void __launch_bounds__(256) k_fused_q(PageSet src, PageSetOut dst, Fu
 {
     const ThrParams& tp = fp.tp;
     const int lane = threadIdx.x & (kWave - 1);
-    const unsigned wpb = blockDim.x >> 6;
-    const unsigned xcd = blockIdx.x & 7u;
-    const unsigned wv = threadIdx.x >> 6;
-    unsigned u = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * wpb + wv);
-    unsigned wid = 0;
-    int trows = 0, tsegs = 1, trow0 = 0;
-    bool found = false;
-    for (int k = 0; k < fp.n_tiers; ++k) {
-        const unsigned n = fp.tier[k].waves;
-        const unsigned lo = (unsigned)(((unsigned long long)n * xcd) >> 3), hi = (unsigned)(((unsigned long long)n * (xcd + 1u)) >> 3);
-        if (u < hi - lo) {
-            wid = lo + u;
-            trows = fp.tier[k].rows; tsegs = fp.tier[k].segs; trow0 = fp.tier[k].row0;
-            found = true;
-            u = fp.tier[k].first;
-            break;
-        }
-        u -= hi - lo;
-    }
-    if (!found) return;
-    const int per_page = fp.n_strips * tsegs;
-    const int page = (int)(wid / (unsigned)per_page);
-    const int rem = (int)(wid - (unsigned)page * (unsigned)per_page);
-    const int seg = rem / fp.n_strips;
-    const int strip = rem - seg * fp.n_strips;
-    wid += u;
+    const WaveJob job = find_wave_job(fp);
+    if (!job.found) return;
+    const int page = job.page, strip = job.strip, ys = job.ys, ye = job.ye;
+    const unsigned wid = job.wid;
     if (__hip_atomic_load(&g[page].worklist_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) return;   // (as k_fused)
     gcptr img = (gcptr)src.page(page);
     gptr out = (gptr)dst.page(page);
     const int xs = strip * fp.uo;
-    const int ys = trow0 + seg * trows;
-    const int ye = min(ys + trows, tp.oh);
     PageK pk;
     pk.c1 = fp.c1;
     pk.imin = 0.0f;
