@@ -230,8 +230,9 @@ __device__ __forceinline__ unsigned refine64(const FusedParams& fp, unsigned S, 
     if (!(v > 4.0 * Ev)) return 2;  // literal sqrt may be NaN / arbitrarily far
     const double s = sqrt(v);
     // |sqrt(v') - sqrt(v)| for |v' - v| <= Ev < v / 4 is at most Ev / sqrt(v - Ev) <= Ev / (0.866 s); the bound only has to hold,
-    // so it takes the hardware's reciprocal square root as it comes (v_rsq_f64: 2^-23 relative, ISA guide) with the slack in the
-    // constant - 1.16 (1 - 2^-20) > 1.001 / 0.866 - instead of a second correctly rounded square root and a division: a third of
+    // so it takes the hardware's reciprocal square root as it comes (v_rsq_f64: within 5.3e-8 = 2^-24.2 of 1 / sqrt(v) over 6.7e7
+    // arguments, tools/ubench/rsq64.hip, profiles/r06/v_rsq_f64_accuracy.json) with the slack in the constant - 1.16 leaves 0.36 %
+    // over 1.001 / 0.866 = 1.1559 - instead of a second correctly rounded square root and a division: a third of
     // this function's instructions, which is what bounds k_fused_exact on a page whose every pixel comes here
     const double Es = 1.16 * Ev * __builtin_amdgcn_rsq(v) + tiny * s;
     double T, ET;
