@@ -571,8 +571,8 @@ def main():
                 "shader_clock_ghz": clock["shader_clock_ghz"],
                 "simd_cycles_per_wavefront_row": simd_cycles_per_row(clock, args, W, g, n_mine),
                 "clock_note": clock["clock_note"],
-                # (windows of 33..129 columns of Sauvola / Niblack / NICK / Wolf-Jolion run their threshold sweep in k_fused_q)
-                "kernel": ("k_fused_q" if 32 <= args.window - 1 <= 128 and method in (0, 1, 2, 3) else "k_fused") if args.mode == "auto" else "literal chain",
+                # (windows of 33..129 columns run their threshold sweep in k_fused_q)
+                "kernel": ("k_fused_q" if 32 <= args.window - 1 <= 128 else "k_fused") if args.mode == "auto" else "literal chain",
                 "kernel_ms": round(kernel_ms, 4),
                 "call_ms": round(call_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,

@@ -1447,7 +1447,7 @@ __global__ void __launch_bounds__(256) k_fused_exact(PageSet src, PageSetOut dst
 
 // ---- the threshold sweep for windows of 33 .. 129 columns with float window rows ("next" 7; strip_loop_f<..., QINT>) -----
 // k_fused's wavefront -> strip / segment mapping; interior strips take the float loop with integer horizontal Q sums, the border
-// strips the float loop's border form, the extended last one the integer loop.  Sauvola, Niblack, NICK, Wolf-Jolion's threshold sweep.  Its own
+// strips the float loop's border form (the extended last one too).  Every method's threshold sweep.  Its own
 // kernel name: the instantiations of k_fused keep theirs (tests/test_frozen_loop.py).
 template <int METHOD, int SH>
 __global__ void __launch_bounds__(256) k_fused_q(PageSet src, PageSetOut dst, FusedParams fp, PageGlobals* __restrict__ g,
@@ -1469,7 +1469,11 @@ __global__ void __launch_bounds__(256) k_fused_q(PageSet src, PageSetOut dst, Fu
     pk.imin = 0.0f;
     pk.p0 = -0.5f * kZ;
     pk.eps1 = fp.eps1;
-    if (METHOD == PRL_WOLFJOLION) {   // (k_fused's arithmetic: the coefficient from sweep A's float32 maximum, the margin widened by what it can be off)
+    if (METHOD == PRL_FENG) {
+        const double imin = (double)g[page].imin;
+        const double c3 = (tp.k2 * imin + (-imin)) + 0.0;  // binarizeFeng.cpp:137 with r2 = c2 = 1 (as k_fused)
+        pk.p0 = (float)((-0.5 - c3) * (double)kZ);
+    } else if (METHOD == PRL_WOLFJOLION) {   // (k_fused's arithmetic: the coefficient from sweep A's float32 maximum, the margin widened by what it can be off)
         pk.imin = (float)g[page].imin * kZ;
         const float kmax = __uint_as_float(g[page].v32max_bits);
         const float klow = kmax / (1.0f + fp.rho) - fp.kabs;
@@ -2133,7 +2137,7 @@ template <int METHOD>
 int launch_sweep(int sh, hipStream_t stream, const PageSet& src, const PageSetOut& dst, const FusedParams& fp,
                  PageGlobals* g, RefItem* rl, WorkItem* cand, unsigned* cnt)
 {
-    if constexpr (METHOD == PRL_SAUVOLA || METHOD == PRL_NIBLACK || METHOD == PRL_NICK || METHOD == PRL_WOLFJOLION) {
+    if constexpr (METHOD == PRL_SAUVOLA || METHOD == PRL_NIBLACK || METHOD == PRL_NICK || METHOD == PRL_WOLFJOLION || METHOD == PRL_FENG) {
         // windows of 33 .. 129 columns: float window rows, integer horizontal Q sums (k_fused_q); typed loads address a page with
         // 32-bit offsets
         const int n1 = fp.tp.w - 1;

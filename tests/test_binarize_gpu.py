@@ -645,7 +645,7 @@ print("MISMATCH", bad)
 
 def test_wide_windows_float_rows_kernel_equals_the_integer_loop_and_the_oracle():
     """k_fused_q (windows of 33..129 columns: float window rows, integer horizontal Q sums - VERDICT r5 "next" 7) is the default for
-    Sauvola / Niblack / NICK / Wolf-Jolion's threshold sweep.  A child per setting of PRL_HIP_FUSED_QINT (hooks build: 0 = k_fused's
+    Sauvola / Niblack / NICK / Feng / Wolf-Jolion's threshold sweep.  A child per setting of PRL_HIP_FUSED_QINT (hooks build: 0 = k_fused's
     integer loop, 1 = interior strips only, 2 = border strips too) binarizes the same pages - documents wide enough for interior
     strips, a ragged width, a page of stripes sitting on their threshold (the queue receives exact sums), byte masks and bit
     planes (morph != 0) - and prints a CRC per call; all three equal each other and the oracle."""
@@ -663,7 +663,7 @@ rng = np.random.default_rng(5)
 docs = [synth.page_numpy(700, 2100, index=3), synth.page_numpy(333, 1501, index=4), synth.text_page_numpy(900, 1300, 2, skew_deg=1.0)]
 noise = rng.integers(0, 256, (420, 1777)).astype(np.uint8)
 cases = []
-for method, w, k in ((0, 101, 0.34), (1, 101, 0.01), (3, 41, -0.1), (2, 101, 0.01), (0, 33, 0.2), (1, 129, 0.2), (0, 131, 0.34), (3, 75, -0.2)):
+for method, w, k in ((0, 101, 0.34), (1, 101, 0.01), (3, 41, -0.1), (2, 101, 0.01), (0, 33, 0.2), (1, 129, 0.2), (0, 131, 0.34), (3, 75, -0.2), (4, 51, 0.2)):
     for morph in (0, 2):
         for img in docs + [noise]:
             cases.append((method, w, k, morph, img))
